@@ -1,0 +1,159 @@
+/*
+ * irn_hip.h — C ABI of libirn_hip.so: the MI355X (gfx950) implementation of IRN's pseudo-label
+ * hot path (inter-pixel affinity random walk + label epilogues + instance front-end).
+ *
+ * The reference (jiwoon-ahn/irn) is pure Python and has no FFI layer of its own; the seam this
+ * library sits behind is the reference's *operator tier* (SURVEY.md §8b):
+ *   misc/indexing.py            PathIndex, edge_to_affinity, affinity_sparse2dense,
+ *                               to_transition_matrix, propagate_to_edge
+ *   step/make_sem_seg_labels.py lines 43-49   (x4 upsample, /max, bg plane, argmax, keys LUT)
+ *   step/make_ins_seg_labels.py find_centroids_with_refinement, cluster_centroids,
+ *                               separte_score_by_mask, lines 137-147
+ * Each entry point below names the reference lines it replaces.  A reference-side binding is a
+ * ctypes stub; irn_amd/_lib.py is the one this repo ships.
+ *
+ * Conventions
+ *   - every function returns an int status (IRN_OK = 0); irn_last_error() gives the message of
+ *     the calling thread's last failure.  Nothing throws across the boundary.
+ *   - all `dev` pointers are caller-owned device memory (fp32 unless noted), contiguous,
+ *     row-major.  The library never allocates or frees device memory the caller can see;
+ *     scratch comes from the caller through a workspace pointer whose size the library reports.
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream); all work is
+ *     enqueued on it and nothing synchronises unless stated.
+ *   - one host thread per context; contexts are independent (one process per GPU, no
+ *     communication on the path — reference misc/torchutils.py:66-68 sharding).
+ */
+#ifndef IRN_HIP_H
+#define IRN_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define IRN_OK 0
+#define IRN_ERR_ARG 1          /* bad argument (null pointer, non-positive size, unsupported radius/beta) */
+#define IRN_ERR_HIP 2          /* a HIP runtime call or kernel launch failed */
+#define IRN_ERR_STATE 3        /* call order violated (e.g. run before configure / workspace too small) */
+
+#define IRN_MAX_RADIUS 16
+
+int irn_version(void);
+const char *irn_last_error(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * PathIndex  (replaces misc/indexing.py:6-56, `PathIndex.get_search_paths_dst`)
+ * order = 0: the reference's channel order (paths grouped by length, discovery order inside a
+ *            group) — the order of edge_to_affinity's channel axis and of `search_dst`;
+ * order = 1: raster (dy, dx) order — the plane order of the walk's internal weight table.
+ * irn_path_count reports sizes; irn_path_table fills host arrays:
+ *   dst_dydx   [n_dirs][2]   destination (dy,dx) of every direction
+ *   path_start [n_dirs+1]    CSR offsets into cells_dydx
+ *   cells_dydx [n_cells][2]  path cells, far-to-near (element 0 of a path is its destination)
+ * ------------------------------------------------------------------------------------------- */
+int irn_path_count(int radius, int *n_dirs, int *n_cells);
+int irn_path_table(int radius, int order, int32_t *dst_dydx, int32_t *path_start, int32_t *cells_dydx);
+
+/* ---------------------------------------------------------------------------------------------
+ * edge_to_affinity  (replaces misc/indexing.py:91-109 and the identical gather in
+ * net/resnet50_irn.py:162-175).  edge: dev [B, Hp, Wp]; aff: dev [B, n_dirs, (Hp-rf)*(Wp-2rf)],
+ * rf = radius-1, channel order 0 (reference).  aff[b,d,s] = 1 - max over path(d) of edge.
+ * No index tensors are built or uploaded (reference :58-88, :96-99).
+ * ------------------------------------------------------------------------------------------- */
+int irn_edge_to_affinity(const float *edge_dev, int batch, int hp, int wp, int radius,
+                         float *aff_dev, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Random-walk context  (replaces misc/indexing.py:141-165 `propagate_to_edge` and everything it
+ * calls: PathIndex :148, edge_to_affinity :151, affinity_sparse2dense :154, to_transition_matrix
+ * :160, the final matmul :164 — as sparse stencil sweeps, never densified).
+ *
+ * A context is bound to one radius and serves batches of independent images ("units").
+ *   irn_walk_create      host-side tables for `radius` are built and uploaded once
+ *   irn_walk_configure   describe a batch: n images with grid (h[i], w[i]) and c[i] walk channels
+ *                        (c = #classes for semantic labels, #classes x #instances for instance
+ *                        labels); returns the scratch bytes the batch needs
+ *   irn_walk_run         for every image i:  out[i][c,h,w] = (cam[i][c] * (1-edge[i])) . T_i^n_sweeps
+ *                        with T_i the column-normalised beta-powered affinity of edge[i]
+ *                        (n_sweeps = 2^exp_times).  Pointer arrays are HOST arrays of device
+ *                        pointers.  `inst_map` (optional, may be NULL or hold NULLs): per image an
+ *                        int32 [h,w] cluster map with k_inst[i] instances — then cam[i] is
+ *                        [c/k_inst, h, w] and channel (cls*k_inst + k) starts from
+ *                        cam[cls] * (inst_map == k)   (step/make_ins_seg_labels.py:77-80,:133).
+ * beta must be > 0 (beta == 0 would make the reference's dense matrix all-ones).
+ * ------------------------------------------------------------------------------------------- */
+typedef struct irn_walk_ctx irn_walk_ctx;
+
+int irn_walk_create(int radius, irn_walk_ctx **ctx_out);
+int irn_walk_destroy(irn_walk_ctx *ctx);
+int irn_walk_configure(irn_walk_ctx *ctx, int n_images, const int32_t *h, const int32_t *w,
+                       const int32_t *c, size_t *workspace_bytes);
+int irn_walk_run(irn_walk_ctx *ctx, const float *const *edge_dev, const float *const *cam_dev,
+                 const int32_t *const *inst_map_dev, const int32_t *k_inst,
+                 float *const *out_dev, float beta, int n_sweeps,
+                 void *workspace_dev, size_t workspace_bytes, void *stream);
+
+/* Tuning knobs (performance only, never results): name/value pairs, e.g. "variant" = 0 generic
+ * table-driven sweep, 1 = register-blocked sweep for radius 5/10 (default).  Unknown names fail. */
+int irn_walk_set_option(irn_walk_ctx *ctx, const char *name, int value);
+
+/* Kernel timing hook for bench.py: when enabled, irn_walk_run brackets the sweep kernels with HIP
+ * events on `stream`; irn_walk_last_sweep_ms synchronises those events and returns the summed
+ * sweep time and the number of sweep launches of the last run. */
+int irn_walk_enable_timing(irn_walk_ctx *ctx, int enable);
+int irn_walk_last_sweep_ms(irn_walk_ctx *ctx, float *ms, int *n_launches);
+
+/* Intermediate products of the last irn_walk_run, for parity tests of the build stage:
+ * weights of image i as [n_dirs, h, w] in raster direction order (order = 1) and 1/degree
+ * as fp64 [h, w], copied device-to-device out of the workspace. */
+int irn_walk_export_weights(irn_walk_ctx *ctx, int image, float *w_dev, double *inv_deg_dev,
+                            void *workspace_dev, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Label epilogue  (replaces step/make_sem_seg_labels.py:43-49 and
+ * step/make_ins_seg_labels.py:137-145).  For every image: bilinear x4 upsample
+ * (align_corners=False) of rw [c,h,w] cropped to (out_h,out_w); divide by the global max;
+ * argmax over {bg_thres, channels} with the first maximum winning.
+ *   labels_dev[i]  uint8 [out_h,out_w] = 0 for background else keys[i][argmax-1]+1
+ *                  (keys: host array of device int64 pointers, the CAM dict's `keys`); may be NULL
+ *   argmax_dev[i]  int32 [out_h,out_w] raw argmax index (0 = background); may be NULL
+ *   rw_up_dev[i]   fp32 [c,out_h,out_w] normalised upsampled scores (instance scoring); may be NULL
+ * scratch: n_images * 4 bytes of device memory (per-image max), provided by the caller.
+ * ------------------------------------------------------------------------------------------- */
+int irn_label_epilogue(int n_images, const float *const *rw_dev, const int32_t *c, const int32_t *h,
+                       const int32_t *w, const int32_t *out_h, const int32_t *out_w, float bg_thres,
+                       const int64_t *const *keys_dev, uint8_t *const *labels_dev,
+                       int32_t *const *argmax_dev, float *const *rw_up_dev, void *scratch_dev,
+                       void *stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Instance front-end
+ *   irn_find_centroids   replaces step/make_ins_seg_labels.py:18-56
+ *       dp dev [2,h,w] -> centroids dev int32 [2,h,w]; float32 state, float64 increment in the
+ *       reference's operation order, no FMA contraction, round-half-even at the end.
+ *   irn_cluster_centroids replaces step/make_ins_seg_labels.py:58-75 (+ misc/imutils.py:182-190):
+ *       weak = |dp| < thres; 4-connected components numbered in raster order of first pixel;
+ *       label at each pixel's centroid; renumbered 0..K-1 ascending.
+ *       -> cluster_map dev int32 [h,w], *k_out (host) = K.  Synchronises `stream` (K is returned).
+ *       scratch: irn_cluster_scratch_bytes(h, w) bytes.
+ * ------------------------------------------------------------------------------------------- */
+int irn_find_centroids(const float *dp_dev, int h, int w, int iterations, int32_t *centroids_dev,
+                       void *stream);
+size_t irn_cluster_scratch_bytes(int h, int w);
+int irn_cluster_centroids(const int32_t *centroids_dev, const float *dp_dev, int h, int w, float thres,
+                          int32_t *cluster_map_dev, int *k_out, void *scratch_dev, void *stream);
+
+/* 4-connected component labelling of a byte mask [n,h,w] (non-zero = foreground), ids 1.. per
+ * image in raster order of first pixel, 0 = background — the skimage.measure.label(connectivity=1,
+ * background=0) call of step/make_ins_seg_labels.py:66,92.  n_labels_dev: int32 [n] component
+ * counts.  scratch: irn_ccl_scratch_bytes(n,h,w). */
+size_t irn_ccl_scratch_bytes(int n, int h, int w);
+int irn_label4(const uint8_t *mask_dev, int n, int h, int w, int32_t *labels_dev, int32_t *n_labels_dev,
+               void *scratch_dev, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* IRN_HIP_H */

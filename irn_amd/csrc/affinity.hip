@@ -1,0 +1,171 @@
+// Path-max affinity kernel (gfx950).
+//
+// Replaces reference misc/indexing.py:91-109 (`edge_to_affinity`: 9-20 index_select + max_pool2d
+// launches over int64 index tensors) by one kernel that stages an edge tile with its radial halo in
+// LDS and walks the (dy,dx) path table itself.  Two instantiations:
+//   POW=false : aff = 1 - max(edge over path)          (API form, reference channel order)
+//   POW=true  : w   = fp32(aff ** beta)                (walk weight table, raster plane order;
+//               fuses the Hadamard power of misc/indexing.py:133)
+//
+// Roofline: per source pixel the kernel reads n_cells LDS words (242 at r=5, 2134 at r=10) and writes
+// n_dirs floats (34 / 152) — one pass, LDS-issue bound; it runs once per image against 2^exp_times
+// sweeps of the walk, so it is <2 % of the path.
+#include "kernels.hpp"
+
+namespace irn {
+
+namespace {
+
+constexpr int AFF_TH = 8;    // source rows per workgroup
+constexpr int AFF_TW = 32;   // source cols per workgroup (one wave covers two rows)
+
+__device__ __forceinline__ float pow_beta(float a, float beta, int beta_int) {
+    // torch.pow(fp32, beta) is a <=1-ulp powf; the fp64 power rounded once to fp32 is the
+    // correctly rounded value and so agrees with it to 1 ulp.
+    double b = (double)a;
+    if (beta_int > 0) {
+        double r = 1.0;
+        int e = beta_int;
+        while (e) {
+            if (e & 1) r *= b;
+            b *= b;
+            e >>= 1;
+        }
+        return (float)r;
+    }
+    return (float)pow(b, (double)beta);
+}
+
+template <bool POW>
+__global__ __launch_bounds__(256) void affinity_kernel(const AffJob *__restrict__ jobs,
+                                                       const int *__restrict__ dir_start,
+                                                       const int *__restrict__ cell_dy,
+                                                       const int *__restrict__ cell_dx, int n_dirs,
+                                                       int radius, float beta, int beta_int) {
+    extern __shared__ float tile[];
+    const AffJob J = jobs[blockIdx.y];
+    const int tiles_x = (J.sw + AFF_TW - 1) / AFF_TW;
+    const int tiles_y = (J.sh + AFF_TH - 1) / AFF_TH;
+    if ((int)blockIdx.x >= tiles_x * tiles_y) return;
+    const int halo = radius - 1;
+    const int LW = AFF_TW + 2 * halo;
+    const int LH = AFF_TH + halo;
+    const int ty0 = ((int)blockIdx.x / tiles_x) * AFF_TH;
+    const int tx0 = ((int)blockIdx.x % tiles_x) * AFF_TW;
+
+    // stage the edge tile: rows [ty0, ty0+TH+halo), cols [tx0-halo, tx0+TW+halo) of the source
+    // rectangle, translated into the grid; anything outside the grid is a boundary (edge = 1),
+    // which is what the reference's F.pad(..., value=1.0) supplies (misc/indexing.py:150).
+    for (int i = threadIdx.x; i < LH * LW; i += 256) {
+        const int ly = i / LW, lx = i - ly * LW;
+        const int gy = J.oy + ty0 + ly;
+        const int gx = J.ox + tx0 + lx - halo;
+        float v = 1.0f;
+        if (gy < J.gh && gx >= 0 && gx < J.gw) v = J.edge[(long)gy * J.gw + gx];
+        tile[i] = v;
+    }
+    __syncthreads();
+
+    const int ly = threadIdx.x / AFF_TW, lx = threadIdx.x % AFF_TW;
+    const int sy = ty0 + ly, sx = tx0 + lx;
+    const bool valid = sy < J.sh && sx < J.sw;
+    const int base = ly * LW + lx + halo;
+    float *out = J.out + (long)sy * J.sw + sx;
+
+    for (int d = 0; d < n_dirs; ++d) {
+        const int k0 = dir_start[d], k1 = dir_start[d + 1];
+        float m = -INFINITY;
+        for (int k = k0; k < k1; ++k) m = fmaxf(m, tile[base + cell_dy[k] * LW + cell_dx[k]]);
+        float a = 1.0f - m;
+        if (POW) a = pow_beta(a, beta, beta_int);
+        if (valid) out[(long)d * J.plane_stride] = a;
+    }
+}
+
+}  // namespace
+
+int launch_affinity(const AffJob *jobs_dev, int n_jobs, int max_sh, int max_sw, const DeviceTable &tab,
+                    bool with_pow, float beta, hipStream_t stream) {
+    const int tiles = cdiv(max_sh, AFF_TH) * cdiv(max_sw, AFF_TW);
+    const int halo = tab.radius - 1;
+    const size_t lds = sizeof(float) * (AFF_TH + halo) * (AFF_TW + 2 * halo);
+    dim3 grid(tiles, n_jobs);
+    int beta_int = 0;
+    if (with_pow && beta == (float)(int)beta && beta >= 1.0f && beta <= 64.0f) beta_int = (int)beta;
+    if (with_pow)
+        hipLaunchKernelGGL(affinity_kernel<true>, grid, dim3(256), lds, stream, jobs_dev, tab.dir_start,
+                           tab.cell_dy, tab.cell_dx, tab.n_dirs, tab.radius, beta, beta_int);
+    else
+        hipLaunchKernelGGL(affinity_kernel<false>, grid, dim3(256), lds, stream, jobs_dev, tab.dir_start,
+                           tab.cell_dy, tab.cell_dx, tab.n_dirs, tab.radius, beta, beta_int);
+    IRN_LAUNCH_CHECK("affinity_kernel");
+    return IRN_OK;
+}
+
+}  // namespace irn
+
+// ------------------------------------------------------------------------------------------------
+// C ABI: path table + edge_to_affinity
+// ------------------------------------------------------------------------------------------------
+using namespace irn;
+
+extern "C" int irn_version(void) { return 100; }
+
+extern "C" const char *irn_last_error(void) { return last_error_slot().c_str(); }
+
+extern "C" int irn_path_count(int radius, int *n_dirs, int *n_cells) {
+    if (radius < 2 || radius > IRN_MAX_RADIUS || !n_dirs || !n_cells)
+        return fail(IRN_ERR_ARG, "irn_path_count: radius must be in [2,%d]", IRN_MAX_RADIUS);
+    PathTable t = build_path_table(radius, 0);
+    *n_dirs = t.n_dirs();
+    *n_cells = t.n_cells();
+    return IRN_OK;
+}
+
+extern "C" int irn_path_table(int radius, int order, int32_t *dst_dydx, int32_t *path_start,
+                              int32_t *cells_dydx) {
+    if (radius < 2 || radius > IRN_MAX_RADIUS || (order != 0 && order != 1) || !dst_dydx || !path_start ||
+        !cells_dydx)
+        return fail(IRN_ERR_ARG, "irn_path_table: bad argument");
+    PathTable t = build_path_table(radius, order);
+    for (int i = 0; i < t.n_dirs(); ++i) {
+        dst_dydx[2 * i] = t.dy[i];
+        dst_dydx[2 * i + 1] = t.dx[i];
+    }
+    for (int i = 0; i <= t.n_dirs(); ++i) path_start[i] = t.start[i];
+    for (int i = 0; i < t.n_cells(); ++i) {
+        cells_dydx[2 * i] = t.cy[i];
+        cells_dydx[2 * i + 1] = t.cx[i];
+    }
+    return IRN_OK;
+}
+
+extern "C" int irn_edge_to_affinity(const float *edge_dev, int batch, int hp, int wp, int radius,
+                                    float *aff_dev, void *stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!edge_dev || !aff_dev || batch < 1 || radius < 2 || radius > IRN_MAX_RADIUS)
+        return fail(IRN_ERR_ARG, "irn_edge_to_affinity: bad argument");
+    const int rf = radius - 1;
+    const int sh = hp - rf, sw = wp - 2 * rf;
+    if (sh < 1 || sw < 1)
+        return fail(IRN_ERR_ARG, "irn_edge_to_affinity: grid %dx%d too small for radius %d", hp, wp, radius);
+    const DeviceTable *tab = nullptr;
+    int rc = get_device_table(radius, 0, &tab);
+    if (rc) return rc;
+    // job descriptors live in a small device buffer owned by the table cache (library-private)
+    std::vector<AffJob> jobs(batch);
+    const long ns = (long)sh * sw;
+    for (int b = 0; b < batch; ++b) {
+        AffJob &j = jobs[b];
+        j.edge = edge_dev + (long)b * hp * wp;
+        j.out = aff_dev + (long)b * tab->n_dirs * ns;
+        j.gh = hp; j.gw = wp; j.oy = 0; j.ox = rf; j.sh = sh; j.sw = sw;
+        j.plane_stride = ns;
+    }
+    AffJob *jobs_dev = nullptr;
+    rc = scratch_upload(jobs.data(), sizeof(AffJob) * batch, (void **)&jobs_dev, stream);
+    if (rc) return rc;
+    rc = launch_affinity(jobs_dev, batch, sh, sw, *tab, false, 0.f, stream);
+    if (rc) return rc;
+    return scratch_release(stream);
+}

@@ -1,0 +1,39 @@
+// Device-side descriptors and launch prototypes shared by the .hip translation units.
+#pragma once
+#include "common.hpp"
+
+namespace irn {
+
+// Path table resident in device memory (library-private, immutable after upload).
+struct DeviceTable {
+    int radius = 0, order = 0, n_dirs = 0, n_cells = 0;
+    int *dir_dy = nullptr, *dir_dx = nullptr;   // [n_dirs]
+    int *dir_start = nullptr;                   // [n_dirs+1]
+    int *cell_dy = nullptr, *cell_dx = nullptr; // [n_cells]
+    PathTable host;
+};
+
+// cached per (radius, order) for the life of the process; uploaded on the calling thread's device
+int get_device_table(int radius, int order, const DeviceTable **out);
+
+// Copy `bytes` of host data into a library-private device scratch buffer (grown on demand) with
+// stream order.  The returned pointer stays valid until the next scratch_upload on this thread.
+int scratch_upload(const void *host, size_t bytes, void **dev_out, hipStream_t stream);
+// Record, on `stream`, that the kernels reading the scratch have been enqueued; the next
+// scratch_upload waits for them before it overwrites the buffers.
+int scratch_release(hipStream_t stream);
+
+// One grid handed to the affinity kernel.
+struct AffJob {
+    const float *edge;   // [gh, gw]
+    float *out;          // plane 0, element of source pixel (0,0)
+    int gh, gw;          // grid the edge lives on
+    int oy, ox;          // origin of the source rectangle inside the grid
+    int sh, sw;          // source rectangle (output plane is [sh, sw] row-major)
+    long plane_stride;   // floats between consecutive direction planes
+};
+
+int launch_affinity(const AffJob *jobs_dev, int n_jobs, int max_sh, int max_sw, const DeviceTable &tab,
+                    bool with_pow, float beta, hipStream_t stream);
+
+}  // namespace irn

@@ -1,0 +1,91 @@
+// Library-private device state: path tables cached per (radius, order, device) and a small
+// stream-ordered upload scratch for descriptor arrays.
+#include <map>
+#include <mutex>
+#include <tuple>
+
+#include "kernels.hpp"
+
+namespace irn {
+
+namespace {
+std::mutex g_mu;
+std::map<std::tuple<int, int, int>, DeviceTable *> g_tables;
+
+template <typename T>
+int upload(const std::vector<T> &v, T **dev) {
+    IRN_HIP_TRY(hipMalloc((void **)dev, sizeof(T) * v.size()));
+    IRN_HIP_TRY(hipMemcpy(*dev, v.data(), sizeof(T) * v.size(), hipMemcpyHostToDevice));
+    return IRN_OK;
+}
+
+struct Scratch {
+    void *dev = nullptr;
+    void *host = nullptr;    // pinned
+    size_t cap = 0;
+    hipEvent_t ev = nullptr;
+    int device = -1;
+};
+thread_local Scratch t_scratch;
+}  // namespace
+
+int get_device_table(int radius, int order, const DeviceTable **out) {
+    int dev = 0;
+    IRN_HIP_TRY(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lk(g_mu);
+    auto key = std::make_tuple(radius, order, dev);
+    auto it = g_tables.find(key);
+    if (it != g_tables.end()) {
+        *out = it->second;
+        return IRN_OK;
+    }
+    DeviceTable *t = new DeviceTable();
+    t->radius = radius;
+    t->order = order;
+    t->host = build_path_table(radius, order);
+    t->n_dirs = t->host.n_dirs();
+    t->n_cells = t->host.n_cells();
+    int rc = upload(t->host.dy, &t->dir_dy);
+    if (!rc) rc = upload(t->host.dx, &t->dir_dx);
+    if (!rc) rc = upload(t->host.start, &t->dir_start);
+    if (!rc) rc = upload(t->host.cy, &t->cell_dy);
+    if (!rc) rc = upload(t->host.cx, &t->cell_dx);
+    if (rc) {
+        delete t;
+        return rc;
+    }
+    g_tables[key] = t;
+    *out = t;
+    return IRN_OK;
+}
+
+int scratch_upload(const void *host, size_t bytes, void **dev_out, hipStream_t stream) {
+    Scratch &s = t_scratch;
+    int dev = 0;
+    IRN_HIP_TRY(hipGetDevice(&dev));
+    if (s.ev) IRN_HIP_TRY(hipEventSynchronize(s.ev));   // previous user of the buffers is done with them
+    if (bytes > s.cap || dev != s.device) {
+        if (s.dev) (void)hipFree(s.dev);
+        if (s.host) (void)hipHostFree(s.host);
+        s.dev = s.host = nullptr;
+        const size_t cap = round_up(bytes, 4096);
+        IRN_HIP_TRY(hipMalloc(&s.dev, cap));
+        IRN_HIP_TRY(hipHostMalloc(&s.host, cap, hipHostMallocDefault));
+        s.cap = cap;
+        s.device = dev;
+        if (!s.ev) IRN_HIP_TRY(hipEventCreateWithFlags(&s.ev, hipEventDisableTiming));
+    }
+    memcpy(s.host, host, bytes);
+    IRN_HIP_TRY(hipMemcpyAsync(s.dev, s.host, bytes, hipMemcpyHostToDevice, stream));
+    *dev_out = s.dev;
+    return IRN_OK;
+}
+
+// Callers record completion of the kernels that read the scratch so the next upload can wait.
+int scratch_release(hipStream_t stream) {
+    Scratch &s = t_scratch;
+    if (s.ev) IRN_HIP_TRY(hipEventRecord(s.ev, stream));
+    return IRN_OK;
+}
+
+}  // namespace irn

@@ -1,0 +1,660 @@
+// Inter-pixel affinity random walk as sparse stencil sweeps (gfx950).
+//
+// Replaces reference misc/indexing.py:112-165: the reference densifies the affinity into an
+// (hw x hw) matrix on the host (:117-127), powers and column-normalises it (:133-135), squares it
+// exp_times times with dense sgemm (:136-137, 70 TFLOP per 512^2 image) and multiplies the CAMs in
+// (:164).  The operator has only 2|S|+1 non-zeros per row (|S| = 34 at radius 5, 152 at radius 10),
+// so the same product is 2^exp_times applications of
+//
+//     x'[c,p] = ( x[c,p] + sum_{d in S} w_d(p) x[c,p+d] + w_d(p-d) x[c,p-d] ) / deg(p)
+//
+// with w_d(p) = (1 - max_{path(d)} edge)^beta stored ONCE per unordered pixel pair (the matrix is
+// symmetric) as |S| planes of the image, and deg(p) = 1 + sum of the 2|S| weights touching p.
+//
+// Numerics (tests/test_precision_model.py): fp32 FMAs inside one neighbour row (<= 2R-1 terms),
+// row partials combined and normalised in fp64, state stored fp32.  This is as close to the exact
+// operator as full fp64 accumulation (1.5e-6) while the bulk arithmetic stays fp32; plain fp32
+// accumulation drifts 1.8e-4 over 256 sweeps and misses the 1e-4 parity bar.
+//
+// HBM layout per image (all in the caller's workspace):
+//   weights  |S| planes, plane d = [front_pad zeros][h*w floats][tail], plane_stride floats apart.
+//            front_pad >= (R-1)*w + (R-1) makes every "-d" read w_d(p-d) in range: rows above the
+//            image land in the zero pad, and a column that leaves the image wraps onto a pixel
+//            whose own +d neighbour is outside the image, i.e. onto a stored zero.
+//   inv_deg  fp64 [h*w]
+//   xa, xb   fp32 [C, h*w] ping-pong state
+//
+// Roofline of one sweep launch: streams the weight planes once from HBM (4*|S|*N bytes) plus
+// 8*C*N of state -> HBM-bound for C <= ~27 at radius 10.  The "-d" reads and tile
+// halos re-read bytes another workgroup already pulled; the block->XCD mapping keeps all tiles of
+// an image on one XCD so those hit its L2 instead of HBM.
+#include <algorithm>
+#include <mutex>
+#include <utility>
+
+#include "kernels.hpp"
+
+namespace irn {
+
+struct WalkImg {
+    const float *edge;   // [h,w]
+    const float *cam;    // [C/k_inst, h, w]
+    const int *inst;     // [h,w] cluster map or null
+    float *out;          // [C,h,w]
+    float *wts;          // plane 0 / pixel 0 (front pad lies before it)
+    double *inv_deg;     // [h*w]
+    float *xa, *xb;      // [C, h*w]
+    int h, w, C, k_inst;
+    long plane_stride;
+    int front_pad, n_dirs;
+};
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------
+// small per-pixel kernels (grid.y = image)
+// ---------------------------------------------------------------------------------------------
+
+__global__ __launch_bounds__(256) void zero_pad_kernel(const WalkImg *__restrict__ imgs, int n_dirs) {
+    const WalkImg I = imgs[blockIdx.y];
+    const int d = blockIdx.x;
+    if (d >= n_dirs) return;
+    float *plane = I.wts + (long)d * I.plane_stride;
+    for (int i = threadIdx.x; i < I.front_pad; i += 256) plane[-1 - i] = 0.f;
+    const long n = (long)I.h * I.w;
+    const long tail = I.plane_stride - I.front_pad - n;
+    for (long i = threadIdx.x; i < tail; i += 256) plane[n + i] = 0.f;
+}
+
+// deg(p) = 1 + sum_d [ w_d(p) + w_d(p-d) ] in fp64; stores 1/deg.  (Column sum of
+// misc/indexing.py:135; the unit diagonal of :123-126 keeps it >= 1.)
+__global__ __launch_bounds__(256) void degree_kernel(const WalkImg *__restrict__ imgs,
+                                                     const int *__restrict__ dir_dy,
+                                                     const int *__restrict__ dir_dx, int n_dirs) {
+    const WalkImg I = imgs[blockIdx.y];
+    const long n = (long)I.h * I.w;
+    const long p = (long)blockIdx.x * 256 + threadIdx.x;
+    if (p >= n) return;
+    const int y = (int)(p / I.w), x = (int)(p - (long)y * I.w);
+    double deg = 1.0;
+    for (int d = 0; d < n_dirs; ++d) {
+        const int dy = dir_dy[d], dx = dir_dx[d];
+        const float *plane = I.wts + (long)d * I.plane_stride;
+        deg += (double)plane[p];
+        const int yy = y - dy, xx = x - dx;
+        if (yy >= 0 && xx >= 0 && xx < I.w) deg += (double)plane[p - ((long)dy * I.w + dx)];
+    }
+    I.inv_deg[p] = 1.0 / deg;
+}
+
+// x0 = cam * (1 - edge)  (misc/indexing.py:162), optionally split by instance
+// (step/make_ins_seg_labels.py:77-80: channel cls*K+k = cam[cls] * (inst == k)).
+__global__ __launch_bounds__(256) void x0_kernel(const WalkImg *__restrict__ imgs, int to_out) {
+    const WalkImg I = imgs[blockIdx.y];
+    const long n = (long)I.h * I.w;
+    const long p = (long)blockIdx.x * 256 + threadIdx.x;
+    if (p >= n) return;
+    const float one_minus = 1.0f - I.edge[p];
+    const int k = I.inst ? I.k_inst : 1;
+    const int id = I.inst ? I.inst[p] : 0;
+    float *dst = to_out ? I.out : I.xa;
+    for (int c = 0; c < I.C; ++c) {
+        const int cls = c / k, kk = c - cls * k;
+        float v = I.cam[(long)cls * n + p];
+        if (I.inst) v = v * (id == kk ? 1.0f : 0.0f);
+        dst[(long)c * n + p] = v * one_minus;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// generic sweep: any radius, one pixel per thread, table-driven, full fp64 accumulation.
+// Correctness fallback (radius other than 5/10, images narrower than the radius) and the
+// on-device cross-check of the blocked kernel.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sweep_generic_kernel(const WalkImg *__restrict__ imgs,
+                                                            const int *__restrict__ dir_dy,
+                                                            const int *__restrict__ dir_dx, int n_dirs,
+                                                            int phase, int last) {
+    const WalkImg I = imgs[blockIdx.y];
+    const long n = (long)I.h * I.w;
+    const long p = (long)blockIdx.x * 256 + threadIdx.x;
+    if (p >= n) return;
+    const float *src = (phase & 1) ? I.xb : I.xa;
+    float *dst = last ? I.out : ((phase & 1) ? I.xa : I.xb);
+    const int y = (int)(p / I.w), x = (int)(p - (long)y * I.w);
+    const double inv = I.inv_deg[p];
+    for (int c = 0; c < I.C; ++c) {
+        const float *xc = src + (long)c * n;
+        double acc = (double)xc[p];
+        for (int d = 0; d < n_dirs; ++d) {
+            const int dy = dir_dy[d], dx = dir_dx[d];
+            const long off = (long)dy * I.w + dx;
+            const float *plane = I.wts + (long)d * I.plane_stride;
+            if (y + dy < I.h && x + dx >= 0 && x + dx < I.w) acc += (double)plane[p] * (double)xc[p + off];
+            if (y - dy >= 0 && x - dx >= 0 && x - dx < I.w) acc += (double)plane[p - off] * (double)xc[p - off];
+        }
+        dst[(long)c * n + p] = (float)(acc * inv);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// blocked sweep for radius R in {5, 10}
+// ---------------------------------------------------------------------------------------------
+constexpr int SW_TH = 16;   // tile rows
+constexpr int SW_TW = 64;   // tile cols; 16 threads x 4 pixels per row
+constexpr int SW_P = 4;
+
+typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));   // 4-byte-aligned dwordx4
+typedef float f4a __attribute__((ext_vector_type(4)));
+
+// Pointers read out of a descriptor in memory are generic ("flat") to the compiler; the hot loop
+// wants global_load with a scalar base + 32-bit lane offset, so say what they are.
+#define IRN_GLOBAL __attribute__((address_space(1)))
+typedef const float IRN_GLOBAL *gcf_t;
+typedef float IRN_GLOBAL *gf_t;
+typedef const double IRN_GLOBAL *gcd_t;
+typedef const f4u IRN_GLOBAL *gcf4_t;
+
+template <int R>
+struct Geo {
+    static constexpr int H = R - 1;                             // halo
+    static constexpr int LH = SW_TH + 2 * H;
+    static constexpr int WIN = ((SW_P + 2 * H + 3) / 4) * 4;     // x window per thread per row (floats)
+    static constexpr int LW = SW_TW - SW_P + WIN;                // LDS row length (multiple of 4)
+};
+
+template <int R>
+__host__ __device__ constexpr bool in_set(int dy, int dx) {     // (dy,dx) in S, dy >= 0
+    return dy == 0 ? (dx >= 1 && dx < R) : (dy < R && dx > -R && dx < R && dx * dx + dy * dy < R * R);
+}
+
+template <int R>
+__host__ __device__ constexpr int plane_of(int dy, int dx) {    // raster index of (dy,dx) in S
+    int n = 0;
+    for (int y = 0; y < R; ++y)
+        for (int x = -R + 1; x < R; ++x) {
+            if (y == dy && x == dx) return n;
+            if (in_set<R>(y, x)) ++n;
+        }
+    return -1;
+}
+
+struct BlockEnt {
+    int img, ty0, tx0, c0;   // img < 0 : idle block
+};
+
+// compile-time loop: f(integral_constant<int,0>) ... f(integral_constant<int,N-1>).  The neighbour
+// loops MUST be expanded at compile time (plane numbers, window offsets and the disc test all fold
+// to constants); `#pragma unroll` gives up on the 19x19 nest of radius 10.
+template <int... Is, typename F>
+__device__ __forceinline__ void static_for_impl(std::integer_sequence<int, Is...>, F &&f) {
+    (f(std::integral_constant<int, Is>{}), ...);
+}
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F &&f) {
+    static_for_impl(std::make_integer_sequence<int, N>{}, f);
+}
+
+template <int R, int CH>
+__device__ __forceinline__ void sweep_body(const WalkImg &I, const BlockEnt &B, const float *src_,
+                                           float *dst_, float *xs) {
+    using G = Geo<R>;
+    constexpr int H = G::H, LH = G::LH, LW = G::LW, WIN = G::WIN;
+    const int tid = threadIdx.x;
+    const int h = I.h, w = I.w;
+    const unsigned n = (unsigned)(h * w);
+    const gcf_t src = (gcf_t)src_ + (size_t)B.c0 * n;
+    const gf_t dst = (gf_t)dst_ + (size_t)B.c0 * n;
+
+    // ---- stage x tile + halo for CH channels (zero outside the image) ----
+    for (int i = tid; i < CH * LH * LW; i += 256) {
+        const int c = i / (LH * LW);
+        const int r = i - c * (LH * LW);
+        const int ly = r / LW, lx = r - ly * LW;
+        const int gy = B.ty0 - H + ly, gx = B.tx0 - H + lx;
+        float v = 0.f;
+        if (gy >= 0 && gy < h && gx >= 0 && gx < w) v = src[(unsigned)c * n + (unsigned)(gy * w + gx)];
+        xs[i] = v;
+    }
+    __syncthreads();
+
+    const int trow = tid / (SW_TW / SW_P);
+    const int tcol = (tid % (SW_TW / SW_P)) * SW_P;
+    const int y = B.ty0 + trow, x = B.tx0 + tcol;
+    const bool live = y < h && x < w;
+    const unsigned p0 = live ? (unsigned)(y * w + x) : 0u;   // lane offset (elements) into a plane
+    // Weight planes are read through a buffer resource: wave-uniform base in the descriptor, the
+    // plane/row offset in an SGPR, the lane offset p0 in one VGPR -> no per-load VALU address math.
+    // Record 0 is the start of plane 0's front pad.
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(
+        (void *)(I.wts - I.front_pad), 0, (int)(I.n_dirs * I.plane_stride * 4), 0x00020000);
+    const int voff = (int)(p0 * 4u);
+    const int ps4 = (int)(I.plane_stride * 4);
+    const int fp4 = I.front_pad * 4;
+
+    double acc[CH][SW_P];
+#pragma unroll
+    for (int c = 0; c < CH; ++c)
+#pragma unroll
+        for (int j = 0; j < SW_P; ++j) acc[c][j] = (double)xs[(c * LH + trow + H) * LW + tcol + H + j];
+
+    static_for<2 * H + 1>([&](auto iy) __attribute__((always_inline)) {
+        constexpr int ddy = decltype(iy)::value - H;      // neighbour row offset
+        float part[CH][SW_P];
+        float xw[CH][WIN];
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+            const f4a *row = reinterpret_cast<const f4a *>(&xs[(c * LH + trow + H + ddy) * LW + tcol]);
+#pragma unroll
+            for (int q = 0; q < WIN / 4; ++q) {
+                const f4a v = row[q];
+                xw[c][4 * q + 0] = v.x;
+                xw[c][4 * q + 1] = v.y;
+                xw[c][4 * q + 2] = v.z;
+                xw[c][4 * q + 3] = v.w;
+            }
+#pragma unroll
+            for (int j = 0; j < SW_P; ++j) part[c][j] = 0.f;
+        }
+        const int rowoff4 = ddy * w * 4;                   // wave-uniform, bytes
+        static_for<2 * H + 1>([&](auto ix) __attribute__((always_inline)) {
+            constexpr int ddx = decltype(ix)::value - H;  // neighbour column offset
+            constexpr bool fwd = ddy > 0 || (ddy == 0 && ddx > 0);       // neighbour p+d, weight at p
+            constexpr int sdy = fwd ? ddy : -ddy, sdx = fwd ? ddx : -ddx;  // the stored direction d
+            if constexpr (!(ddy == 0 && ddx == 0) && in_set<R>(sdy, sdx)) {
+                constexpr int pl = plane_of<R>(sdy, sdx);
+                // weight of the pair {p, p+(ddy,ddx)}: stored at p for a forward neighbour, at the
+                // neighbour itself (p + (ddy,ddx) = p - d) for a backward one.
+                const int soff = fp4 + pl * ps4 + (fwd ? 0 : rowoff4 + ddx * 4);
+                const f4a wv = __builtin_bit_cast(f4a, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, voff, soff, 0));
+                const float wj[4] = {wv.x, wv.y, wv.z, wv.w};
+#pragma unroll
+                for (int c = 0; c < CH; ++c)
+#pragma unroll
+                    for (int j = 0; j < SW_P; ++j) part[c][j] = fmaf(wj[j], xw[c][H + ddx + j], part[c][j]);
+            }
+        });
+#pragma unroll
+        for (int c = 0; c < CH; ++c)
+#pragma unroll
+            for (int j = 0; j < SW_P; ++j) {
+                acc[c][j] += (double)part[c][j];
+                // Pin this row's arithmetic here.  Pure ALU nodes carry no ordering and would
+                // otherwise sink to the end of the (single) basic block while the loads stay put,
+                // keeping every weight of the sweep live (512 registers + spills).
+                asm volatile("" : "+v"(acc[c][j]));
+            }
+        __builtin_amdgcn_sched_barrier(0);
+    });
+
+    if (!live) return;
+    const gcd_t inv_deg = (gcd_t)I.inv_deg;
+#pragma unroll
+    for (int j = 0; j < SW_P; ++j) {
+        if (x + j < w) {
+            const double inv = inv_deg[p0 + j];
+#pragma unroll
+            for (int c = 0; c < CH; ++c) dst[(unsigned)c * n + p0 + j] = (float)(acc[c][j] * inv);
+        }
+    }
+}
+
+template <int R, int CH>
+__global__ __launch_bounds__(256) void sweep_blocked_kernel(const WalkImg *__restrict__ imgs,
+                                                            const int4 *__restrict__ block_map, int phase,
+                                                            int last) {
+    extern __shared__ __attribute__((aligned(16))) float xs[];
+    const int4 e = block_map[blockIdx.x];
+    if (e.x < 0) return;
+    const WalkImg I = imgs[e.x];
+    const BlockEnt B{e.x, e.y, e.z, e.w};
+    const float *src = (phase & 1) ? I.xb : I.xa;
+    float *dst = last ? I.out : ((phase & 1) ? I.xa : I.xb);
+    sweep_body<R, CH>(I, B, src, dst, xs);
+}
+
+template <int R>
+constexpr size_t sweep_lds_bytes(int nch) {
+    return sizeof(float) * nch * Geo<R>::LH * Geo<R>::LW;
+}
+
+}  // namespace
+}  // namespace irn
+
+// ------------------------------------------------------------------------------------------------
+// context + C ABI
+// ------------------------------------------------------------------------------------------------
+using namespace irn;
+
+struct irn_walk_ctx {
+    int radius = 0;
+    const DeviceTable *tab = nullptr;   // raster order
+    int variant = 1;                    // 0 generic, 1 blocked (radius 5/10 only)
+    int xcd_map = 1;                    // keep all tiles of an image on one XCD
+    int max_chunk = 4;
+    // batch
+    int n = 0;
+    std::vector<int> h, w, c;
+    std::vector<size_t> off_wts, off_deg, off_xa, off_xb;   // byte offsets into the workspace
+    std::vector<long> plane_stride;
+    std::vector<int> front_pad;
+    size_t ws_bytes = 0;
+    int max_h = 0, max_w = 0, max_n = 0;
+    bool all_blocked_ok = false;
+    // device-side descriptor storage (library-private)
+    WalkImg *imgs_dev = nullptr;
+    AffJob *jobs_dev = nullptr;
+    int4 *map_dev = nullptr;
+    int cap_imgs = 0, cap_map = 0;
+    int cls_off[6] = {0, 0, 0, 0, 0, 0};   // block-map slice of channel-chunk class k: [cls_off[k], cls_off[k+1])
+    // pinned staging for the per-run descriptors (2 slots, guarded by events)
+    void *stage[2] = {nullptr, nullptr};
+    size_t stage_cap = 0;
+    hipEvent_t stage_ev[2] = {nullptr, nullptr};
+    int stage_next = 0;
+    // timing
+    int timing = 0;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    int last_launches = 0;
+    bool ev_valid = false;
+};
+
+extern "C" int irn_walk_create(int radius, irn_walk_ctx **ctx_out) {
+    if (!ctx_out || radius < 2 || radius > IRN_MAX_RADIUS)
+        return fail(IRN_ERR_ARG, "irn_walk_create: radius must be in [2,%d]", IRN_MAX_RADIUS);
+    const DeviceTable *tab = nullptr;
+    int rc = get_device_table(radius, 1, &tab);
+    if (rc) return rc;
+    irn_walk_ctx *c = new irn_walk_ctx();
+    c->radius = radius;
+    c->tab = tab;
+    c->variant = (radius == 5 || radius == 10) ? 1 : 0;
+    *ctx_out = c;
+    return IRN_OK;
+}
+
+extern "C" int irn_walk_destroy(irn_walk_ctx *ctx) {
+    if (!ctx) return IRN_OK;
+    if (ctx->imgs_dev) (void)hipFree(ctx->imgs_dev);
+    if (ctx->jobs_dev) (void)hipFree(ctx->jobs_dev);
+    if (ctx->map_dev) (void)hipFree(ctx->map_dev);
+    if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
+    if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    for (int k = 0; k < 2; ++k) {
+        if (ctx->stage[k]) (void)hipHostFree(ctx->stage[k]);
+        if (ctx->stage_ev[k]) (void)hipEventDestroy(ctx->stage_ev[k]);
+    }
+    delete ctx;
+    return IRN_OK;
+}
+
+extern "C" int irn_walk_set_option(irn_walk_ctx *ctx, const char *name, int value) {
+    if (!ctx || !name) return fail(IRN_ERR_ARG, "irn_walk_set_option: null argument");
+    if (!strcmp(name, "variant")) {
+        if (value == 1 && !(ctx->radius == 5 || ctx->radius == 10))
+            return fail(IRN_ERR_ARG, "blocked sweep exists for radius 5 and 10 only");
+        if (value < 0 || value > 1) return fail(IRN_ERR_ARG, "variant must be 0 or 1");
+        ctx->variant = value;
+    } else if (!strcmp(name, "xcd_map")) {
+        ctx->xcd_map = value ? 1 : 0;
+    } else if (!strcmp(name, "max_chunk")) {
+        if (value < 1 || value > 4) return fail(IRN_ERR_ARG, "max_chunk must be in [1,4]");
+        ctx->max_chunk = value;
+    } else {
+        return fail(IRN_ERR_ARG, "irn_walk_set_option: unknown option '%s'", name);
+    }
+    ctx->n = 0;   // force re-configure
+    return IRN_OK;
+}
+
+extern "C" int irn_walk_enable_timing(irn_walk_ctx *ctx, int enable) {
+    if (!ctx) return fail(IRN_ERR_ARG, "null ctx");
+    ctx->timing = enable ? 1 : 0;
+    if (enable && !ctx->ev0) {
+        IRN_HIP_TRY(hipEventCreate(&ctx->ev0));
+        IRN_HIP_TRY(hipEventCreate(&ctx->ev1));
+    }
+    return IRN_OK;
+}
+
+extern "C" int irn_walk_last_sweep_ms(irn_walk_ctx *ctx, float *ms, int *n_launches) {
+    if (!ctx || !ms || !n_launches) return fail(IRN_ERR_ARG, "null argument");
+    if (!ctx->ev_valid) return fail(IRN_ERR_STATE, "no timed run recorded");
+    IRN_HIP_TRY(hipEventSynchronize(ctx->ev1));
+    IRN_HIP_TRY(hipEventElapsedTime(ms, ctx->ev0, ctx->ev1));
+    *n_launches = ctx->last_launches;
+    return IRN_OK;
+}
+
+extern "C" int irn_walk_configure(irn_walk_ctx *ctx, int n_images, const int32_t *h, const int32_t *w,
+                                  const int32_t *c, size_t *workspace_bytes) {
+    if (!ctx || !h || !w || !c || !workspace_bytes || n_images < 1)
+        return fail(IRN_ERR_ARG, "irn_walk_configure: bad argument");
+    const int R = ctx->radius;
+    ctx->n = 0;
+    ctx->h.assign(h, h + n_images);
+    ctx->w.assign(w, w + n_images);
+    ctx->c.assign(c, c + n_images);
+    ctx->off_wts.resize(n_images);
+    ctx->off_deg.resize(n_images);
+    ctx->off_xa.resize(n_images);
+    ctx->off_xb.resize(n_images);
+    ctx->plane_stride.resize(n_images);
+    ctx->front_pad.resize(n_images);
+    size_t off = 0;
+    ctx->max_h = ctx->max_w = ctx->max_n = 0;
+    bool blocked_ok = ctx->variant == 1;
+    for (int i = 0; i < n_images; ++i) {
+        if (h[i] < 1 || w[i] < 1 || c[i] < 1 || c[i] > 0xffff)
+            return fail(IRN_ERR_ARG, "irn_walk_configure: image %d has invalid size %dx%d c=%d", i, h[i], w[i], c[i]);
+        const size_t npx = (size_t)h[i] * w[i];
+        const int fp = (int)round_up((size_t)(R - 1) * w[i] + (R - 1), 64);
+        const long ps = (long)round_up(fp + npx + 8, 64);
+        ctx->front_pad[i] = fp;
+        ctx->plane_stride[i] = ps;
+        ctx->off_wts[i] = off;
+        off += round_up(sizeof(float) * ps * ctx->tab->n_dirs, 256);
+        ctx->off_deg[i] = off;
+        off += round_up(sizeof(double) * npx, 256);
+        ctx->off_xa[i] = off;
+        off += round_up(sizeof(float) * npx * c[i] + 64, 256);
+        ctx->off_xb[i] = off;
+        off += round_up(sizeof(float) * npx * c[i] + 64, 256);
+        ctx->max_h = std::max(ctx->max_h, (int)h[i]);
+        ctx->max_w = std::max(ctx->max_w, (int)w[i]);
+        ctx->max_n = std::max(ctx->max_n, (int)npx);
+        if (w[i] < R) blocked_ok = false;   // the wrap-onto-a-zero argument needs w >= R
+    }
+    ctx->ws_bytes = off;
+    ctx->all_blocked_ok = blocked_ok;
+
+    // ---- block maps of the blocked sweep, one slice per channel-chunk width (1..4) ----
+    // Entry = (image, tile row0, tile col0, first channel).  Inside a slice, block b is meant for
+    // XCD b % 8 (observed dispatch order; speed only): every image is pinned to one XCD so that the
+    // halo / "-d" re-reads of its weight planes hit that XCD's L2.
+    std::vector<int4> map;
+    for (int k = 0; k < 6; ++k) ctx->cls_off[k] = 0;
+    if (blocked_ok) {
+        const int NX = ctx->xcd_map ? 8 : 1;
+        for (int cls = 1; cls <= 4; ++cls) {
+            ctx->cls_off[cls] = (int)map.size();
+            std::vector<std::vector<int4>> q(NX);
+            std::vector<size_t> load(NX, 0);
+            for (int i = 0; i < n_images; ++i) {
+                int best = 0;
+                for (int k = 1; k < NX; ++k)
+                    if (load[k] < load[best]) best = k;
+                for (int c0 = 0; c0 < c[i]; c0 += ctx->max_chunk) {
+                    const int nch = std::min(ctx->max_chunk, c[i] - c0);
+                    if (nch != cls) continue;
+                    for (int ty = 0; ty < h[i]; ty += SW_TH)
+                        for (int tx = 0; tx < w[i]; tx += SW_TW) {
+                            q[best].push_back(make_int4(i, ty, tx, c0));
+                            ++load[best];
+                        }
+                }
+            }
+            size_t depth = 0;
+            for (auto &v : q) depth = std::max(depth, v.size());
+            const size_t begin = map.size();
+            for (size_t s = 0; s < depth; ++s)
+                for (int k = 0; k < NX; ++k) map.push_back(s < q[k].size() ? q[k][s] : make_int4(-1, 0, 0, 0));
+            while (map.size() > begin && map.back().x < 0) map.pop_back();
+        }
+        ctx->cls_off[5] = (int)map.size();
+    }
+
+    if (n_images > ctx->cap_imgs) {
+        if (ctx->imgs_dev) (void)hipFree(ctx->imgs_dev);
+        if (ctx->jobs_dev) (void)hipFree(ctx->jobs_dev);
+        ctx->imgs_dev = nullptr;
+        ctx->jobs_dev = nullptr;
+        IRN_HIP_TRY(hipMalloc((void **)&ctx->imgs_dev, sizeof(WalkImg) * n_images));
+        IRN_HIP_TRY(hipMalloc((void **)&ctx->jobs_dev, sizeof(AffJob) * n_images));
+        ctx->cap_imgs = n_images;
+    }
+    const size_t stage_need = (sizeof(WalkImg) + sizeof(AffJob)) * (size_t)n_images;
+    if (stage_need > ctx->stage_cap) {
+        for (int k = 0; k < 2; ++k) {
+            if (ctx->stage[k]) (void)hipHostFree(ctx->stage[k]);
+            ctx->stage[k] = nullptr;
+            IRN_HIP_TRY(hipHostMalloc(&ctx->stage[k], stage_need, hipHostMallocDefault));
+            if (!ctx->stage_ev[k]) IRN_HIP_TRY(hipEventCreateWithFlags(&ctx->stage_ev[k], hipEventDisableTiming));
+        }
+        ctx->stage_cap = stage_need;
+    }
+    if ((int)map.size() > ctx->cap_map) {
+        if (ctx->map_dev) (void)hipFree(ctx->map_dev);
+        ctx->map_dev = nullptr;
+        IRN_HIP_TRY(hipMalloc((void **)&ctx->map_dev, sizeof(int4) * map.size()));
+        ctx->cap_map = (int)map.size();
+    }
+    if (!map.empty())
+        IRN_HIP_TRY(hipMemcpy(ctx->map_dev, map.data(), sizeof(int4) * map.size(), hipMemcpyHostToDevice));
+    ctx->n = n_images;
+    *workspace_bytes = ctx->ws_bytes;
+    return IRN_OK;
+}
+
+template <int R, int CH>
+static int launch_blocked_cls(irn_walk_ctx *ctx, int phase, int last, hipStream_t stream) {
+    const int nb = ctx->cls_off[CH + 1] - ctx->cls_off[CH];
+    if (nb <= 0) return IRN_OK;
+    hipLaunchKernelGGL((sweep_blocked_kernel<R, CH>), dim3(nb), dim3(256), sweep_lds_bytes<R>(CH), stream,
+                       ctx->imgs_dev, ctx->map_dev + ctx->cls_off[CH], phase, last);
+    IRN_LAUNCH_CHECK("sweep_blocked_kernel");
+    return IRN_OK;
+}
+
+template <int R>
+static int launch_blocked(irn_walk_ctx *ctx, int phase, int last, hipStream_t stream) {
+    int rc = launch_blocked_cls<R, 1>(ctx, phase, last, stream);
+    if (!rc) rc = launch_blocked_cls<R, 2>(ctx, phase, last, stream);
+    if (!rc) rc = launch_blocked_cls<R, 3>(ctx, phase, last, stream);
+    if (!rc) rc = launch_blocked_cls<R, 4>(ctx, phase, last, stream);
+    return rc;
+}
+
+extern "C" int irn_walk_run(irn_walk_ctx *ctx, const float *const *edge_dev, const float *const *cam_dev,
+                            const int32_t *const *inst_map_dev, const int32_t *k_inst,
+                            float *const *out_dev, float beta, int n_sweeps, void *workspace_dev,
+                            size_t workspace_bytes, void *stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!ctx || !edge_dev || !cam_dev || !out_dev || !workspace_dev)
+        return fail(IRN_ERR_ARG, "irn_walk_run: null argument");
+    if (ctx->n < 1) return fail(IRN_ERR_STATE, "irn_walk_run: irn_walk_configure has not been called");
+    if (workspace_bytes < ctx->ws_bytes)
+        return fail(IRN_ERR_STATE, "irn_walk_run: workspace of %zu bytes, %zu needed", workspace_bytes, ctx->ws_bytes);
+    if (!(beta > 0.f)) return fail(IRN_ERR_ARG, "irn_walk_run: beta must be > 0 (got %g)", (double)beta);
+    if (n_sweeps < 0) return fail(IRN_ERR_ARG, "irn_walk_run: n_sweeps must be >= 0");
+    if (((uintptr_t)workspace_dev & 255) != 0)
+        return fail(IRN_ERR_ARG, "irn_walk_run: workspace must be 256-byte aligned");
+
+    const int n = ctx->n;
+    const int slot = ctx->stage_next;
+    ctx->stage_next ^= 1;
+    IRN_HIP_TRY(hipEventSynchronize(ctx->stage_ev[slot]));   // previous upload from this slot has landed
+    WalkImg *imgs = (WalkImg *)ctx->stage[slot];
+    AffJob *jobs = (AffJob *)(imgs + n);
+    char *ws = (char *)workspace_dev;
+    for (int i = 0; i < n; ++i) {
+        if (!edge_dev[i] || !cam_dev[i] || !out_dev[i])
+            return fail(IRN_ERR_ARG, "irn_walk_run: null pointer for image %d", i);
+        WalkImg &I = imgs[i];
+        I.edge = edge_dev[i];
+        I.cam = cam_dev[i];
+        I.inst = (inst_map_dev && inst_map_dev[i]) ? inst_map_dev[i] : nullptr;
+        I.k_inst = (I.inst && k_inst) ? k_inst[i] : 1;
+        if (I.inst && (I.k_inst < 1 || ctx->c[i] % I.k_inst != 0))
+            return fail(IRN_ERR_ARG, "irn_walk_run: image %d: c=%d is not a multiple of k_inst=%d", i, ctx->c[i], I.k_inst);
+        I.out = out_dev[i];
+        I.wts = (float *)(ws + ctx->off_wts[i]) + ctx->front_pad[i];
+        I.inv_deg = (double *)(ws + ctx->off_deg[i]);
+        I.xa = (float *)(ws + ctx->off_xa[i]);
+        I.xb = (float *)(ws + ctx->off_xb[i]);
+        I.h = ctx->h[i];
+        I.w = ctx->w[i];
+        I.C = ctx->c[i];
+        I.plane_stride = ctx->plane_stride[i];
+        I.front_pad = ctx->front_pad[i];
+        I.n_dirs = ctx->tab->n_dirs;
+        AffJob &J = jobs[i];
+        J.edge = I.edge;
+        J.out = I.wts;
+        J.gh = I.h; J.gw = I.w; J.oy = 0; J.ox = 0; J.sh = I.h; J.sw = I.w;
+        J.plane_stride = I.plane_stride;
+    }
+    IRN_HIP_TRY(hipMemcpyAsync(ctx->imgs_dev, imgs, sizeof(WalkImg) * n, hipMemcpyHostToDevice, stream));
+    IRN_HIP_TRY(hipMemcpyAsync(ctx->jobs_dev, jobs, sizeof(AffJob) * n, hipMemcpyHostToDevice, stream));
+    IRN_HIP_TRY(hipEventRecord(ctx->stage_ev[slot], stream));
+
+    const DeviceTable &tab = *ctx->tab;
+    hipLaunchKernelGGL(zero_pad_kernel, dim3(tab.n_dirs, n), dim3(256), 0, stream, ctx->imgs_dev, tab.n_dirs);
+    IRN_LAUNCH_CHECK("zero_pad_kernel");
+    int rc = launch_affinity(ctx->jobs_dev, n, ctx->max_h, ctx->max_w, tab, true, beta, stream);
+    if (rc) return rc;
+    const int pix_blocks = cdiv(ctx->max_n, 256);
+    hipLaunchKernelGGL(degree_kernel, dim3(pix_blocks, n), dim3(256), 0, stream, ctx->imgs_dev, tab.dir_dy,
+                       tab.dir_dx, tab.n_dirs);
+    IRN_LAUNCH_CHECK("degree_kernel");
+    hipLaunchKernelGGL(x0_kernel, dim3(pix_blocks, n), dim3(256), 0, stream, ctx->imgs_dev, n_sweeps == 0 ? 1 : 0);
+    IRN_LAUNCH_CHECK("x0_kernel");
+
+    const bool blocked = ctx->variant == 1 && ctx->all_blocked_ok;
+    if (ctx->timing) IRN_HIP_TRY(hipEventRecord(ctx->ev0, stream));
+    for (int t = 0; t < n_sweeps; ++t) {
+        const int last = (t == n_sweeps - 1) ? 1 : 0;
+        if (blocked) {
+            rc = ctx->radius == 5 ? launch_blocked<5>(ctx, t, last, stream) : launch_blocked<10>(ctx, t, last, stream);
+            if (rc) return rc;
+        } else {
+            hipLaunchKernelGGL(sweep_generic_kernel, dim3(pix_blocks, n), dim3(256), 0, stream, ctx->imgs_dev,
+                               tab.dir_dy, tab.dir_dx, tab.n_dirs, t, last);
+            IRN_LAUNCH_CHECK("sweep_generic_kernel");
+        }
+    }
+    if (ctx->timing) {
+        IRN_HIP_TRY(hipEventRecord(ctx->ev1, stream));
+        ctx->last_launches = n_sweeps;
+        ctx->ev_valid = true;
+    }
+    return IRN_OK;
+}
+
+extern "C" int irn_walk_export_weights(irn_walk_ctx *ctx, int image, float *w_dev, double *inv_deg_dev,
+                                       void *workspace_dev, void *stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!ctx || ctx->n < 1 || image < 0 || image >= ctx->n || !workspace_dev)
+        return fail(IRN_ERR_ARG, "irn_walk_export_weights: bad argument");
+    char *ws = (char *)workspace_dev;
+    const size_t npx = (size_t)ctx->h[image] * ctx->w[image];
+    if (w_dev) {
+        const float *src = (const float *)(ws + ctx->off_wts[image]) + ctx->front_pad[image];
+        IRN_HIP_TRY(hipMemcpy2DAsync(w_dev, sizeof(float) * npx, src, sizeof(float) * ctx->plane_stride[image],
+                                     sizeof(float) * npx, ctx->tab->n_dirs, hipMemcpyDeviceToDevice, stream));
+    }
+    if (inv_deg_dev)
+        IRN_HIP_TRY(hipMemcpyAsync(inv_deg_dev, ws + ctx->off_deg[image], sizeof(double) * npx,
+                                   hipMemcpyDeviceToDevice, stream));
+    return IRN_OK;
+}

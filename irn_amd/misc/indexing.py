@@ -1,0 +1,300 @@
+"""Operator tier of the pseudo-label hot path — API mirror of reference misc/indexing.py, backed by
+libirn_hip.so (hand-written gfx950 kernels, C ABI in include/irn_hip.h).
+
+Same names, argument meaning and return shapes as the reference:
+
+    PathIndex(radius, default_size)                      misc/indexing.py:6-88
+    edge_to_affinity(edge, paths_indices)                misc/indexing.py:91-109
+    affinity_sparse2dense(aff, ind_from, ind_to, n)      misc/indexing.py:112-129
+    to_transition_matrix(affinity_dense, beta, times)    misc/indexing.py:132-139
+    propagate_to_edge(x, edge, radius, beta, exp_times)  misc/indexing.py:141-165
+
+plus the batched form the steps and bench use (``RandomWalk``).  Tensors must live on the GPU; there
+is no CPU implementation here (the CPU restatement is test infrastructure under ``oracle/``).
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from .. import _lib
+from .._lib import check, i32_array, lib, ptr_array
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _need_cuda(t, what):
+    if not (isinstance(t, torch.Tensor) and t.is_cuda):
+        raise ValueError("%s must be a GPU tensor: the HIP path has no CPU fallback" % what)
+
+
+# ------------------------------------------------------------------------------------------------
+# PathIndex
+# ------------------------------------------------------------------------------------------------
+
+def _path_table(radius, order):
+    nd, nc = C.c_int(), C.c_int()
+    check(lib.irn_path_count(int(radius), C.byref(nd), C.byref(nc)))
+    dst = np.empty((nd.value, 2), np.int32)
+    start = np.empty(nd.value + 1, np.int32)
+    cells = np.empty((nc.value, 2), np.int32)
+    check(lib.irn_path_table(int(radius), int(order), dst.ctypes.data_as(_lib.pi32),
+                             start.ctypes.data_as(_lib.pi32), cells.ctypes.data_as(_lib.pi32)))
+    return dst, start, cells
+
+
+class _PathIndexList(list):
+    """``path_indices`` as the reference exposes it (a list of int64 arrays [n_paths, L, Ns]) that
+    also remembers which (radius, grid) it belongs to, so ``edge_to_affinity`` can run the HIP
+    kernel without ever touching the index arrays."""
+    radius = None
+    size = None
+
+
+class PathIndex:
+    """Radial path tables (reference misc/indexing.py:6-88).
+
+    ``search_paths`` / ``search_dst`` come from the library (irn_path_table, reference channel
+    order).  The flat int64 index tensors ``path_indices / src_indices / dst_indices`` exist for
+    API compatibility (training code indexes with them); they are built lazily with numpy and the
+    kernels never read them."""
+
+    def __init__(self, radius, default_size):
+        self.radius = radius
+        self.radius_floor = int(np.ceil(radius) - 1)
+        self.default_size = tuple(int(v) for v in default_size)
+        dst, start, cells = _path_table(radius, 0)
+        lens = np.diff(start)
+        self.search_dst = dst.astype(np.int64)
+        self.search_paths = []
+        for length in np.unique(lens):                      # groups ascending by path length
+            sel = np.nonzero(lens == length)[0]
+            self.search_paths.append(np.stack([cells[start[i]:start[i + 1]] for i in sel]).astype(np.int64))
+        self._indices = None
+
+    def _build_indices(self):
+        hp, wp = self.default_size
+        rf = self.radius_floor
+        ch, cw = hp - rf, wp - 2 * rf
+        grid = np.arange(hp * wp, dtype=np.int64).reshape(hp, wp)
+
+        def window(dy, dx):
+            return grid[dy:dy + ch, rf + dx:rf + dx + cw].reshape(-1)
+
+        plist = _PathIndexList()
+        plist.radius, plist.size = self.radius, self.default_size
+        for group in self.search_paths:
+            plist.append(np.stack([np.stack([window(int(dy), int(dx)) for dy, dx in path]) for path in group]))
+        src = window(0, 0)
+        dst = np.concatenate([p[:, 0] for p in plist], axis=0)
+        self._indices = (plist, src, dst)
+
+    @property
+    def path_indices(self):
+        if self._indices is None:
+            self._build_indices()
+        return self._indices[0]
+
+    @property
+    def src_indices(self):
+        if self._indices is None:
+            self._build_indices()
+        return self._indices[1]
+
+    @property
+    def dst_indices(self):
+        if self._indices is None:
+            self._build_indices()
+        return self._indices[2]
+
+
+def edge_to_affinity(edge, paths_indices=None, radius=None, size=None):
+    """aff[b, d, s] = 1 - max over path(d) of edge (reference misc/indexing.py:91-109).
+
+    ``edge``: GPU float tensor [B, Hp*Wp] or [B, 1, Hp, Wp] (viewed as [B, -1] like the reference).
+    ``paths_indices``: ``PathIndex.path_indices`` (carries radius and grid size) — or pass
+    ``radius=`` and ``size=(Hp, Wp)`` directly.  Returns [B, |S|, (Hp-rf)*(Wp-2rf)] in the
+    reference's channel order."""
+    _need_cuda(edge, "edge")
+    if paths_indices is not None and radius is None:
+        radius, size = getattr(paths_indices, "radius", None), getattr(paths_indices, "size", None)
+    if radius is None or size is None:
+        raise ValueError("edge_to_affinity needs PathIndex.path_indices or explicit radius= and size=")
+    hp, wp = int(size[0]), int(size[1])
+    e = edge.reshape(edge.size(0), -1).contiguous().float()
+    if e.size(1) != hp * wp:
+        raise ValueError("edge has %d elements per item, grid is %dx%d" % (e.size(1), hp, wp))
+    rf = int(np.ceil(radius) - 1)
+    nd, nc = C.c_int(), C.c_int()
+    check(lib.irn_path_count(int(radius), C.byref(nd), C.byref(nc)))
+    out = torch.empty((e.size(0), nd.value, (hp - rf) * (wp - 2 * rf)), device=e.device, dtype=torch.float32)
+    with torch.cuda.device(e.device):
+        check(lib.irn_edge_to_affinity(e.data_ptr(), e.size(0), hp, wp, int(radius), out.data_ptr(), _stream()))
+    return out
+
+
+def affinity_sparse2dense(affinity_sparse, ind_from, ind_to, n_vertices):
+    """Dense symmetric affinity with unit diagonal (reference misc/indexing.py:112-129).
+    Kept for API completeness only — the walk never densifies; built on-device with index_put
+    instead of the reference's device->host->to_dense->device round trip."""
+    dev = affinity_sparse.device
+    a = affinity_sparse.reshape(-1)
+    f = torch.as_tensor(np.asarray(ind_from), device=dev).repeat(np.asarray(ind_to).shape[0]).reshape(-1)
+    t = torch.as_tensor(np.asarray(ind_to), device=dev).reshape(-1)
+    dense = torch.zeros((n_vertices, n_vertices), device=dev, dtype=a.dtype)
+    dense[f, t] = a
+    dense[t, f] = a
+    d = torch.arange(n_vertices, device=dev)
+    dense[d, d] = 1.0
+    return dense
+
+
+def to_transition_matrix(affinity_dense, beta, times):
+    """Reference misc/indexing.py:132-139 verbatim semantics (dense; API completeness only)."""
+    s = torch.pow(affinity_dense, beta)
+    t = s / torch.sum(s, dim=0, keepdim=True)
+    for _ in range(times):
+        t = torch.matmul(t, t)
+    return t
+
+
+# ------------------------------------------------------------------------------------------------
+# Random walk
+# ------------------------------------------------------------------------------------------------
+
+class RandomWalk:
+    """Batched affinity random walk on one GPU (wraps an ``irn_walk_ctx``).
+
+        rw = RandomWalk(radius=5)
+        outs = rw(edges, cams, beta=10, exp_times=8)
+
+    ``edges[i]`` [h,w] (or [1,h,w]) and ``cams[i]`` [C,h,w] are GPU fp32 tensors of one image;
+    ``outs[i]`` is [C,1,h,w] like ``propagate_to_edge``.  With ``inst_maps`` (int32 [h,w] cluster maps,
+    ``k_inst[i]`` instances) channel cls*K+k starts from cam[cls]*(inst==k)
+    (reference step/make_ins_seg_labels.py:77-80,:133) and ``outs[i]`` is [C*K,1,h,w]."""
+
+    def __init__(self, radius=5, device=None):
+        self.radius = int(radius)
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        self._ctx = C.c_void_p()
+        with torch.cuda.device(self.device):
+            check(lib.irn_walk_create(self.radius, C.byref(self._ctx)))
+        self._sig = None
+        self._ws = None
+        self._ws_bytes = 0
+
+    def close(self):
+        if self._ctx:
+            lib.irn_walk_destroy(self._ctx)
+            self._ctx = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_option(self, name, value):
+        check(lib.irn_walk_set_option(self._ctx, name.encode(), int(value)))
+        self._sig = None
+
+    def enable_timing(self, on=True):
+        with torch.cuda.device(self.device):
+            check(lib.irn_walk_enable_timing(self._ctx, 1 if on else 0))
+
+    def last_sweep_ms(self):
+        ms, n = C.c_float(), C.c_int()
+        check(lib.irn_walk_last_sweep_ms(self._ctx, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+    def configure(self, shapes):
+        """shapes: list of (h, w, c).  Sizes the workspace; cached while the shapes stay the same."""
+        sig = tuple((int(h), int(w), int(c)) for h, w, c in shapes)
+        if sig == self._sig:
+            return
+        need = C.c_size_t()
+        with torch.cuda.device(self.device):
+            check(lib.irn_walk_configure(self._ctx, len(sig), i32_array([s[0] for s in sig]),
+                                         i32_array([s[1] for s in sig]), i32_array([s[2] for s in sig]),
+                                         C.byref(need)))
+        if self._ws is None or self._ws.numel() < need.value:
+            self._ws = None
+            self._ws = torch.empty(need.value, dtype=torch.uint8, device=self.device)
+        self._ws_bytes = need.value
+        self._sig = sig
+
+    @property
+    def workspace_bytes(self):
+        return self._ws_bytes
+
+    def __call__(self, edges, cams, beta=10, exp_times=8, inst_maps=None, k_inst=None, outs=None, n_sweeps=None):
+        n = len(edges)
+        if n_sweeps is None:
+            n_sweeps = 2 ** int(exp_times)
+        es, cs, shapes = [], [], []
+        for i in range(n):
+            _need_cuda(edges[i], "edge")
+            _need_cuda(cams[i], "cam")
+            c = cams[i].reshape((-1,) + tuple(cams[i].shape[-2:])).contiguous().float()
+            h, w = c.shape[-2:]
+            e = edges[i].reshape(h, w).contiguous().float()
+            k = 1
+            if inst_maps is not None and inst_maps[i] is not None:
+                k = int(k_inst[i])
+            es.append(e)
+            cs.append(c)
+            shapes.append((h, w, c.shape[0] * k))
+        self.configure(shapes)
+        if outs is None:
+            outs = [torch.empty((s[2], 1, s[0], s[1]), device=self.device, dtype=torch.float32) for s in shapes]
+        im_ptrs, ks = None, None
+        keep = []
+        if inst_maps is not None:
+            ims = [None if m is None else m.reshape(shapes[i][0], shapes[i][1]).to(torch.int32).contiguous()
+                   for i, m in enumerate(inst_maps)]
+            keep = ims
+            im_ptrs = ptr_array([None if m is None else m.data_ptr() for m in ims])
+            ks = i32_array([1 if (k_inst is None or k_inst[i] is None) else k_inst[i] for i in range(n)])
+        with torch.cuda.device(self.device):
+            check(lib.irn_walk_run(self._ctx, ptr_array([e.data_ptr() for e in es]),
+                                   ptr_array([c.data_ptr() for c in cs]), im_ptrs, ks,
+                                   ptr_array([o.data_ptr() for o in outs]), float(beta), int(n_sweeps),
+                                   self._ws.data_ptr(), self._ws.numel(), _stream()))
+        del keep
+        return outs
+
+    def export_weights(self, image, n_dirs):
+        """(weights [|S|,h,w] in raster direction order, inv_deg fp64 [h,w]) of the last run."""
+        h, w, _ = self._sig[image]
+        wt = torch.empty((n_dirs, h, w), device=self.device, dtype=torch.float32)
+        dg = torch.empty((h, w), device=self.device, dtype=torch.float64)
+        with torch.cuda.device(self.device):
+            check(lib.irn_walk_export_weights(self._ctx, int(image), wt.data_ptr(), dg.data_ptr(),
+                                              self._ws.data_ptr(), _stream()))
+        return wt, dg
+
+
+_WALKERS = {}
+
+
+def _walker(device, radius):
+    key = (torch.device(device).index, int(radius))
+    w = _WALKERS.get(key)
+    if w is None:
+        w = _WALKERS[key] = RandomWalk(radius, device)
+    return w
+
+
+def propagate_to_edge(x, edge, radius=5, beta=10, exp_times=8):
+    """Drop-in for reference misc/indexing.py:141-165.
+
+    x: [C,h,w] or [C,K,h,w] GPU tensor, edge: [1,h,w]; returns [C' ,1,h,w] with C' = prod of the
+    leading dims of x:  (x * (1-edge)) . T^(2^exp_times), T the column-normalised beta-powered
+    path-max affinity of `edge`."""
+    _need_cuda(x, "x")
+    _need_cuda(edge, "edge")
+    beta = float(beta)                 # run_sample.py passes CLI strings for --beta/--exp_times
+    exp_times = int(exp_times)
+    return _walker(x.device, radius)([edge], [x], beta=beta, exp_times=exp_times)[0]

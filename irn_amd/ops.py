@@ -1,0 +1,151 @@
+"""Host-side wrappers of the label epilogue and instance front-end kernels in libirn_hip.so.
+
+Reference functions mirrored (names kept where the reference has one):
+    find_centroids_with_refinement(displacement, iterations=300)   step/make_ins_seg_labels.py:18-56
+    cluster_centroids(centroids, displacement, thres=2.5)          step/make_ins_seg_labels.py:58-75
+    label4(mask)                = skimage.measure.label(mask, connectivity=1, background=0)  (:66,:92)
+    label_epilogue(...)         = step/make_sem_seg_labels.py:43-49, step/make_ins_seg_labels.py:137-145
+    detect_instance(...)        = step/make_ins_seg_labels.py:82-105
+GPU tensors in, GPU tensors out; no CPU fallback.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from ._lib import check, i32_array, lib, ptr_array
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _need_cuda(t, what):
+    if not (isinstance(t, torch.Tensor) and t.is_cuda):
+        raise ValueError("%s must be a GPU tensor: the HIP path has no CPU fallback" % what)
+
+
+def label_epilogue(rws, out_sizes, bg_thres, keys=None, want_labels=True, want_argmax=False, want_rw_up=False):
+    """Batched x4-upsample / normalise / background / argmax.
+
+    rws[i]: GPU fp32 [C,1,h,w] (or [C,h,w]); out_sizes[i] = (H, W) with H <= 4h, W <= 4w;
+    keys[i]: GPU int64 [C] (0-based class ids, the CAM dict's ``keys``) when labels are wanted.
+    Returns dict of lists: 'labels' uint8 [H,W] (0 = background, else key+1), 'argmax' int32 [H,W],
+    'rw_up' fp32 [C,H,W] (divided by the global max) — each present only if requested."""
+    n = len(rws)
+    dev = rws[0].device
+    rs, cs, hs, ws, ohs, ows = [], [], [], [], [], []
+    for i in range(n):
+        _need_cuda(rws[i], "rw")
+        r = rws[i].reshape((-1,) + tuple(rws[i].shape[-2:])).contiguous().float()
+        rs.append(r)
+        cs.append(r.shape[0]); hs.append(r.shape[1]); ws.append(r.shape[2])
+        ohs.append(int(out_sizes[i][0])); ows.append(int(out_sizes[i][1]))
+    labels = [torch.empty((ohs[i], ows[i]), dtype=torch.uint8, device=dev) for i in range(n)] if want_labels else None
+    argmax = [torch.empty((ohs[i], ows[i]), dtype=torch.int32, device=dev) for i in range(n)] if want_argmax else None
+    rw_up = [torch.empty((cs[i], ohs[i], ows[i]), dtype=torch.float32, device=dev) for i in range(n)] if want_rw_up else None
+    ks = None
+    if want_labels:
+        if keys is None:
+            raise ValueError("labels need keys")
+        ks = [torch.as_tensor(k, device=dev).to(torch.int64).contiguous() for k in keys]
+    scratch = torch.empty(max(n, 64), dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        check(lib.irn_label_epilogue(
+            n, ptr_array([r.data_ptr() for r in rs]), i32_array(cs), i32_array(hs), i32_array(ws),
+            i32_array(ohs), i32_array(ows), float(bg_thres),
+            None if ks is None else ptr_array([k.data_ptr() for k in ks]),
+            None if labels is None else ptr_array([t.data_ptr() for t in labels]),
+            None if argmax is None else ptr_array([t.data_ptr() for t in argmax]),
+            None if rw_up is None else ptr_array([t.data_ptr() for t in rw_up]),
+            scratch.data_ptr(), _stream()))
+    out = {}
+    if want_labels:
+        out["labels"] = labels
+    if want_argmax:
+        out["argmax"] = argmax
+    if want_rw_up:
+        out["rw_up"] = rw_up
+    return out
+
+
+def find_centroids_with_refinement(displacement, iterations=300):
+    """dp GPU fp32 [2,h,w] -> GPU int32 [2,h,w] (cy, cx); bit-identical to the reference's numpy
+    (step/make_ins_seg_labels.py:18-56)."""
+    _need_cuda(displacement, "displacement")
+    dp = displacement.contiguous().float()
+    _, h, w = dp.shape
+    out = torch.empty((2, h, w), dtype=torch.int32, device=dp.device)
+    with torch.cuda.device(dp.device):
+        check(lib.irn_find_centroids(dp.data_ptr(), h, w, int(iterations), out.data_ptr(), _stream()))
+    return out
+
+
+def cluster_centroids(centroids, displacement, thres=2.5, as_one_hot=False):
+    """-> (cluster_map GPU int32 [h,w] with values 0..K-1, K).  With ``as_one_hot`` returns the
+    reference's bool [K,h,w] instead (step/make_ins_seg_labels.py:58-75)."""
+    _need_cuda(centroids, "centroids")
+    dp = displacement.contiguous().float()
+    cen = centroids.to(torch.int32).contiguous()
+    _, h, w = dp.shape
+    cmap = torch.empty((h, w), dtype=torch.int32, device=dp.device)
+    scratch = torch.empty(lib.irn_cluster_scratch_bytes(h, w), dtype=torch.uint8, device=dp.device)
+    k = C.c_int()
+    with torch.cuda.device(dp.device):
+        check(lib.irn_cluster_centroids(cen.data_ptr(), dp.data_ptr(), h, w, float(thres), cmap.data_ptr(),
+                                        C.byref(k), scratch.data_ptr(), _stream()))
+    if as_one_hot:
+        return (cmap[None] == torch.arange(k.value, device=dp.device, dtype=torch.int32)[:, None, None])
+    return cmap, k.value
+
+
+def label4(mask):
+    """4-connected components of a GPU mask [n,h,w] or [h,w] (non-zero = foreground): int32 ids 1..
+    per image in raster order of each component's first pixel, 0 background; and counts [n]."""
+    _need_cuda(mask, "mask")
+    squeeze = mask.dim() == 2
+    m = (mask != 0).to(torch.uint8).contiguous()
+    if squeeze:
+        m = m[None]
+    n, h, w = m.shape
+    labels = torch.empty((n, h, w), dtype=torch.int32, device=m.device)
+    counts = torch.empty(n, dtype=torch.int32, device=m.device)
+    scratch = torch.empty(lib.irn_ccl_scratch_bytes(n, h, w), dtype=torch.uint8, device=m.device)
+    with torch.cuda.device(m.device):
+        check(lib.irn_label4(m.data_ptr(), n, h, w, labels.data_ptr(), counts.data_ptr(), scratch.data_ptr(), _stream()))
+    return (labels[0], counts[0]) if squeeze else (labels, counts)
+
+
+def detect_instance(rw_up, argmax, class_ids, n_channels, max_fragment_size=0):
+    """Pixel-wise instance ids -> detections (reference step/make_ins_seg_labels.py:82-105), on GPU.
+
+    rw_up: fp32 [C',H,W] normalised scores; argmax: int32 [H,W] (0 = bg, c+1 = channel c);
+    class_ids: int64 [C'] (np.repeat(keys, K)).  For every non-empty channel mask, every 4-connected
+    segment becomes a detection: score = max(rw_up[c] over the segment), or 0 when the segment has
+    fewer than max_fragment_size pixels.  Returns numpy dict {'score','mask','class'} ordered like the
+    reference (channel ascending, segment id ascending).  Raises ValueError when nothing is detected
+    (the reference crashes in np.stack([]) — SURVEY.md §3.5)."""
+    dev = rw_up.device
+    masks = (argmax[None] == torch.arange(1, n_channels + 1, device=dev, dtype=argmax.dtype)[:, None, None])
+    nonempty = torch.nonzero(masks.flatten(1).any(dim=1))[:, 0]
+    if nonempty.numel() == 0:
+        raise ValueError("detect_instance: no foreground pixel in any channel")
+    labels, counts = label4(masks[nonempty])
+    counts = counts.cpu().numpy()
+    scores, out_masks, classes = [], [], []
+    class_ids = np.asarray(class_ids)
+    for j, ch in enumerate(nonempty.cpu().numpy()):
+        lab = labels[j]
+        sc = rw_up[ch]
+        for seg in range(1, int(counts[j]) + 1):
+            m = lab == seg
+            area = int(m.sum().item())
+            if area < max_fragment_size:
+                scores.append(0.0)
+            else:
+                scores.append(float(torch.max(sc * m).item()))
+            out_masks.append(m.cpu().numpy())
+            classes.append(class_ids[ch])
+    return {"score": np.asarray(scores, np.float32),
+            "mask": np.stack(out_masks, 0),
+            "class": np.stack(classes, 0)}

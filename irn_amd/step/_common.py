@@ -1,0 +1,37 @@
+"""Shared plumbing of the label-generation steps: one worker process per GPU over strided shards
+(reference step/make_cam.py:67-74), fail-fast, no communication between workers."""
+import importlib
+
+import torch
+from torch import multiprocessing
+
+_NET_ALIASES = {"net.resnet50_cam": "irn_amd.net.resnet50_cam", "net.resnet50_irn": "irn_amd.net.resnet50_irn"}
+
+
+def import_network(dotted):
+    """`--cam_network net.resnet50_cam` style names of the reference resolve to this package."""
+    return importlib.import_module(_NET_ALIASES.get(dotted, dotted))
+
+
+def n_gpus_or_raise():
+    n = torch.cuda.device_count()
+    if n < 1:
+        # the reference silently does nothing with zero GPUs (spawn(nprocs=0)); fail loudly instead
+        raise RuntimeError("irn_amd steps need at least one GPU (torch.cuda.device_count() == 0)")
+    return n
+
+
+def spawn_workers(work, model, shards, args):
+    n = len(shards)
+    if n == 1:
+        work(0, model, shards, args)        # same code path, no fork needed for a single GPU
+    else:
+        multiprocessing.spawn(work, nprocs=n, args=(model, shards, args), join=True)
+
+
+def progress(process_id, n_workers, it, n_items):
+    """The reference prints 5 % ticks from the last rank and divides by len//20 (ZeroDivision for
+    shards under 20 images, step/make_cam.py:58); guarded here."""
+    step = max(n_items // 20, 1)
+    if process_id == n_workers - 1 and it % step == 0:
+        print("%d " % ((5 * it + 1) // step), end="", flush=True)

@@ -1,0 +1,73 @@
+"""Multi-scale CAM inference step — drop-in for reference step/make_cam.py (`run(args)`).
+
+Reads  args.cam_network, args.cam_weights_name(+'.pth'), args.train_list, args.voc12_root,
+       args.cam_scales, args.num_workers
+Writes args.cam_out_dir/<name>.npy = {"keys": LongTensor[K], "cam": FloatTensor[K,h,w] (cpu),
+       "high_res": float32 ndarray [K,H,W]}   (same pickle schema as step/make_cam.py:55-56)
+
+The ResNet-50 forward passes run on PyTorch-ROCm (MIOpen); the merge (step/make_cam.py:38-52) is
+torch ops on the GPU.  One process per GPU over strided shards, no communication.
+"""
+import os
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+from torch.utils.data import DataLoader
+
+from ..misc import imutils, torchutils
+from ..voc12 import dataloader as voc12_dataloader
+from . import _common
+
+
+def merge_scales(outputs, size, label):
+    """outputs: per-scale [20,hs,ws] activation maps -> (keys, cam [K,h/4,w/4], high_res [K,H,W])
+    (step/make_cam.py:32-52)."""
+    size = (int(size[0]), int(size[1]))
+    strided_size = imutils.get_strided_size(size, 4)
+    strided_up_size = imutils.get_strided_up_size(size, 16)
+    strided_cam = torch.sum(torch.stack(
+        [F.interpolate(o[None], strided_size, mode="bilinear", align_corners=False)[0] for o in outputs]), 0)
+    highres = torch.sum(torch.stack(
+        [F.interpolate(o[:, None], strided_up_size, mode="bilinear", align_corners=False) for o in outputs], 0), 0)
+    highres = highres[:, 0, :size[0], :size[1]]
+    valid_cat = torch.nonzero(label)[:, 0]
+    strided_cam = strided_cam[valid_cat]
+    strided_cam = strided_cam / (F.adaptive_max_pool2d(strided_cam, (1, 1)) + 1e-5)
+    highres = highres[valid_cat]
+    highres = highres / (F.adaptive_max_pool2d(highres, (1, 1)) + 1e-5)
+    return valid_cat, strided_cam, highres
+
+
+def _work(process_id, model, dataset, args):
+    databin = dataset[process_id]
+    n_gpus = len(dataset)
+    loader = DataLoader(databin, shuffle=False, num_workers=int(args.num_workers) // n_gpus, pin_memory=False)
+    with torch.no_grad(), torch.cuda.device(process_id):
+        model.cuda()
+        for it, pack in enumerate(loader):
+            img_name = pack["name"][0]
+            label = pack["label"][0]
+            size = (int(pack["size"][0]), int(pack["size"][1]))
+            imgs = pack["img"] if isinstance(pack["img"], (list, tuple)) else [pack["img"]]
+            outputs = [model(img[0].cuda(non_blocking=True)) for img in imgs]
+            keys, cam, high_res = merge_scales(outputs, size, label.cuda())
+            np.save(os.path.join(args.cam_out_dir, img_name + ".npy"),
+                    {"keys": keys.cpu(), "cam": cam.cpu(), "high_res": high_res.cpu().numpy()})
+            _common.progress(process_id, n_gpus, it, len(databin))
+
+
+def run(args):
+    model = getattr(_common.import_network(args.cam_network), "CAM")()
+    model.load_state_dict(torch.load(args.cam_weights_name + ".pth", map_location="cpu"), strict=True)
+    model.eval()
+    n_gpus = _common.n_gpus_or_raise()
+    scales = tuple(float(s) for s in args.cam_scales)
+    dataset = voc12_dataloader.VOC12ClassificationDatasetMSF(args.train_list, voc12_root=args.voc12_root,
+                                                             scales=scales)
+    dataset = torchutils.split_dataset(dataset, n_gpus)
+    os.makedirs(args.cam_out_dir, exist_ok=True)
+    print("[ ", end="")
+    _common.spawn_workers(_work, model, dataset, args)
+    print("]")
+    torch.cuda.empty_cache()

@@ -1,0 +1,80 @@
+"""Instance pseudo-label step — drop-in for reference step/make_ins_seg_labels.py (`run(args)`).
+
+Reads  args.irn_network, args.irn_weights_name, args.infer_list, args.voc12_root, args.cam_out_dir,
+       args.beta, args.exp_times, args.ins_seg_bg_thres, args.num_workers
+Writes args.ins_seg_out_dir/<name>.npy = {'score': float[N], 'mask': bool[N,H,W], 'class': int64[N]}
+       (schema consumed by step/make_cocoann.py:34-38 and step/eval_ins_seg.py)
+
+Per image (step/make_ins_seg_labels.py:119-152): EdgeDisplacement forward -> edge, dp; centroid
+refinement, clustering, per-instance CAM split, random walk, label epilogue and the per-mask
+connected components all run on the GPU through libirn_hip.so.  An image with no detected instance
+is skipped with a warning (the reference crashes in np.stack([])).
+"""
+import os
+import warnings
+
+import numpy as np
+import torch
+from torch.utils.data import DataLoader
+
+from .. import ops
+from ..misc import indexing, torchutils
+from ..voc12 import dataloader as voc12_dataloader
+from . import _common
+
+RADIUS = 5   # step/make_ins_seg_labels.py:135
+
+find_centroids_with_refinement = ops.find_centroids_with_refinement
+cluster_centroids = ops.cluster_centroids
+detect_instance = ops.detect_instance
+
+
+def instance_labels(walker, edge, dp, cams, keys, size, beta, exp_times, bg_thres):
+    """One image: returns the detection dict (numpy) — step/make_ins_seg_labels.py:131-150."""
+    centroids = ops.find_centroids_with_refinement(dp)
+    cmap, k = ops.cluster_centroids(centroids, dp)
+    n_cls = cams.shape[0]
+    rw = walker([edge], [cams], beta=beta, exp_times=exp_times, inst_maps=[cmap], k_inst=[k])[0]
+    ep = ops.label_epilogue([rw], [size], bg_thres, want_labels=False, want_argmax=True, want_rw_up=True)
+    class_ids = np.repeat(np.asarray(keys.cpu()), k)
+    return ops.detect_instance(ep["rw_up"][0], ep["argmax"][0], class_ids, n_cls * k,
+                               max_fragment_size=size[0] * size[1] * 0.01)
+
+
+def _work(process_id, model, dataset, args):
+    databin = dataset[process_id]
+    n_gpus = len(dataset)
+    loader = DataLoader(databin, shuffle=False, num_workers=int(args.num_workers) // n_gpus, pin_memory=False)
+    with torch.no_grad(), torch.cuda.device(process_id):
+        model.cuda()
+        walker = indexing.RandomWalk(RADIUS)
+        for it, pack in enumerate(loader):
+            name = pack["name"][0]
+            size = (int(pack["size"][0]), int(pack["size"][1]))
+            edge, dp = model(pack["img"][0].cuda(non_blocking=True))
+            cam_dict = np.load(os.path.join(args.cam_out_dir, name + ".npy"), allow_pickle=True).item()
+            cams = torch.as_tensor(cam_dict["cam"]).cuda()
+            keys = torch.as_tensor(cam_dict["keys"])
+            try:
+                det = instance_labels(walker, edge, dp, cams, keys, size, float(args.beta), int(args.exp_times),
+                                      float(args.ins_seg_bg_thres))
+            except ValueError as e:
+                warnings.warn("%s: %s — no file written" % (name, e))
+                continue
+            np.save(os.path.join(args.ins_seg_out_dir, name + ".npy"), det)
+            _common.progress(process_id, n_gpus, it, len(databin))
+        walker.close()
+
+
+def run(args):
+    model = getattr(_common.import_network(args.irn_network), "EdgeDisplacement")()
+    model.load_state_dict(torch.load(args.irn_weights_name, map_location="cpu"), strict=False)
+    model.eval()
+    n_gpus = _common.n_gpus_or_raise()
+    dataset = voc12_dataloader.VOC12ClassificationDatasetMSF(args.infer_list, voc12_root=args.voc12_root,
+                                                             scales=(1.0,))
+    dataset = torchutils.split_dataset(dataset, n_gpus)
+    os.makedirs(args.ins_seg_out_dir, exist_ok=True)
+    print("[ ", end="")
+    _common.spawn_workers(_work, model, dataset, args)
+    print("]")

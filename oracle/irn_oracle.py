@@ -222,9 +222,24 @@ def _bilinear_axis(n_in, n_out, scale):
     return i0, i1, l0, l1
 
 
+def _fma32(a, b, c):
+    """fp32 fused multiply-add: the product of two fp32 is exact in fp64."""
+    return (np.asarray(a, np.float64) * np.asarray(b, np.float64) + np.asarray(c, np.float64)).astype(np.float32)
+
+
+def _bilinear_taps(x, y0, y1, ly0, ly1, x0, x1, lx0, lx1):
+    """ATen CPU upsample_bilinear2d arithmetic (torch 2.10, pinned bit-exactly by
+    tests/golden/semseg.npz and cam_merge.npz):
+        top = fma(v00, lx0, v01*lx1); bot = fma(v10, lx0, v11*lx1); out = fma(ly0, top, ly1*bot)"""
+    r0, r1 = x[:, y0], x[:, y1]
+    top = _fma32(r0[:, :, x0], lx0, r0[:, :, x1] * lx1)
+    bot = _fma32(r1[:, :, x0], lx0, r1[:, :, x1] * lx1)
+    return _fma32(ly0[None, :, None], top, ly1[None, :, None] * bot)
+
+
 def upsample_bilinear(x, scale=4, out_hw=None):
     """F.interpolate(x[C,1,h,w], scale_factor=scale, mode='bilinear', align_corners=False) cropped to
-    out_hw.  fp32; per output: l0y*(l0x*a + l1x*b) + l1y*(l0x*c + l1x*d) (ATen CPU order)."""
+    out_hw, fp32."""
     x = np.asarray(x, np.float32)
     c, h, w = x.shape[0], x.shape[-2], x.shape[-1]
     x = x.reshape(c, h, w)
@@ -235,9 +250,7 @@ def upsample_bilinear(x, scale=4, out_hw=None):
         oh, ow = out_hw
         y0, y1, ly0, ly1 = y0[:oh], y1[:oh], ly0[:oh], ly1[:oh]
         x0, x1, lx0, lx1 = x0[:ow], x1[:ow], lx0[:ow], lx1[:ow]
-    top = x[:, y0][:, :, x0] * lx0 + x[:, y0][:, :, x1] * lx1
-    bot = x[:, y1][:, :, x0] * lx0 + x[:, y1][:, :, x1] * lx1
-    return (ly0[None, :, None] * top + ly1[None, :, None] * bot).astype(np.float32)
+    return _bilinear_taps(x, y0, y1, ly0, ly1, x0, x1, lx0, lx1)
 
 
 def sem_seg_epilogue(rw, out_hw, keys, bg_thres=0.25):
@@ -400,9 +413,7 @@ def resize_bilinear(x, size):
     x = np.asarray(x, np.float32)
     y0, y1, ly0, ly1 = _resize_axis(x.shape[-2], size[0])
     x0, x1, lx0, lx1 = _resize_axis(x.shape[-1], size[1])
-    top = x[:, y0][:, :, x0] * lx0 + x[:, y0][:, :, x1] * lx1
-    bot = x[:, y1][:, :, x0] * lx0 + x[:, y1][:, :, x1] * lx1
-    return (ly0[None, :, None] * top + ly1[None, :, None] * bot).astype(np.float32)
+    return _bilinear_taps(x, y0, y1, ly0, ly1, x0, x1, lx0, lx1)
 
 
 def cam_merge(outputs, size, label):

@@ -1,0 +1,82 @@
+"""The C-ABI library loads without a GPU, exports every symbol include/irn_hip.h declares, and its
+host-only entry points (path tables, argument validation) behave."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from irn_amd import _lib
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    src = open(os.path.join(ROOT, "include", "irn_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(irn_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_every_declared_symbol_is_exported_and_bound():
+    names = _declared()
+    assert len(names) >= 19
+    for n in names:
+        assert hasattr(_lib.lib, n), "header declares %s but the library does not export it" % n
+    assert sorted(_lib.EXPORTS) == names, "irn_amd/_lib.py binds a different set than the header declares"
+
+
+def test_version_and_error_string():
+    assert _lib.lib.irn_version() >= 100
+    nd, nc = C.c_int(), C.c_int()
+    assert _lib.lib.irn_path_count(1, C.byref(nd), C.byref(nc)) == 1          # IRN_ERR_ARG
+    assert b"radius" in _lib.lib.irn_last_error()
+    with pytest.raises(_lib.IrnHipError):
+        _lib.check(_lib.lib.irn_path_count(99, C.byref(nd), C.byref(nc)))
+
+
+@pytest.mark.parametrize("r", [2, 3, 5, 7, 10])
+def test_path_table_reference_order_vs_golden(golden, r):
+    from irn_amd.misc import indexing
+    pt = golden("path_tables")
+    dst, start, cells = indexing._path_table(r, 0)
+    assert np.array_equal(dst, pt["r%d_dst" % r])
+    assert np.array_equal(cells, pt["r%d_paths_flat" % r])
+    lens = np.diff(start)
+    assert np.array_equal(lens, np.repeat(pt["r%d_group_lens" % r], pt["r%d_group_counts" % r]))
+
+
+@pytest.mark.parametrize("r", [5, 10])
+def test_path_table_raster_order_is_a_permutation(r):
+    from irn_amd.misc import indexing
+    d0, s0, c0 = indexing._path_table(r, 0)
+    d1, s1, c1 = indexing._path_table(r, 1)
+    assert [tuple(x) for x in d1] == sorted(tuple(x) for x in d0)
+    paths0 = {tuple(d0[i]): c0[s0[i]:s0[i + 1]].tolist() for i in range(len(d0))}
+    for i in range(len(d1)):
+        assert c1[s1[i]:s1[i + 1]].tolist() == paths0[tuple(d1[i])]
+
+
+def test_pathindex_mirror_matches_golden(golden):
+    from irn_amd.misc import indexing
+    pt = golden("path_tables")
+    for r in (3, 5, 10):
+        pi = indexing.PathIndex(r, tuple(pt["r%d_size" % r]))
+        assert pi.radius_floor == r - 1
+        assert np.array_equal(pi.search_dst, pt["r%d_dst" % r])
+        assert np.array_equal(pi.src_indices, pt["r%d_src_indices" % r])
+        assert np.array_equal(pi.dst_indices, pt["r%d_dst_indices" % r])
+        assert np.array_equal(np.concatenate([p.reshape(-1) for p in pi.path_indices]),
+                              pt["r%d_path_indices_flat" % r])
+        assert pi.path_indices.radius == r
+
+
+def test_device_entry_points_fail_loudly_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    ctx = C.c_void_p()
+    rc = _lib.lib.irn_walk_create(5, C.byref(ctx))
+    assert rc == 2 and _lib.lib.irn_last_error()                              # IRN_ERR_HIP, no crash
+    from irn_amd.misc import indexing
+    with pytest.raises(ValueError):
+        indexing.propagate_to_edge(torch.zeros(1, 4, 4), torch.zeros(1, 4, 4))  # CPU tensors are refused
