@@ -99,9 +99,11 @@ int irn_walk_run(irn_walk_ctx *ctx, const float *const *edge_dev, const float *c
  * table-driven sweep, 1 = register-blocked sweep for radius 5/10 (default).  Unknown names fail. */
 int irn_walk_set_option(irn_walk_ctx *ctx, const char *name, int value);
 
-/* Kernel timing hook for bench.py: when enabled, irn_walk_run brackets the sweep kernels with HIP
- * events on `stream`; irn_walk_last_sweep_ms synchronises those events and returns the summed
- * sweep time and the number of sweep launches of the last run. */
+/* Kernel timing hook for bench.py: when enabled, every irn_walk_run brackets its sweep kernels
+ * with a pair of HIP events on `stream` (no synchronisation).  irn_walk_last_sweep_ms waits for the
+ * pairs recorded since its previous call, returns their summed elapsed time and the number of
+ * sweeps (one sweep = one pass of the transition operator over the whole batch) they cover, and
+ * forgets them. */
 int irn_walk_enable_timing(irn_walk_ctx *ctx, int enable);
 int irn_walk_last_sweep_ms(irn_walk_ctx *ctx, float *ms, int *n_launches);
 

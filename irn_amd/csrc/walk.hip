@@ -352,11 +352,11 @@ struct irn_walk_ctx {
     size_t stage_cap = 0;
     hipEvent_t stage_ev[2] = {nullptr, nullptr};
     int stage_next = 0;
-    // timing
+    // timing: one event pair per timed run since the last irn_walk_last_sweep_ms call
     int timing = 0;
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    int last_launches = 0;
-    bool ev_valid = false;
+    std::vector<hipEvent_t> ev_pool;       // all events ever created (reused)
+    size_t ev_used = 0;                    // events handed out since the last read-out
+    int pending_launches = 0;
 };
 
 extern "C" int irn_walk_create(int radius, irn_walk_ctx **ctx_out) {
@@ -378,8 +378,7 @@ extern "C" int irn_walk_destroy(irn_walk_ctx *ctx) {
     if (ctx->imgs_dev) (void)hipFree(ctx->imgs_dev);
     if (ctx->jobs_dev) (void)hipFree(ctx->jobs_dev);
     if (ctx->map_dev) (void)hipFree(ctx->map_dev);
-    if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
-    if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    for (hipEvent_t e : ctx->ev_pool) (void)hipEventDestroy(e);
     for (int k = 0; k < 2; ++k) {
         if (ctx->stage[k]) (void)hipHostFree(ctx->stage[k]);
         if (ctx->stage_ev[k]) (void)hipEventDestroy(ctx->stage_ev[k]);
@@ -410,19 +409,23 @@ extern "C" int irn_walk_set_option(irn_walk_ctx *ctx, const char *name, int valu
 extern "C" int irn_walk_enable_timing(irn_walk_ctx *ctx, int enable) {
     if (!ctx) return fail(IRN_ERR_ARG, "null ctx");
     ctx->timing = enable ? 1 : 0;
-    if (enable && !ctx->ev0) {
-        IRN_HIP_TRY(hipEventCreate(&ctx->ev0));
-        IRN_HIP_TRY(hipEventCreate(&ctx->ev1));
-    }
     return IRN_OK;
 }
 
 extern "C" int irn_walk_last_sweep_ms(irn_walk_ctx *ctx, float *ms, int *n_launches) {
     if (!ctx || !ms || !n_launches) return fail(IRN_ERR_ARG, "null argument");
-    if (!ctx->ev_valid) return fail(IRN_ERR_STATE, "no timed run recorded");
-    IRN_HIP_TRY(hipEventSynchronize(ctx->ev1));
-    IRN_HIP_TRY(hipEventElapsedTime(ms, ctx->ev0, ctx->ev1));
-    *n_launches = ctx->last_launches;
+    if (ctx->ev_used == 0) return fail(IRN_ERR_STATE, "no timed run recorded");
+    float total = 0.f;
+    for (size_t i = 0; i + 1 < ctx->ev_used; i += 2) {
+        float t = 0.f;
+        IRN_HIP_TRY(hipEventSynchronize(ctx->ev_pool[i + 1]));
+        IRN_HIP_TRY(hipEventElapsedTime(&t, ctx->ev_pool[i], ctx->ev_pool[i + 1]));
+        total += t;
+    }
+    *ms = total;
+    *n_launches = ctx->pending_launches;
+    ctx->ev_used = 0;
+    ctx->pending_launches = 0;
     return IRN_OK;
 }
 
@@ -621,7 +624,17 @@ extern "C" int irn_walk_run(irn_walk_ctx *ctx, const float *const *edge_dev, con
     IRN_LAUNCH_CHECK("x0_kernel");
 
     const bool blocked = ctx->variant == 1 && ctx->all_blocked_ok;
-    if (ctx->timing) IRN_HIP_TRY(hipEventRecord(ctx->ev0, stream));
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    if (ctx->timing) {
+        while (ctx->ev_pool.size() < ctx->ev_used + 2) {
+            hipEvent_t e;
+            IRN_HIP_TRY(hipEventCreate(&e));
+            ctx->ev_pool.push_back(e);
+        }
+        ev0 = ctx->ev_pool[ctx->ev_used];
+        ev1 = ctx->ev_pool[ctx->ev_used + 1];
+        IRN_HIP_TRY(hipEventRecord(ev0, stream));
+    }
     for (int t = 0; t < n_sweeps; ++t) {
         const int last = (t == n_sweeps - 1) ? 1 : 0;
         if (blocked) {
@@ -634,9 +647,9 @@ extern "C" int irn_walk_run(irn_walk_ctx *ctx, const float *const *edge_dev, con
         }
     }
     if (ctx->timing) {
-        IRN_HIP_TRY(hipEventRecord(ctx->ev1, stream));
-        ctx->last_launches = n_sweeps;
-        ctx->ev_valid = true;
+        IRN_HIP_TRY(hipEventRecord(ev1, stream));
+        ctx->ev_used += 2;
+        ctx->pending_launches += n_sweeps;
     }
     return IRN_OK;
 }

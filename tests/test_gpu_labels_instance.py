@@ -1,0 +1,119 @@
+"""GPU parity of the label epilogue and the instance front-end (through the C ABI): bit-exact
+against the reference's outputs in tests/golden/ and against the oracle on fresh inputs."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import irn_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev():
+    assert torch.cuda.is_available()
+    return torch.device("cuda", 0)
+
+
+def _unpack(d, key):
+    shape = tuple(d[key + "_shape"])
+    return np.unpackbits(d[key])[:int(np.prod(shape))].reshape(shape).astype(bool)
+
+
+def test_sem_seg_labels_bit_exact_vs_reference(golden):
+    from irn_amd import ops
+    wk, sg = golden("walk"), golden("semseg")
+    names = sorted(k[:-6] for k in sg.files if k.endswith("_label"))
+    rws = [torch.from_numpy(wk[n + "_rw"]).to(_dev()) for n in names]
+    sizes = [tuple(int(v) for v in sg[n + "_size"]) for n in names]
+    keys = [torch.from_numpy(sg[n + "_keys"]).to(_dev()) for n in names]
+    # one bg threshold per call: run the two thresholds separately
+    for bg in sorted({float(sg[n + "_bg"]) for n in names}):
+        idx = [i for i, n in enumerate(names) if float(sg[n + "_bg"]) == bg]
+        out = ops.label_epilogue([rws[i] for i in idx], [sizes[i] for i in idx], bg, keys=[keys[i] for i in idx],
+                                 want_argmax=True, want_rw_up=True)
+        for j, i in enumerate(idx):
+            n = names[i]
+            assert np.array_equal(out["rw_up"][j].cpu().numpy(), sg[n + "_rw_up"]), n
+            assert np.array_equal(out["labels"][j].cpu().numpy(), sg[n + "_label"]), n
+
+
+def test_epilogue_full_size_vs_oracle():
+    from irn_amd import ops, synth
+    rng = np.random.RandomState(5)
+    rw = (synth.cam_blobs(4, 128, 128, seed=9) * rng.uniform(0.2, 1.0, (4, 1, 1))).astype(np.float32)[:, None]
+    keys = np.array([1, 4, 9, 19])
+    for size in ((512, 512), (500, 375), (509, 1)):
+        out = ops.label_epilogue([torch.from_numpy(rw).to(_dev())], [size], 0.25,
+                                 keys=[torch.from_numpy(keys).to(_dev())], want_argmax=True, want_rw_up=True)
+        up, lab, idx = O.sem_seg_epilogue(rw, size, keys, 0.25)
+        assert np.array_equal(out["rw_up"][0].cpu().numpy(), up)
+        assert np.array_equal(out["labels"][0].cpu().numpy(), lab)
+        assert np.array_equal(out["argmax"][0].cpu().numpy(), idx)
+
+
+def test_argmax_tie_rule_first_maximum_wins():
+    from irn_amd import ops
+    rw = torch.zeros((3, 1, 4, 4), device=_dev())
+    rw[0] = 0.25
+    rw[1] = 1.0
+    rw[2] = 1.0                                      # channels 1 and 2 tie at the max -> channel 1
+    out = ops.label_epilogue([rw], [(16, 16)], 1.0, want_labels=False, want_argmax=True)
+    assert int(out["argmax"][0].max()) == 0          # background (1.0) ties with the max -> background first
+    out = ops.label_epilogue([rw], [(16, 16)], 0.5, want_labels=False, want_argmax=True)
+    assert torch.all(out["argmax"][0] == 2)
+
+
+@pytest.mark.parametrize("name", ["a", "b", "c", "cen64", "cen_ragged"])
+def test_centroids_and_clusters_bit_exact_vs_reference(golden, name):
+    from irn_amd import ops
+    ins = golden("instance")
+    dp = torch.from_numpy(ins[name + "_dp"]).to(_dev())
+    cen = ops.find_centroids_with_refinement(dp)
+    assert np.array_equal(cen.cpu().numpy(), ins[name + "_centroids"])
+    oh = ops.cluster_centroids(cen, dp, as_one_hot=True)
+    assert np.array_equal(oh.cpu().numpy(), _unpack(ins, name + "_instance_map"))
+
+
+def test_centroids_128_vs_oracle():
+    from irn_amd import ops, synth
+    dp = synth.displacement_field(128, 128, seed=77, strength=0.3)
+    cen = ops.find_centroids_with_refinement(torch.from_numpy(dp).to(_dev())).cpu().numpy()
+    assert np.array_equal(cen, O.find_centroids_with_refinement(dp))
+
+
+def test_label4_vs_oracle_random_masks():
+    from irn_amd import ops
+    rng = np.random.RandomState(1)
+    for shape, p in (((3, 37, 41), 0.55), ((2, 64, 64), 0.62), ((1, 128, 128), 0.59), ((2, 9, 200), 0.7),
+                     ((1, 16, 16), 0.0), ((1, 16, 16), 1.0)):
+        m = rng.rand(*shape) < p
+        labels, counts = ops.label4(torch.from_numpy(m).to(_dev()))
+        labels, counts = labels.cpu().numpy(), counts.cpu().numpy()
+        for i in range(shape[0]):
+            ref = O.label4(m[i])
+            assert np.array_equal(labels[i], ref), (shape, p, i)
+            assert counts[i] == ref.max()
+    # snake: one long component forces deep union-find chains
+    m = np.zeros((1, 64, 64), bool)
+    m[0, ::2] = True
+    m[0, 1::4, -1] = True
+    m[0, 3::4, 0] = True
+    labels, counts = ops.label4(torch.from_numpy(m).to(_dev()))
+    assert int(counts[0]) == 1 and np.array_equal(labels[0].cpu().numpy(), O.label4(m[0]))
+
+
+@pytest.mark.parametrize("name", ["a", "b", "c"])
+def test_instance_labels_end_to_end_vs_reference(golden, name):
+    from irn_amd.misc import indexing
+    from irn_amd.step import make_ins_seg_labels as mis
+    ins = golden("instance")
+    H, W = (int(v) for v in ins[name + "_size"])
+    walker = indexing.RandomWalk(5, _dev())
+    det = mis.instance_labels(walker, torch.from_numpy(ins[name + "_edge"])[None].to(_dev()),
+                              torch.from_numpy(ins[name + "_dp"]).to(_dev()),
+                              torch.from_numpy(ins[name + "_cam"]).to(_dev()),
+                              torch.from_numpy(ins[name + "_keys"]), (H, W), 10.0, 8, 0.25)
+    assert np.array_equal(det["mask"], _unpack(ins, name + "_det_mask"))
+    assert np.array_equal(det["class"], ins[name + "_det_class"])
+    assert np.abs(det["score"] - ins[name + "_det_score"]).max() <= 1e-4
+    walker.close()

@@ -1,0 +1,83 @@
+"""The run_sample.py step API end to end on a synthetic VOC-shaped directory: make_cam ->
+make_sem_seg_labels -> make_ins_seg_labels with random-init checkpoints; checks file schemas through
+the reference's readers' access patterns and the step results against the operator tier."""
+import argparse
+import os
+
+import numpy as np
+import pytest
+import torch
+from PIL import Image
+
+pytestmark = pytest.mark.gpu
+
+
+def _make_voc(tmp, n=5):
+    root = tmp / "voc"
+    (root / "JPEGImages").mkdir(parents=True)
+    rng = np.random.RandomState(0)
+    names, labels = [], {}
+    for i in range(n):
+        name = "2008_%06d" % (i + 1)
+        h, w = rng.randint(90, 140), rng.randint(100, 160)
+        img = (rng.rand(h // 8 + 1, w // 8 + 1, 3) * 255).astype(np.uint8)
+        Image.fromarray(img).resize((w, h), Image.BICUBIC).save(root / "JPEGImages" / (name + ".jpg"), quality=95)
+        names.append(name)
+        lab = np.zeros(20, np.float32)
+        lab[rng.choice(20, rng.randint(1, 4), replace=False)] = 1
+        labels[int(name.replace("_", ""))] = lab
+    (tmp / "lists").mkdir()
+    (tmp / "lists" / "train.txt").write_text("\n".join(names) + "\n")
+    np.save(tmp / "lists" / "cls_labels.npy", labels)
+    return root, names, labels
+
+
+def test_steps_end_to_end(tmp_path):
+    from irn_amd.net import weights
+    from irn_amd.step import make_cam, make_ins_seg_labels, make_sem_seg_labels
+    root, names, labels = _make_voc(tmp_path)
+    torch.save(weights.random_cam_state(1), tmp_path / "res50_cam.pth")
+    torch.save(weights.random_irn_state(2), tmp_path / "res50_irn.pth")
+    args = argparse.Namespace(
+        num_workers=0, voc12_root=str(root), train_list=str(tmp_path / "lists" / "train.txt"),
+        infer_list=str(tmp_path / "lists" / "train.txt"), cam_network="net.resnet50_cam",
+        cam_weights_name=str(tmp_path / "res50_cam"), cam_scales=(1.0, 0.5, 1.5, 2.0),
+        irn_network="net.resnet50_irn", irn_weights_name=str(tmp_path / "res50_irn.pth"),
+        beta=10, exp_times=8, sem_seg_bg_thres=0.25, ins_seg_bg_thres=0.25,
+        cam_out_dir=str(tmp_path / "cam"), sem_seg_out_dir=str(tmp_path / "sem"),
+        ins_seg_out_dir=str(tmp_path / "ins"), walk_batch=3)
+    os.makedirs(args.cam_out_dir)
+    os.makedirs(args.sem_seg_out_dir)
+    os.makedirs(args.ins_seg_out_dir)
+
+    make_cam.run(args)
+    for n in names:
+        d = np.load(os.path.join(args.cam_out_dir, n + ".npy"), allow_pickle=True).item()
+        W, H = Image.open(root / "JPEGImages" / (n + ".jpg")).size
+        k = int(labels[int(n.replace("_", ""))].sum())
+        assert d["keys"].dtype == torch.int64 and d["keys"].shape == (k,)
+        assert isinstance(d["cam"], torch.Tensor) and d["cam"].shape == (k, (H - 1) // 4 + 1, (W - 1) // 4 + 1)
+        assert isinstance(d["high_res"], np.ndarray) and d["high_res"].shape == (k, H, W)
+        assert float(d["cam"].max()) <= 1.0 + 1e-6 and float(d["cam"].min()) >= 0.0
+        # the reference's readers: keys + 1 padded (make_sem_seg_labels.py:37), cam.cuda() (:39)
+        assert np.pad(d["keys"] + 1, (1, 0), mode="constant")[0] == 0
+
+    make_sem_seg_labels.run(args)
+    for n in names:
+        png = np.asarray(Image.open(os.path.join(args.sem_seg_out_dir, n + ".png")))
+        W, H = Image.open(root / "JPEGImages" / (n + ".jpg")).size
+        assert png.dtype == np.uint8 and png.shape == (H, W)
+        present = set(np.nonzero(labels[int(n.replace("_", ""))])[0] + 1) | {0}
+        assert set(np.unique(png)) <= present
+
+    make_ins_seg_labels.run(args)
+    written = [n for n in names if os.path.exists(os.path.join(args.ins_seg_out_dir, n + ".npy"))]
+    assert written, "no instance file written"
+    for n in written:
+        d = np.load(os.path.join(args.ins_seg_out_dir, n + ".npy"), allow_pickle=True).item()
+        W, H = Image.open(root / "JPEGImages" / (n + ".jpg")).size
+        assert set(d) == {"score", "mask", "class"}
+        assert d["mask"].dtype == np.bool_ and d["mask"].shape[1:] == (H, W)
+        assert len(d["score"]) == len(d["mask"]) == len(d["class"])
+        # masks of one image never overlap (they come from an argmax)
+        assert d["mask"].sum(0).max() <= 1

@@ -1,0 +1,199 @@
+"""GPU parity of the random walk (through the C ABI) against the reference's own outputs
+(tests/golden/walk.npz), the fp64 oracle, and size-independent properties at BASELINE sizes."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import irn_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+TOL_REF = 1e-4      # north star: <= 1e-4 max-abs fp32 vs the reference, identical argmax
+TOL_F64 = 1e-5      # vs the exact (fp64) operator
+
+
+def _dev():
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    return torch.device("cuda", 0)
+
+
+def _cases(golden):
+    wk = golden("walk")
+    return wk, sorted(k[:-3] for k in wk.files if k.endswith("_rw"))
+
+
+def test_native_library_is_loaded():
+    from irn_amd import _lib
+    maps = open("/proc/self/maps").read()
+    assert "libirn_hip.so" in maps and _lib.lib.irn_version() >= 100
+
+
+@pytest.mark.parametrize("r", [3, 5, 10])
+def test_edge_to_affinity_exact(golden, r):
+    from irn_amd.misc import indexing
+    af = golden("affinity")
+    e = af["r%d_edge" % r]
+    h, w = e.shape
+    ep = np.ones((h + r, w + 2 * r), np.float32)
+    ep[:h, r:r + w] = e
+    pi = indexing.PathIndex(r, (h + r, w + 2 * r))
+    aff = indexing.edge_to_affinity(torch.from_numpy(ep)[None, None].to(_dev()), pi.path_indices)
+    assert aff.shape == (1,) + af["r%d_aff" % r].shape
+    assert np.array_equal(aff[0].cpu().numpy(), af["r%d_aff" % r])
+    # batch of 3 distinct edges
+    eb = np.stack([ep, ep[::-1].copy(), ep[:, ::-1].copy()])
+    ab = indexing.edge_to_affinity(torch.from_numpy(eb).to(_dev()), radius=r, size=ep.shape).cpu().numpy()
+    for b in range(3):
+        pio = O.PathIndexOracle(r, ep.shape)
+        assert np.array_equal(ab[b], O.edge_to_affinity(eb[b].reshape(-1), pio.path_indices))
+
+
+@pytest.mark.parametrize("variant", [0, 1])
+def test_propagate_to_edge_vs_reference_golden(golden, variant):
+    from irn_amd.misc import indexing
+    wk, names = _cases(golden)
+    for n in names:
+        h, w, c, r, b, e = (int(v) for v in wk[n + "_params"])
+        if variant == 1 and r not in (5, 10):
+            continue
+        walker = indexing.RandomWalk(r, _dev())
+        walker.set_option("variant", variant)
+        cam = torch.from_numpy(wk[n + "_cam"]).to(_dev())
+        if n.endswith("_ck"):
+            cam = cam.view(2, c // 2, h, w)
+        edge = torch.from_numpy(wk[n + "_edge"])[None].to(_dev())
+        rw = walker([edge], [cam], beta=b, exp_times=e)[0].cpu().numpy()
+        ref = wk[n + "_rw"]
+        assert rw.shape == ref.shape, n
+        assert np.abs(rw - ref).max() <= TOL_REF, (n, np.abs(rw - ref).max())
+        assert np.array_equal(np.argmax(rw[:, 0], 0), np.argmax(ref[:, 0], 0)), n
+        st = O.propagate_to_edge_stencil(wk[n + "_cam"], wk[n + "_edge"], r, b, e)
+        assert np.abs(rw - st).max() <= TOL_F64, (n, np.abs(rw - st).max())
+        walker.close()
+
+
+def test_propagate_to_edge_dropin_signature(golden):
+    from irn_amd.misc import indexing
+    wk, _ = _cases(golden)
+    n = "r5_b10_e8"
+    x = torch.from_numpy(wk[n + "_cam"]).to(_dev())
+    edge = torch.from_numpy(wk[n + "_edge"])[None].to(_dev())
+    rw = indexing.propagate_to_edge(x, edge, radius=5, beta="10", exp_times="8")   # CLI strings (run_sample.py:47-50)
+    assert tuple(rw.shape) == (3, 1, 32, 32)
+    assert np.abs(rw.cpu().numpy() - wk[n + "_rw"]).max() <= TOL_REF
+    with pytest.raises(Exception):
+        indexing.propagate_to_edge(x, edge, beta=0)
+
+
+@pytest.mark.parametrize("r", [5, 10])
+def test_weights_and_degree_vs_oracle(golden, r):
+    from irn_amd.misc import indexing
+    wk, _ = _cases(golden)
+    n = "r%d_b10_e8" % r
+    edge_np, cam_np = wk[n + "_edge"], wk[n + "_cam"]
+    walker = indexing.RandomWalk(r, _dev())
+    walker([torch.from_numpy(edge_np).to(_dev())], [torch.from_numpy(cam_np).to(_dev())], beta=10, n_sweeps=1)
+    dirs, wts = O.stencil_weights(edge_np, r, 10)
+    w_gpu, inv_deg = walker.export_weights(0, len(dirs))
+    w_gpu = w_gpu.cpu().numpy()
+    # torch.pow is a <=1-ulp powf; ours is the correctly rounded fp64 power: identical to the oracle
+    assert np.array_equal(w_gpu, wts)
+    deg = O.stencil_degree(dirs, wts)
+    assert np.abs(inv_deg.cpu().numpy() * deg - 1).max() <= 1e-14
+    walker.close()
+
+
+def test_ragged_batch_equals_single_images(golden):
+    """Images of different sizes and channel counts in one batch (all channel-chunk kernels, C > 4)."""
+    from irn_amd import synth
+    from irn_amd.misc import indexing
+    shapes = [(40, 52, 1), (33, 70, 2), (64, 64, 3), (28, 36, 4), (47, 31, 7), (30, 30, 9), (130, 66, 1)]
+    edges = [torch.from_numpy(synth.edge_field(h, w, seed=50 + i)).to(_dev()) for i, (h, w, c) in enumerate(shapes)]
+    cams = [torch.from_numpy(synth.cam_blobs(c, h, w, seed=50 + i)).to(_dev()) for i, (h, w, c) in enumerate(shapes)]
+    walker = indexing.RandomWalk(5, _dev())
+    batch = [o.cpu().numpy() for o in walker(edges, cams, beta=10, exp_times=5)]
+    for i in range(len(shapes)):
+        single = walker([edges[i]], [cams[i]], beta=10, exp_times=5)[0].cpu().numpy()
+        assert np.array_equal(batch[i], single), i
+    for i in (0, 4):
+        st = O.propagate_to_edge_stencil(cams[i].cpu().numpy(), edges[i].cpu().numpy(), 5, 10, 5)
+        assert np.abs(batch[i] - st).max() <= TOL_F64
+    walker.set_option("xcd_map", 0)
+    again = walker(edges, cams, beta=10, exp_times=5)
+    assert all(np.array_equal(a.cpu().numpy(), b) for a, b in zip(again, batch))
+    walker.close()
+
+
+def test_narrow_image_and_other_radius_take_generic_path():
+    from irn_amd import synth
+    from irn_amd.misc import indexing
+    for r, (h, w) in ((5, (12, 4)), (7, (20, 26)), (3, (9, 11))):
+        edge = synth.edge_field(h, w, seed=3)
+        cam = synth.cam_blobs(2, h, w, seed=3)
+        walker = indexing.RandomWalk(r, _dev())
+        rw = walker([torch.from_numpy(edge).to(_dev())], [torch.from_numpy(cam).to(_dev())], beta=8, exp_times=6)[0]
+        st = O.propagate_to_edge_stencil(cam, edge, r, 8, 6)
+        assert np.abs(rw.cpu().numpy() - st).max() <= TOL_F64
+        walker.close()
+
+
+def test_instance_split_channels(golden):
+    from irn_amd.misc import indexing
+    ins = golden("instance")
+    for name in "abc":
+        edge, cam, dp = ins[name + "_edge"], ins[name + "_cam"], ins[name + "_dp"]
+        shape = tuple(ins[name + "_instance_map_shape"])
+        inst = np.unpackbits(ins[name + "_instance_map"])[:int(np.prod(shape))].reshape(shape)
+        cmap = np.argmax(inst, 0).astype(np.int32)
+        walker = indexing.RandomWalk(5, _dev())
+        rw = walker([torch.from_numpy(edge).to(_dev())], [torch.from_numpy(cam).to(_dev())], beta=10, exp_times=8,
+                    inst_maps=[torch.from_numpy(cmap).to(_dev())], k_inst=[shape[0]])[0].cpu().numpy()
+        assert rw.shape == ins[name + "_rw"].shape
+        assert np.abs(rw - ins[name + "_rw"]).max() <= TOL_REF
+        walker.close()
+
+
+# ---- BASELINE sizes: properties that need no O(N^3) reference --------------------------------
+
+@pytest.mark.parametrize("r,h,w,c", [(10, 128, 128, 3), (5, 128, 128, 3), (10, 94, 125, 2), (10, 256, 256, 5)])
+def test_full_size_blocked_equals_generic_and_conserves_mass(r, h, w, c):
+    from irn_amd import synth
+    from irn_amd.misc import indexing
+    edge = torch.from_numpy(synth.edge_field(h, w, seed=7)).to(_dev())
+    cam = torch.from_numpy(synth.cam_blobs(c, h, w, seed=7)).to(_dev())
+    walker = indexing.RandomWalk(r, _dev())
+    n_sw = 64
+    fast = walker([edge], [cam], beta=10, n_sweeps=n_sw)[0]
+    n_dirs = {5: 34, 10: 152}[r]
+    _, inv_deg = walker.export_weights(0, n_dirs)
+    walker.set_option("variant", 0)
+    slow = walker([edge], [cam], beta=10, n_sweeps=n_sw)[0]
+    assert (fast - slow).abs().max().item() <= 2e-6          # fp32-row/fp64-combine vs full fp64 accumulation
+    # sum_p deg(p) x(p) is invariant under the column-normalised operator
+    deg = 1.0 / inv_deg
+    x0 = (cam * (1 - edge)).double()
+    m0 = (deg * x0).sum(dim=(1, 2))
+    m1 = (deg * fast[:, 0].double()).sum(dim=(1, 2))
+    assert ((m1 - m0).abs() / m0).max().item() <= 2e-5       # fp32 state rounding over 64 sweeps
+    # linearity in x
+    cam2 = torch.flip(cam, dims=(0,))
+    walker.set_option("variant", 1)
+    a = walker([edge], [cam], beta=10, n_sweeps=16)[0]
+    b = walker([edge], [cam2], beta=10, n_sweeps=16)[0]
+    ab = walker([edge], [0.5 * cam + 2.0 * cam2], beta=10, n_sweeps=16)[0]
+    assert (ab - (0.5 * a + 2.0 * b)).abs().max().item() <= 5e-6
+    walker.close()
+
+
+def test_full_size_128_vs_fp64_oracle():
+    """One 128^2 radius-10 image, 2^8 sweeps, against the fp64 numpy stencil (~40 s on the host)."""
+    from irn_amd import synth
+    from irn_amd.misc import indexing
+    h = w = 128
+    edge = synth.edge_field(h, w, seed=11)
+    cam = synth.cam_blobs(2, h, w, seed=11)
+    rw = indexing.propagate_to_edge(torch.from_numpy(cam).to(_dev()), torch.from_numpy(edge)[None].to(_dev()),
+                                    radius=10, beta=10, exp_times=8).cpu().numpy()
+    st = O.propagate_to_edge_stencil(cam, edge, 10, 10, 8)
+    assert np.abs(rw - st).max() <= TOL_F64
+    assert np.array_equal(np.argmax(rw[:, 0], 0), np.argmax(st[:, 0], 0))
