@@ -12,14 +12,17 @@ from PIL import Image
 pytestmark = pytest.mark.gpu
 
 
-def _make_voc(tmp, n=5):
+os.environ.setdefault("MIOPEN_FIND_MODE", "2")     # fast find: the backbones are plumbing here, not the subject
+
+
+def _make_voc(tmp, n=4):
     root = tmp / "voc"
     (root / "JPEGImages").mkdir(parents=True)
     rng = np.random.RandomState(0)
     names, labels = [], {}
     for i in range(n):
         name = "2008_%06d" % (i + 1)
-        h, w = rng.randint(90, 140), rng.randint(100, 160)
+        h, w = ((96, 128), (113, 150))[i % 2]            # two sizes only: every new conv shape costs a MIOpen find
         img = (rng.rand(h // 8 + 1, w // 8 + 1, 3) * 255).astype(np.uint8)
         Image.fromarray(img).resize((w, h), Image.BICUBIC).save(root / "JPEGImages" / (name + ".jpg"), quality=95)
         names.append(name)
@@ -41,7 +44,7 @@ def test_steps_end_to_end(tmp_path):
     args = argparse.Namespace(
         num_workers=0, voc12_root=str(root), train_list=str(tmp_path / "lists" / "train.txt"),
         infer_list=str(tmp_path / "lists" / "train.txt"), cam_network="net.resnet50_cam",
-        cam_weights_name=str(tmp_path / "res50_cam"), cam_scales=(1.0, 0.5, 1.5, 2.0),
+        cam_weights_name=str(tmp_path / "res50_cam"), cam_scales=(1.0, 0.5, 1.5),
         irn_network="net.resnet50_irn", irn_weights_name=str(tmp_path / "res50_irn.pth"),
         beta=10, exp_times=8, sem_seg_bg_thres=0.25, ins_seg_bg_thres=0.25,
         cam_out_dir=str(tmp_path / "cam"), sem_seg_out_dir=str(tmp_path / "sem"),
