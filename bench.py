@@ -43,6 +43,7 @@ def parse():
     ap.add_argument("--unique", type=int, default=64, help="distinct synthetic images per GPU")
     ap.add_argument("--variant", type=int, default=1)
     ap.add_argument("--xcd-map", type=int, default=1)
+    ap.add_argument("--tile", type=int, default=0, help="sweep tile shape id (irn_walk_set_option 'tile')")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-images", type=int, default=8)
     ap.add_argument("--json-out", default=None)
@@ -120,12 +121,8 @@ def main():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist_
-        dist = dist_
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=device)
+    from irn_amd import parallel
+    dist = parallel.init_process_group(backend="nccl", device=device)      # nccl == RCCL on ROCm; None at N=1
 
     from irn_amd import ops
     from irn_amd.misc import indexing
@@ -146,6 +143,7 @@ def main():
     walker = indexing.RandomWalk(radius, device)
     walker.set_option("variant", a.variant)
     walker.set_option("xcd_map", a.xcd_map)
+    walker.set_option("tile", a.tile)
     walker.enable_timing(True)
     outs = [torch.empty((s[2], 1, h, w), device=device) for s in shapes]
 
@@ -171,10 +169,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    if dist:
-        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = parallel.max_over_ranks(elapsed, dist, device)
 
     # HIP events recorded inside the timed region on the launch stream, read out after it
     sweep_ms, sweep_launches = walker.last_sweep_ms()
@@ -211,7 +206,7 @@ def main():
                                    "label histogram; inputs resident in HBM" %
                                    (a.workload, out_hw[0], out_hw[1], h, w, radius, beta, exp_times),
                        "images_per_gpu_per_step": batch, "sharding": "images strided over ranks, no collective",
-                       "variant": a.variant, "mean_channels": float(np.mean([s[2] for s in shapes]))},
+                       "variant": a.variant, "tile": a.tile, "mean_channels": float(np.mean([s[2] for s in shapes]))},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "sweep_blocked_kernel<%d,CH> (one sweep over the batch = 1 launch per channel-chunk width)" % radius,

@@ -6,6 +6,12 @@ There is no CPU fallback: if the library is missing, importing this module raise
 import ctypes as C
 import os
 
+# PyTorch-ROCm owns the process's HIP runtime (it ships its own libamdhip64.so.7).  It must be
+# loaded BEFORE libirn_hip.so so that the library binds to the same runtime instance: loading ours
+# first pulls in /opt/rocm's copy, the process ends up with two runtimes, and ours then reports
+# "no ROCm-capable device" while torch works (seen on the GPU box under pytest's import order).
+import torch  # noqa: F401  (side effect: HIP runtime of the process)
+
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libirn_hip.so")
 

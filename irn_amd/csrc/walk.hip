@@ -139,28 +139,31 @@ __global__ __launch_bounds__(256) void sweep_generic_kernel(const WalkImg *__res
 
 // ---------------------------------------------------------------------------------------------
 // blocked sweep for radius R in {5, 10}
+//
+// One workgroup (256 threads) owns a TH x TW tile of one image for CH channels; a thread owns P
+// consecutive pixels of a row.  The state tile + halo is staged in LDS.  For every stored direction
+// d = (dy,dx) the thread issues the FORWARD load w_d(p) and the BACKWARD load w_d(p-d) back to
+// back: both come from the same plane, shifted by d, so all but dy rows / |dx| columns of the
+// second load hit in L1/L2 instead of HBM (visiting neighbour rows in raster order instead puts
+// ~one block lifetime between the two touches of a plane and doubles the HBM traffic).
 // ---------------------------------------------------------------------------------------------
-constexpr int SW_TH = 16;   // tile rows
-constexpr int SW_TW = 64;   // tile cols; 16 threads x 4 pixels per row
-constexpr int SW_P = 4;
-
-typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));   // 4-byte-aligned dwordx4
 typedef float f4a __attribute__((ext_vector_type(4)));
+typedef float f2a __attribute__((ext_vector_type(2)));
 
-// Pointers read out of a descriptor in memory are generic ("flat") to the compiler; the hot loop
-// wants global_load with a scalar base + 32-bit lane offset, so say what they are.
+// Pointers read out of a descriptor in memory are generic ("flat") to the compiler; the kernel
+// wants global_load / buffer_load, so say what they are.
 #define IRN_GLOBAL __attribute__((address_space(1)))
 typedef const float IRN_GLOBAL *gcf_t;
 typedef float IRN_GLOBAL *gf_t;
 typedef const double IRN_GLOBAL *gcd_t;
-typedef const f4u IRN_GLOBAL *gcf4_t;
 
-template <int R>
+template <int R, int P, int TH, int TW>
 struct Geo {
-    static constexpr int H = R - 1;                             // halo
-    static constexpr int LH = SW_TH + 2 * H;
-    static constexpr int WIN = ((SW_P + 2 * H + 3) / 4) * 4;     // x window per thread per row (floats)
-    static constexpr int LW = SW_TW - SW_P + WIN;                // LDS row length (multiple of 4)
+    static_assert((TW / P) * TH == 256, "tile must map onto 256 threads");
+    static constexpr int H = R - 1;                              // halo
+    static constexpr int LH = TH + 2 * H;
+    static constexpr int WIN = ((P + 2 * H + P - 1) / P) * P;    // state window per thread per row
+    static constexpr int LW = ((TW - P + WIN + 3) / 4) * 4;      // LDS row length
 };
 
 template <int R>
@@ -185,7 +188,7 @@ struct BlockEnt {
 
 // compile-time loop: f(integral_constant<int,0>) ... f(integral_constant<int,N-1>).  The neighbour
 // loops MUST be expanded at compile time (plane numbers, window offsets and the disc test all fold
-// to constants); `#pragma unroll` gives up on the 19x19 nest of radius 10.
+// to constants); `#pragma unroll` gives up on the nest of radius 10.
 template <int... Is, typename F>
 __device__ __forceinline__ void static_for_impl(std::integer_sequence<int, Is...>, F &&f) {
     (f(std::integral_constant<int, Is>{}), ...);
@@ -195,10 +198,45 @@ __device__ __forceinline__ void static_for(F &&f) {
     static_for_impl(std::make_integer_sequence<int, N>{}, f);
 }
 
-template <int R, int CH>
+// P consecutive weights of one plane through the buffer resource: wave-uniform base in the
+// descriptor, plane/row offset in an SGPR, lane offset in one VGPR -> no per-load VALU address math.
+template <int P>
+__device__ __forceinline__ void load_w(float (&w)[P], __amdgpu_buffer_rsrc_t rsrc, int voff, int soff) {
+    if constexpr (P == 4) {
+        const f4a v = __builtin_bit_cast(f4a, __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, soff, 0));
+        w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
+    } else if constexpr (P == 2) {
+        const f2a v = __builtin_bit_cast(f2a, __builtin_amdgcn_raw_buffer_load_b64(rsrc, voff, soff, 0));
+        w[0] = v.x; w[1] = v.y;
+    } else {
+        w[0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff, soff, 0));
+    }
+}
+
+template <int P, int WIN>
+__device__ __forceinline__ void load_window(float (&xw)[WIN], const float *row) {
+    if constexpr (P == 4) {
+#pragma unroll
+        for (int q = 0; q < WIN / 4; ++q) {
+            const f4a v = reinterpret_cast<const f4a *>(row)[q];
+            xw[4 * q] = v.x; xw[4 * q + 1] = v.y; xw[4 * q + 2] = v.z; xw[4 * q + 3] = v.w;
+        }
+    } else if constexpr (P == 2) {
+#pragma unroll
+        for (int q = 0; q < WIN / 2; ++q) {
+            const f2a v = reinterpret_cast<const f2a *>(row)[q];
+            xw[2 * q] = v.x; xw[2 * q + 1] = v.y;
+        }
+    } else {
+#pragma unroll
+        for (int q = 0; q < WIN; ++q) xw[q] = row[q];
+    }
+}
+
+template <int R, int CH, int P, int TH, int TW>
 __device__ __forceinline__ void sweep_body(const WalkImg &I, const BlockEnt &B, const float *src_,
                                            float *dst_, float *xs) {
-    using G = Geo<R>;
+    using G = Geo<R, P, TH, TW>;
     constexpr int H = G::H, LH = G::LH, LW = G::LW, WIN = G::WIN;
     const int tid = threadIdx.x;
     const int h = I.h, w = I.w;
@@ -206,7 +244,7 @@ __device__ __forceinline__ void sweep_body(const WalkImg &I, const BlockEnt &B, 
     const gcf_t src = (gcf_t)src_ + (size_t)B.c0 * n;
     const gf_t dst = (gf_t)dst_ + (size_t)B.c0 * n;
 
-    // ---- stage x tile + halo for CH channels (zero outside the image) ----
+    // ---- stage state tile + halo for CH channels (zero outside the image) ----
     for (int i = tid; i < CH * LH * LW; i += 256) {
         const int c = i / (LH * LW);
         const int r = i - c * (LH * LW);
@@ -218,67 +256,63 @@ __device__ __forceinline__ void sweep_body(const WalkImg &I, const BlockEnt &B, 
     }
     __syncthreads();
 
-    const int trow = tid / (SW_TW / SW_P);
-    const int tcol = (tid % (SW_TW / SW_P)) * SW_P;
+    const int trow = tid / (TW / P);
+    const int tcol = (tid % (TW / P)) * P;
     const int y = B.ty0 + trow, x = B.tx0 + tcol;
     const bool live = y < h && x < w;
     const unsigned p0 = live ? (unsigned)(y * w + x) : 0u;   // lane offset (elements) into a plane
-    // Weight planes are read through a buffer resource: wave-uniform base in the descriptor, the
-    // plane/row offset in an SGPR, the lane offset p0 in one VGPR -> no per-load VALU address math.
-    // Record 0 is the start of plane 0's front pad.
+    // record 0 of the resource is the start of plane 0's front pad
     const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(
         (void *)(I.wts - I.front_pad), 0, (int)(I.n_dirs * I.plane_stride * 4), 0x00020000);
     const int voff = (int)(p0 * 4u);
     const int ps4 = (int)(I.plane_stride * 4);
     const int fp4 = I.front_pad * 4;
+    const int w4 = w * 4;
 
-    double acc[CH][SW_P];
+    double acc[CH][P];
 #pragma unroll
     for (int c = 0; c < CH; ++c)
 #pragma unroll
-        for (int j = 0; j < SW_P; ++j) acc[c][j] = (double)xs[(c * LH + trow + H) * LW + tcol + H + j];
+        for (int j = 0; j < P; ++j) acc[c][j] = (double)xs[(c * LH + trow + H) * LW + tcol + H + j];
 
-    static_for<2 * H + 1>([&](auto iy) __attribute__((always_inline)) {
-        constexpr int ddy = decltype(iy)::value - H;      // neighbour row offset
-        float part[CH][SW_P];
-        float xw[CH][WIN];
+    static_for<H + 1>([&](auto iy) __attribute__((always_inline)) {
+        constexpr int dy = decltype(iy)::value;            // row of the stored directions (dy, *)
+        float pf[CH][P], pb[CH][P];                        // fp32 partials: forward / backward neighbours
+        float xf[CH][WIN], xb[CH][WIN];                    // state windows of rows y+dy and y-dy
 #pragma unroll
         for (int c = 0; c < CH; ++c) {
-            const f4a *row = reinterpret_cast<const f4a *>(&xs[(c * LH + trow + H + ddy) * LW + tcol]);
+            load_window<P, WIN>(xf[c], &xs[(c * LH + trow + H + dy) * LW + tcol]);
+            if constexpr (dy != 0) load_window<P, WIN>(xb[c], &xs[(c * LH + trow + H - dy) * LW + tcol]);
 #pragma unroll
-            for (int q = 0; q < WIN / 4; ++q) {
-                const f4a v = row[q];
-                xw[c][4 * q + 0] = v.x;
-                xw[c][4 * q + 1] = v.y;
-                xw[c][4 * q + 2] = v.z;
-                xw[c][4 * q + 3] = v.w;
-            }
-#pragma unroll
-            for (int j = 0; j < SW_P; ++j) part[c][j] = 0.f;
+            for (int j = 0; j < P; ++j) pf[c][j] = pb[c][j] = 0.f;
         }
-        const int rowoff4 = ddy * w * 4;                   // wave-uniform, bytes
+        const int rowoff4 = dy * w4;                        // wave-uniform, bytes
         static_for<2 * H + 1>([&](auto ix) __attribute__((always_inline)) {
-            constexpr int ddx = decltype(ix)::value - H;  // neighbour column offset
-            constexpr bool fwd = ddy > 0 || (ddy == 0 && ddx > 0);       // neighbour p+d, weight at p
-            constexpr int sdy = fwd ? ddy : -ddy, sdx = fwd ? ddx : -ddx;  // the stored direction d
-            if constexpr (!(ddy == 0 && ddx == 0) && in_set<R>(sdy, sdx)) {
-                constexpr int pl = plane_of<R>(sdy, sdx);
-                // weight of the pair {p, p+(ddy,ddx)}: stored at p for a forward neighbour, at the
-                // neighbour itself (p + (ddy,ddx) = p - d) for a backward one.
-                const int soff = fp4 + pl * ps4 + (fwd ? 0 : rowoff4 + ddx * 4);
-                const f4a wv = __builtin_bit_cast(f4a, __builtin_amdgcn_raw_buffer_load_b128(wrsrc, voff, soff, 0));
-                const float wj[4] = {wv.x, wv.y, wv.z, wv.w};
+            constexpr int dx = decltype(ix)::value - H;
+            if constexpr (in_set<R>(dy, dx)) {
+                constexpr int pl = plane_of<R>(dy, dx);
+                const int soff = fp4 + pl * ps4;
+                float wf[P], wb[P];
+                load_w<P>(wf, wrsrc, voff, soff);                         // w_d(p)    pairs p with p+d
+                load_w<P>(wb, wrsrc, voff, soff - rowoff4 - dx * 4);      // w_d(p-d)  pairs p with p-d
 #pragma unroll
                 for (int c = 0; c < CH; ++c)
 #pragma unroll
-                    for (int j = 0; j < SW_P; ++j) part[c][j] = fmaf(wj[j], xw[c][H + ddx + j], part[c][j]);
+                    for (int j = 0; j < P; ++j) {
+                        pf[c][j] = fmaf(wf[j], xf[c][H + dx + j], pf[c][j]);
+                        if constexpr (dy != 0)
+                            pb[c][j] = fmaf(wb[j], xb[c][H - dx + j], pb[c][j]);
+                        else
+                            pb[c][j] = fmaf(wb[j], xf[c][H - dx + j], pb[c][j]);
+                    }
             }
         });
 #pragma unroll
         for (int c = 0; c < CH; ++c)
 #pragma unroll
-            for (int j = 0; j < SW_P; ++j) {
-                acc[c][j] += (double)part[c][j];
+            for (int j = 0; j < P; ++j) {
+                acc[c][j] += (double)pf[c][j];
+                acc[c][j] += (double)pb[c][j];
                 // Pin this row's arithmetic here.  Pure ALU nodes carry no ordering and would
                 // otherwise sink to the end of the (single) basic block while the loads stay put,
                 // keeping every weight of the sweep live (512 registers + spills).
@@ -290,7 +324,7 @@ __device__ __forceinline__ void sweep_body(const WalkImg &I, const BlockEnt &B, 
     if (!live) return;
     const gcd_t inv_deg = (gcd_t)I.inv_deg;
 #pragma unroll
-    for (int j = 0; j < SW_P; ++j) {
+    for (int j = 0; j < P; ++j) {
         if (x + j < w) {
             const double inv = inv_deg[p0 + j];
 #pragma unroll
@@ -299,7 +333,7 @@ __device__ __forceinline__ void sweep_body(const WalkImg &I, const BlockEnt &B, 
     }
 }
 
-template <int R, int CH>
+template <int R, int CH, int P, int TH, int TW>
 __global__ __launch_bounds__(256) void sweep_blocked_kernel(const WalkImg *__restrict__ imgs,
                                                             const int4 *__restrict__ block_map, int phase,
                                                             int last) {
@@ -310,12 +344,35 @@ __global__ __launch_bounds__(256) void sweep_blocked_kernel(const WalkImg *__res
     const BlockEnt B{e.x, e.y, e.z, e.w};
     const float *src = (phase & 1) ? I.xb : I.xa;
     float *dst = last ? I.out : ((phase & 1) ? I.xa : I.xb);
-    sweep_body<R, CH>(I, B, src, dst, xs);
+    sweep_body<R, CH, P, TH, TW>(I, B, src, dst, xs);
 }
 
-template <int R>
-constexpr size_t sweep_lds_bytes(int nch) {
-    return sizeof(float) * nch * Geo<R>::LH * Geo<R>::LW;
+// tile shapes selectable with irn_walk_set_option("tile", id)
+struct TileShape {
+    int P, TH, TW;
+};
+constexpr TileShape kTiles[] = {{4, 16, 64}, {4, 32, 32}, {2, 16, 32}, {1, 8, 32}};
+constexpr int kNumTiles = sizeof(kTiles) / sizeof(kTiles[0]);
+
+template <int R, int CH, int T>
+int launch_sweep_tile(const WalkImg *imgs, const int4 *map, int nb, int phase, int last, hipStream_t stream) {
+    constexpr int P = kTiles[T].P, TH = kTiles[T].TH, TW = kTiles[T].TW;
+    using G = Geo<R, P, TH, TW>;
+    const size_t lds = sizeof(float) * CH * G::LH * G::LW;
+    hipLaunchKernelGGL((sweep_blocked_kernel<R, CH, P, TH, TW>), dim3(nb), dim3(256), lds, stream, imgs, map, phase,
+                       last);
+    IRN_LAUNCH_CHECK("sweep_blocked_kernel");
+    return IRN_OK;
+}
+
+template <int R, int CH>
+int launch_sweep(int tile, const WalkImg *imgs, const int4 *map, int nb, int phase, int last, hipStream_t stream) {
+    switch (tile) {
+        case 0: return launch_sweep_tile<R, CH, 0>(imgs, map, nb, phase, last, stream);
+        case 1: return launch_sweep_tile<R, CH, 1>(imgs, map, nb, phase, last, stream);
+        case 2: return launch_sweep_tile<R, CH, 2>(imgs, map, nb, phase, last, stream);
+        default: return launch_sweep_tile<R, CH, 3>(imgs, map, nb, phase, last, stream);
+    }
 }
 
 }  // namespace
@@ -331,6 +388,7 @@ struct irn_walk_ctx {
     const DeviceTable *tab = nullptr;   // raster order
     int variant = 1;                    // 0 generic, 1 blocked (radius 5/10 only)
     int xcd_map = 1;                    // keep all tiles of an image on one XCD
+    int tile = 0;                       // index into kTiles
     int max_chunk = 4;
     // batch
     int n = 0;
@@ -396,6 +454,9 @@ extern "C" int irn_walk_set_option(irn_walk_ctx *ctx, const char *name, int valu
         ctx->variant = value;
     } else if (!strcmp(name, "xcd_map")) {
         ctx->xcd_map = value ? 1 : 0;
+    } else if (!strcmp(name, "tile")) {
+        if (value < 0 || value >= kNumTiles) return fail(IRN_ERR_ARG, "tile must be in [0,%d)", kNumTiles);
+        ctx->tile = value;
     } else if (!strcmp(name, "max_chunk")) {
         if (value < 1 || value > 4) return fail(IRN_ERR_ARG, "max_chunk must be in [1,4]");
         ctx->max_chunk = value;
@@ -490,8 +551,8 @@ extern "C" int irn_walk_configure(irn_walk_ctx *ctx, int n_images, const int32_t
                 for (int c0 = 0; c0 < c[i]; c0 += ctx->max_chunk) {
                     const int nch = std::min(ctx->max_chunk, c[i] - c0);
                     if (nch != cls) continue;
-                    for (int ty = 0; ty < h[i]; ty += SW_TH)
-                        for (int tx = 0; tx < w[i]; tx += SW_TW) {
+                    for (int ty = 0; ty < h[i]; ty += kTiles[ctx->tile].TH)
+                        for (int tx = 0; tx < w[i]; tx += kTiles[ctx->tile].TW) {
                             q[best].push_back(make_int4(i, ty, tx, c0));
                             ++load[best];
                         }
@@ -543,10 +604,7 @@ template <int R, int CH>
 static int launch_blocked_cls(irn_walk_ctx *ctx, int phase, int last, hipStream_t stream) {
     const int nb = ctx->cls_off[CH + 1] - ctx->cls_off[CH];
     if (nb <= 0) return IRN_OK;
-    hipLaunchKernelGGL((sweep_blocked_kernel<R, CH>), dim3(nb), dim3(256), sweep_lds_bytes<R>(CH), stream,
-                       ctx->imgs_dev, ctx->map_dev + ctx->cls_off[CH], phase, last);
-    IRN_LAUNCH_CHECK("sweep_blocked_kernel");
-    return IRN_OK;
+    return launch_sweep<R, CH>(ctx->tile, ctx->imgs_dev, ctx->map_dev + ctx->cls_off[CH], nb, phase, last, stream);
 }
 
 template <int R>

@@ -1,0 +1,84 @@
+#!/usr/bin/env python3
+"""CLI boundary — same flags and step order as reference run_sample.py:8-137, for the three
+label-generation steps this repository implements (make_cam, make_ins_seg, make_sem_seg).
+
+The training / CRF / evaluation steps of the reference (train_cam, eval_cam, cam_to_ir_label,
+train_irn, eval_ins_seg, eval_sem_seg) are outside the hot-path scope; their
+`--*_pass` flags are accepted so existing command lines keep working, and asking for one of them
+is an error rather than a silent skip.  Weights are inputs: --cam_weights_name / --irn_weights_name
+must point at checkpoints written by the reference's training steps (or any state dict with the
+same keys).
+"""
+import argparse
+import os
+
+from irn_amd.misc import pyutils
+
+
+def _flag(v):
+    """The reference declares pass flags without type= (a CLI value arrives as str and fails its
+    `is True` test); parse the usual spellings instead."""
+    if isinstance(v, bool):
+        return v
+    return str(v).strip().lower() in ("1", "true", "yes", "y")
+
+
+def build_parser():
+    p = argparse.ArgumentParser()
+    p.add_argument("--num_workers", default=(os.cpu_count() or 2) // 2, type=int)
+    p.add_argument("--voc12_root", required=True, type=str)
+    p.add_argument("--train_list", default="voc12/train_aug.txt", type=str)
+    p.add_argument("--val_list", default="voc12/val.txt", type=str)
+    p.add_argument("--infer_list", default="voc12/train.txt", type=str)
+    p.add_argument("--chainer_eval_set", default="train", type=str)
+    p.add_argument("--cam_network", default="net.resnet50_cam", type=str)
+    p.add_argument("--cam_scales", default=(1.0, 0.5, 1.5, 2.0), type=float, nargs="+")
+    p.add_argument("--irn_network", default="net.resnet50_irn", type=str)
+    p.add_argument("--beta", default=10, type=float)
+    p.add_argument("--exp_times", default=8, type=int)
+    p.add_argument("--ins_seg_bg_thres", default=0.25, type=float)
+    p.add_argument("--sem_seg_bg_thres", default=0.25, type=float)
+    p.add_argument("--walk_batch", default=16, type=int, help="images per random-walk launch (not in the reference)")
+    p.add_argument("--log_name", default="sample_train_eval", type=str)
+    p.add_argument("--cam_weights_name", default="sess/res50_cam.pth", type=str)
+    p.add_argument("--irn_weights_name", default="sess/res50_irn.pth", type=str)
+    p.add_argument("--cam_out_dir", default="result/cam", type=str)
+    p.add_argument("--ir_label_out_dir", default="result/ir_label", type=str)
+    p.add_argument("--sem_seg_out_dir", default="result/sem_seg", type=str)
+    p.add_argument("--ins_seg_out_dir", default="result/ins_seg", type=str)
+    for name, default in (("train_cam_pass", False), ("make_cam_pass", True), ("eval_cam_pass", False),
+                          ("cam_to_ir_label_pass", False), ("train_irn_pass", False), ("make_ins_seg_pass", True),
+                          ("eval_ins_seg_pass", False), ("make_sem_seg_pass", True), ("eval_sem_seg_pass", False)):
+        p.add_argument("--" + name, default=default, type=_flag)
+    return p
+
+
+OUT_OF_SCOPE = ("train_cam_pass", "eval_cam_pass", "cam_to_ir_label_pass", "train_irn_pass", "eval_ins_seg_pass",
+                "eval_sem_seg_pass")
+
+
+def main(argv=None):
+    args = build_parser().parse_args(argv)
+    for name in OUT_OF_SCOPE:
+        if getattr(args, name):
+            raise SystemExit("--%s: this step is not part of the MI355X hot-path build; run it with the reference" % name)
+    for d in (args.cam_out_dir, args.sem_seg_out_dir, args.ins_seg_out_dir):
+        os.makedirs(d, exist_ok=True)
+    pyutils.Logger(args.log_name + ".log")
+    print(vars(args))
+    if args.make_cam_pass is True:
+        from irn_amd.step import make_cam
+        timer = pyutils.Timer("step.make_cam:")
+        make_cam.run(args)
+    if args.make_ins_seg_pass is True:
+        from irn_amd.step import make_ins_seg_labels
+        timer = pyutils.Timer("step.make_ins_seg_labels:")
+        make_ins_seg_labels.run(args)
+    if args.make_sem_seg_pass is True:
+        from irn_amd.step import make_sem_seg_labels
+        timer = pyutils.Timer("step.make_sem_seg_labels:")  # noqa: F841
+        make_sem_seg_labels.run(args)
+
+
+if __name__ == "__main__":
+    main()

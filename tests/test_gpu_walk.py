@@ -48,8 +48,8 @@ def test_edge_to_affinity_exact(golden, r):
         assert np.array_equal(ab[b], O.edge_to_affinity(eb[b].reshape(-1), pio.path_indices))
 
 
-@pytest.mark.parametrize("variant", [0, 1])
-def test_propagate_to_edge_vs_reference_golden(golden, variant):
+@pytest.mark.parametrize("variant,tile", [(0, 0), (1, 0), (1, 1), (1, 2), (1, 3)])
+def test_propagate_to_edge_vs_reference_golden(golden, variant, tile):
     from irn_amd.misc import indexing
     wk, names = _cases(golden)
     for n in names:
@@ -58,6 +58,7 @@ def test_propagate_to_edge_vs_reference_golden(golden, variant):
             continue
         walker = indexing.RandomWalk(r, _dev())
         walker.set_option("variant", variant)
+        walker.set_option("tile", tile)
         cam = torch.from_numpy(wk[n + "_cam"]).to(_dev())
         if n.endswith("_ck"):
             cam = cam.view(2, c // 2, h, w)
@@ -155,13 +156,16 @@ def test_instance_split_channels(golden):
 
 # ---- BASELINE sizes: properties that need no O(N^3) reference --------------------------------
 
-@pytest.mark.parametrize("r,h,w,c", [(10, 128, 128, 3), (5, 128, 128, 3), (10, 94, 125, 2), (10, 256, 256, 5)])
-def test_full_size_blocked_equals_generic_and_conserves_mass(r, h, w, c):
+@pytest.mark.parametrize("r,h,w,c,tile", [(10, 128, 128, 3, 0), (5, 128, 128, 3, 0), (10, 94, 125, 2, 0),
+                                          (10, 256, 256, 5, 0), (10, 94, 125, 7, 1), (10, 128, 128, 4, 2),
+                                          (5, 94, 125, 6, 2), (10, 125, 94, 3, 3), (5, 128, 128, 1, 3)])
+def test_full_size_blocked_equals_generic_and_conserves_mass(r, h, w, c, tile):
     from irn_amd import synth
     from irn_amd.misc import indexing
     edge = torch.from_numpy(synth.edge_field(h, w, seed=7)).to(_dev())
     cam = torch.from_numpy(synth.cam_blobs(c, h, w, seed=7)).to(_dev())
     walker = indexing.RandomWalk(r, _dev())
+    walker.set_option("tile", tile)
     n_sw = 64
     fast = walker([edge], [cam], beta=10, n_sweeps=n_sw)[0]
     n_dirs = {5: 34, 10: 152}[r]
