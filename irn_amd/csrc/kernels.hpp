@@ -10,6 +10,8 @@ struct DeviceTable {
     int *dir_dy = nullptr, *dir_dx = nullptr;   // [n_dirs]
     int *dir_start = nullptr;                   // [n_dirs+1]
     int *cell_dy = nullptr, *cell_dx = nullptr; // [n_cells]
+    int *plane_tab = nullptr;                   // [radius][2*radius-1]: index of direction (dy, dx=ix-(radius-1))
+                                                // in this table's order, or n_dirs when (dy,dx) is not in the set
     PathTable host;
 };
 

@@ -50,6 +50,9 @@ int get_device_table(int radius, int order, const DeviceTable **out) {
     if (!rc) rc = upload(t->host.start, &t->dir_start);
     if (!rc) rc = upload(t->host.cy, &t->cell_dy);
     if (!rc) rc = upload(t->host.cx, &t->cell_dx);
+    std::vector<int> ptab((size_t)radius * (2 * radius - 1), t->n_dirs);
+    for (int i = 0; i < t->n_dirs; ++i) ptab[(size_t)t->host.dy[i] * (2 * radius - 1) + t->host.dx[i] + radius - 1] = i;
+    if (!rc) rc = upload(ptab, &t->plane_tab);
     if (rc) {
         delete t;
         return rc;

@@ -55,15 +55,18 @@ namespace {
 // small per-pixel kernels (grid.y = image)
 // ---------------------------------------------------------------------------------------------
 
+// Zeroes what the affinity kernel does not write: every plane's front pad and tail, and the whole
+// extra plane n_dirs (the "zero plane" that offsets outside the direction set are mapped to).
 __global__ __launch_bounds__(256) void zero_pad_kernel(const WalkImg *__restrict__ imgs, int n_dirs) {
     const WalkImg I = imgs[blockIdx.y];
     const int d = blockIdx.x;
-    if (d >= n_dirs) return;
+    if (d > n_dirs) return;
     float *plane = I.wts + (long)d * I.plane_stride;
     for (int i = threadIdx.x; i < I.front_pad; i += 256) plane[-1 - i] = 0.f;
     const long n = (long)I.h * I.w;
-    const long tail = I.plane_stride - I.front_pad - n;
-    for (long i = threadIdx.x; i < tail; i += 256) plane[n + i] = 0.f;
+    const long first = d == n_dirs ? 0 : n;
+    const long end = I.plane_stride - I.front_pad;
+    for (long i = first + threadIdx.x; i < end; i += 256) plane[i] = 0.f;
 }
 
 // deg(p) = 1 + sum_d [ w_d(p) + w_d(p-d) ] in fp64; stores 1/deg.  (Column sum of
@@ -235,7 +238,7 @@ __device__ __forceinline__ void load_window(float (&xw)[WIN], const float *row) 
 
 template <int R, int CH, int P, int TH, int TW>
 __device__ __forceinline__ void sweep_body(const WalkImg &I, const BlockEnt &B, const float *src_,
-                                           float *dst_, float *xs) {
+                                           float *dst_, const int *__restrict__ plane_tab, float *xs) {
     using G = Geo<R, P, TH, TW>;
     constexpr int H = G::H, LH = G::LH, LW = G::LW, WIN = G::WIN;
     const int tid = threadIdx.x;
@@ -261,9 +264,9 @@ __device__ __forceinline__ void sweep_body(const WalkImg &I, const BlockEnt &B, 
     const int y = B.ty0 + trow, x = B.tx0 + tcol;
     const bool live = y < h && x < w;
     const unsigned p0 = live ? (unsigned)(y * w + x) : 0u;   // lane offset (elements) into a plane
-    // record 0 of the resource is the start of plane 0's front pad
+    // record 0 of the resource is the start of plane 0's front pad; plane n_dirs is all zeros
     const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(
-        (void *)(I.wts - I.front_pad), 0, (int)(I.n_dirs * I.plane_stride * 4), 0x00020000);
+        (void *)(I.wts - I.front_pad), 0, (int)((I.n_dirs + 1) * I.plane_stride * 4), 0x00020000);
     const int voff = (int)(p0 * 4u);
     const int ps4 = (int)(I.plane_stride * 4);
     const int fp4 = I.front_pad * 4;
@@ -275,37 +278,39 @@ __device__ __forceinline__ void sweep_body(const WalkImg &I, const BlockEnt &B, 
 #pragma unroll
         for (int j = 0; j < P; ++j) acc[c][j] = (double)xs[(c * LH + trow + H) * LW + tcol + H + j];
 
-    static_for<H + 1>([&](auto iy) __attribute__((always_inline)) {
-        constexpr int dy = decltype(iy)::value;            // row of the stored directions (dy, *)
+    // Rows of stored directions are a RUNTIME loop (the 2H+1 column offsets inside are expanded):
+    // the body stays a few KB and lives in the instruction cache.  The fully expanded form (10-20k
+    // instructions of straight-line code) was instruction-fetch bound: 50-100 us per workgroup
+    // regardless of how many workgroups were resident (profiles/r01_s2_*).  Offsets (dy,dx) that
+    // are not in the direction set read the all-zero plane instead of branching, so the 2(2H+1)
+    // loads of a row are issued together.
+    const float *xrow = &xs[(trow + H) * LW + tcol];
+#pragma unroll 1
+    for (int dy = 0; dy <= H; ++dy) {
         float pf[CH][P], pb[CH][P];                        // fp32 partials: forward / backward neighbours
         float xf[CH][WIN], xb[CH][WIN];                    // state windows of rows y+dy and y-dy
 #pragma unroll
         for (int c = 0; c < CH; ++c) {
-            load_window<P, WIN>(xf[c], &xs[(c * LH + trow + H + dy) * LW + tcol]);
-            if constexpr (dy != 0) load_window<P, WIN>(xb[c], &xs[(c * LH + trow + H - dy) * LW + tcol]);
+            load_window<P, WIN>(xf[c], xrow + (c * LH + dy) * LW);
+            load_window<P, WIN>(xb[c], xrow + (c * LH - dy) * LW);
 #pragma unroll
             for (int j = 0; j < P; ++j) pf[c][j] = pb[c][j] = 0.f;
         }
         const int rowoff4 = dy * w4;                        // wave-uniform, bytes
+        const int *prow = plane_tab + dy * (2 * H + 1);
         static_for<2 * H + 1>([&](auto ix) __attribute__((always_inline)) {
             constexpr int dx = decltype(ix)::value - H;
-            if constexpr (in_set<R>(dy, dx)) {
-                constexpr int pl = plane_of<R>(dy, dx);
-                const int soff = fp4 + pl * ps4;
-                float wf[P], wb[P];
-                load_w<P>(wf, wrsrc, voff, soff);                         // w_d(p)    pairs p with p+d
-                load_w<P>(wb, wrsrc, voff, soff - rowoff4 - dx * 4);      // w_d(p-d)  pairs p with p-d
+            const int soff = fp4 + prow[dx + H] * ps4;                    // scalar: table entry * plane bytes
+            float wf[P], wb[P];
+            load_w<P>(wf, wrsrc, voff, soff);                             // w_d(p)    pairs p with p+d
+            load_w<P>(wb, wrsrc, voff, soff - rowoff4 - dx * 4);          // w_d(p-d)  pairs p with p-d
 #pragma unroll
-                for (int c = 0; c < CH; ++c)
+            for (int c = 0; c < CH; ++c)
 #pragma unroll
-                    for (int j = 0; j < P; ++j) {
-                        pf[c][j] = fmaf(wf[j], xf[c][H + dx + j], pf[c][j]);
-                        if constexpr (dy != 0)
-                            pb[c][j] = fmaf(wb[j], xb[c][H - dx + j], pb[c][j]);
-                        else
-                            pb[c][j] = fmaf(wb[j], xf[c][H - dx + j], pb[c][j]);
-                    }
-            }
+                for (int j = 0; j < P; ++j) {
+                    pf[c][j] = fmaf(wf[j], xf[c][H + dx + j], pf[c][j]);
+                    pb[c][j] = fmaf(wb[j], xb[c][H - dx + j], pb[c][j]);
+                }
         });
 #pragma unroll
         for (int c = 0; c < CH; ++c)
@@ -313,13 +318,8 @@ __device__ __forceinline__ void sweep_body(const WalkImg &I, const BlockEnt &B, 
             for (int j = 0; j < P; ++j) {
                 acc[c][j] += (double)pf[c][j];
                 acc[c][j] += (double)pb[c][j];
-                // Pin this row's arithmetic here.  Pure ALU nodes carry no ordering and would
-                // otherwise sink to the end of the (single) basic block while the loads stay put,
-                // keeping every weight of the sweep live (512 registers + spills).
-                asm volatile("" : "+v"(acc[c][j]));
             }
-        __builtin_amdgcn_sched_barrier(0);
-    });
+    }
 
     if (!live) return;
     const gcd_t inv_deg = (gcd_t)I.inv_deg;
@@ -333,9 +333,12 @@ __device__ __forceinline__ void sweep_body(const WalkImg &I, const BlockEnt &B, 
     }
 }
 
-template <int R, int CH, int P, int TH, int TW>
-__global__ __launch_bounds__(256) void sweep_blocked_kernel(const WalkImg *__restrict__ imgs,
-                                                            const int4 *__restrict__ block_map, int phase,
+// MAXW caps the occupancy the register allocator aims for: with a low cap it spends registers on
+// keeping 10+ weight loads in flight per wave instead of squeezing into 64 VGPRs with 2-3 in flight.
+template <int R, int CH, int P, int TH, int TW, int MAXW>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, MAXW))) void sweep_blocked_kernel(const WalkImg *__restrict__ imgs,
+                                                            const int4 *__restrict__ block_map,
+                                                            const int *__restrict__ plane_tab, int phase,
                                                             int last) {
     extern __shared__ __attribute__((aligned(16))) float xs[];
     const int4 e = block_map[blockIdx.x];
@@ -344,34 +347,41 @@ __global__ __launch_bounds__(256) void sweep_blocked_kernel(const WalkImg *__res
     const BlockEnt B{e.x, e.y, e.z, e.w};
     const float *src = (phase & 1) ? I.xb : I.xa;
     float *dst = last ? I.out : ((phase & 1) ? I.xa : I.xb);
-    sweep_body<R, CH, P, TH, TW>(I, B, src, dst, xs);
+    sweep_body<R, CH, P, TH, TW>(I, B, src, dst, plane_tab, xs);
 }
 
 // tile shapes selectable with irn_walk_set_option("tile", id)
 struct TileShape {
-    int P, TH, TW;
+    int P, TH, TW, MAXW;
 };
-constexpr TileShape kTiles[] = {{4, 16, 64}, {4, 32, 32}, {2, 16, 32}, {1, 8, 32}};
+constexpr TileShape kTiles[] = {{4, 16, 64, 4}, {4, 16, 64, 8}, {2, 16, 32, 4}, {1, 8, 32, 4},
+                                {1, 8, 32, 8},  {4, 32, 32, 4}, {2, 16, 32, 8}, {4, 8, 128, 4}};
 constexpr int kNumTiles = sizeof(kTiles) / sizeof(kTiles[0]);
 
 template <int R, int CH, int T>
-int launch_sweep_tile(const WalkImg *imgs, const int4 *map, int nb, int phase, int last, hipStream_t stream) {
-    constexpr int P = kTiles[T].P, TH = kTiles[T].TH, TW = kTiles[T].TW;
+int launch_sweep_tile(const WalkImg *imgs, const int4 *map, const int *ptab, int nb, int phase, int last,
+                      hipStream_t stream) {
+    constexpr int P = kTiles[T].P, TH = kTiles[T].TH, TW = kTiles[T].TW, MAXW = kTiles[T].MAXW;
     using G = Geo<R, P, TH, TW>;
     const size_t lds = sizeof(float) * CH * G::LH * G::LW;
-    hipLaunchKernelGGL((sweep_blocked_kernel<R, CH, P, TH, TW>), dim3(nb), dim3(256), lds, stream, imgs, map, phase,
-                       last);
+    hipLaunchKernelGGL((sweep_blocked_kernel<R, CH, P, TH, TW, MAXW>), dim3(nb), dim3(256), lds, stream, imgs, map, ptab,
+                       phase, last);
     IRN_LAUNCH_CHECK("sweep_blocked_kernel");
     return IRN_OK;
 }
 
 template <int R, int CH>
-int launch_sweep(int tile, const WalkImg *imgs, const int4 *map, int nb, int phase, int last, hipStream_t stream) {
+int launch_sweep(int tile, const WalkImg *imgs, const int4 *map, const int *ptab, int nb, int phase, int last,
+                 hipStream_t stream) {
     switch (tile) {
-        case 0: return launch_sweep_tile<R, CH, 0>(imgs, map, nb, phase, last, stream);
-        case 1: return launch_sweep_tile<R, CH, 1>(imgs, map, nb, phase, last, stream);
-        case 2: return launch_sweep_tile<R, CH, 2>(imgs, map, nb, phase, last, stream);
-        default: return launch_sweep_tile<R, CH, 3>(imgs, map, nb, phase, last, stream);
+        case 0: return launch_sweep_tile<R, CH, 0>(imgs, map, ptab, nb, phase, last, stream);
+        case 1: return launch_sweep_tile<R, CH, 1>(imgs, map, ptab, nb, phase, last, stream);
+        case 2: return launch_sweep_tile<R, CH, 2>(imgs, map, ptab, nb, phase, last, stream);
+        case 3: return launch_sweep_tile<R, CH, 3>(imgs, map, ptab, nb, phase, last, stream);
+        case 4: return launch_sweep_tile<R, CH, 4>(imgs, map, ptab, nb, phase, last, stream);
+        case 5: return launch_sweep_tile<R, CH, 5>(imgs, map, ptab, nb, phase, last, stream);
+        case 6: return launch_sweep_tile<R, CH, 6>(imgs, map, ptab, nb, phase, last, stream);
+        default: return launch_sweep_tile<R, CH, 7>(imgs, map, ptab, nb, phase, last, stream);
     }
 }
 
@@ -389,6 +399,9 @@ struct irn_walk_ctx {
     int variant = 1;                    // 0 generic, 1 blocked (radius 5/10 only)
     int xcd_map = 1;                    // keep all tiles of an image on one XCD
     int tile = 0;                       // index into kTiles
+    int use_streams = 1;                // run the channel-chunk classes of a sweep on separate streams
+    hipStream_t side[3] = {nullptr, nullptr, nullptr};
+    hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
     int max_chunk = 4;
     // batch
     int n = 0;
@@ -437,6 +450,11 @@ extern "C" int irn_walk_destroy(irn_walk_ctx *ctx) {
     if (ctx->jobs_dev) (void)hipFree(ctx->jobs_dev);
     if (ctx->map_dev) (void)hipFree(ctx->map_dev);
     for (hipEvent_t e : ctx->ev_pool) (void)hipEventDestroy(e);
+    for (int k = 0; k < 3; ++k) {
+        if (ctx->side[k]) (void)hipStreamDestroy(ctx->side[k]);
+        if (ctx->ev_join[k]) (void)hipEventDestroy(ctx->ev_join[k]);
+    }
+    if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
     for (int k = 0; k < 2; ++k) {
         if (ctx->stage[k]) (void)hipHostFree(ctx->stage[k]);
         if (ctx->stage_ev[k]) (void)hipEventDestroy(ctx->stage_ev[k]);
@@ -454,6 +472,8 @@ extern "C" int irn_walk_set_option(irn_walk_ctx *ctx, const char *name, int valu
         ctx->variant = value;
     } else if (!strcmp(name, "xcd_map")) {
         ctx->xcd_map = value ? 1 : 0;
+    } else if (!strcmp(name, "streams")) {
+        ctx->use_streams = value ? 1 : 0;
     } else if (!strcmp(name, "tile")) {
         if (value < 0 || value >= kNumTiles) return fail(IRN_ERR_ARG, "tile must be in [0,%d)", kNumTiles);
         ctx->tile = value;
@@ -517,7 +537,7 @@ extern "C" int irn_walk_configure(irn_walk_ctx *ctx, int n_images, const int32_t
         ctx->front_pad[i] = fp;
         ctx->plane_stride[i] = ps;
         ctx->off_wts[i] = off;
-        off += round_up(sizeof(float) * ps * ctx->tab->n_dirs, 256);
+        off += round_up(sizeof(float) * ps * (ctx->tab->n_dirs + 1), 256);
         ctx->off_deg[i] = off;
         off += round_up(sizeof(double) * npx, 256);
         ctx->off_xa[i] = off;
@@ -604,15 +624,19 @@ template <int R, int CH>
 static int launch_blocked_cls(irn_walk_ctx *ctx, int phase, int last, hipStream_t stream) {
     const int nb = ctx->cls_off[CH + 1] - ctx->cls_off[CH];
     if (nb <= 0) return IRN_OK;
-    return launch_sweep<R, CH>(ctx->tile, ctx->imgs_dev, ctx->map_dev + ctx->cls_off[CH], nb, phase, last, stream);
+    return launch_sweep<R, CH>(ctx->tile, ctx->imgs_dev, ctx->map_dev + ctx->cls_off[CH], ctx->tab->plane_tab, nb,
+                               phase, last, stream);
 }
 
+// One sweep = one launch per channel-chunk width present in the batch.  The widths touch disjoint
+// images, so each runs its whole chain of sweeps on its own stream (st[CH-1]); a width with a handful
+// of workgroups then overlaps the big one instead of costing a full kernel latency per sweep.
 template <int R>
-static int launch_blocked(irn_walk_ctx *ctx, int phase, int last, hipStream_t stream) {
-    int rc = launch_blocked_cls<R, 1>(ctx, phase, last, stream);
-    if (!rc) rc = launch_blocked_cls<R, 2>(ctx, phase, last, stream);
-    if (!rc) rc = launch_blocked_cls<R, 3>(ctx, phase, last, stream);
-    if (!rc) rc = launch_blocked_cls<R, 4>(ctx, phase, last, stream);
+static int launch_blocked(irn_walk_ctx *ctx, int phase, int last, hipStream_t const *st) {
+    int rc = launch_blocked_cls<R, 1>(ctx, phase, last, st[0]);
+    if (!rc) rc = launch_blocked_cls<R, 2>(ctx, phase, last, st[1]);
+    if (!rc) rc = launch_blocked_cls<R, 3>(ctx, phase, last, st[2]);
+    if (!rc) rc = launch_blocked_cls<R, 4>(ctx, phase, last, st[3]);
     return rc;
 }
 
@@ -670,7 +694,7 @@ extern "C" int irn_walk_run(irn_walk_ctx *ctx, const float *const *edge_dev, con
     IRN_HIP_TRY(hipEventRecord(ctx->stage_ev[slot], stream));
 
     const DeviceTable &tab = *ctx->tab;
-    hipLaunchKernelGGL(zero_pad_kernel, dim3(tab.n_dirs, n), dim3(256), 0, stream, ctx->imgs_dev, tab.n_dirs);
+    hipLaunchKernelGGL(zero_pad_kernel, dim3(tab.n_dirs + 1, n), dim3(256), 0, stream, ctx->imgs_dev, tab.n_dirs);
     IRN_LAUNCH_CHECK("zero_pad_kernel");
     int rc = launch_affinity(ctx->jobs_dev, n, ctx->max_h, ctx->max_w, tab, true, beta, stream);
     if (rc) return rc;
@@ -682,6 +706,23 @@ extern "C" int irn_walk_run(irn_walk_ctx *ctx, const float *const *edge_dev, con
     IRN_LAUNCH_CHECK("x0_kernel");
 
     const bool blocked = ctx->variant == 1 && ctx->all_blocked_ok;
+    // stream of every channel-chunk class: the class with most workgroups stays on the caller's stream
+    hipStream_t st[4] = {stream, stream, stream, stream};
+    int n_side = 0;
+    if (blocked && ctx->use_streams && n_sweeps > 0) {
+        int big = 1;
+        for (int k = 2; k <= 4; ++k)
+            if (ctx->cls_off[k + 1] - ctx->cls_off[k] > ctx->cls_off[big + 1] - ctx->cls_off[big]) big = k;
+        for (int k = 1; k <= 4; ++k) {
+            if (k == big || ctx->cls_off[k + 1] == ctx->cls_off[k]) continue;
+            if (!ctx->side[n_side]) {
+                IRN_HIP_TRY(hipStreamCreateWithFlags(&ctx->side[n_side], hipStreamNonBlocking));
+                IRN_HIP_TRY(hipEventCreateWithFlags(&ctx->ev_join[n_side], hipEventDisableTiming));
+            }
+            st[k - 1] = ctx->side[n_side++];
+        }
+        if (n_side && !ctx->ev_fork) IRN_HIP_TRY(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
+    }
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     if (ctx->timing) {
         while (ctx->ev_pool.size() < ctx->ev_used + 2) {
@@ -693,16 +734,24 @@ extern "C" int irn_walk_run(irn_walk_ctx *ctx, const float *const *edge_dev, con
         ev1 = ctx->ev_pool[ctx->ev_used + 1];
         IRN_HIP_TRY(hipEventRecord(ev0, stream));
     }
+    if (n_side) {
+        IRN_HIP_TRY(hipEventRecord(ctx->ev_fork, stream));
+        for (int k = 0; k < n_side; ++k) IRN_HIP_TRY(hipStreamWaitEvent(ctx->side[k], ctx->ev_fork, 0));
+    }
     for (int t = 0; t < n_sweeps; ++t) {
         const int last = (t == n_sweeps - 1) ? 1 : 0;
         if (blocked) {
-            rc = ctx->radius == 5 ? launch_blocked<5>(ctx, t, last, stream) : launch_blocked<10>(ctx, t, last, stream);
+            rc = ctx->radius == 5 ? launch_blocked<5>(ctx, t, last, st) : launch_blocked<10>(ctx, t, last, st);
             if (rc) return rc;
         } else {
             hipLaunchKernelGGL(sweep_generic_kernel, dim3(pix_blocks, n), dim3(256), 0, stream, ctx->imgs_dev,
                                tab.dir_dy, tab.dir_dx, tab.n_dirs, t, last);
             IRN_LAUNCH_CHECK("sweep_generic_kernel");
         }
+    }
+    for (int k = 0; k < n_side; ++k) {
+        IRN_HIP_TRY(hipEventRecord(ctx->ev_join[k], ctx->side[k]));
+        IRN_HIP_TRY(hipStreamWaitEvent(stream, ctx->ev_join[k], 0));
     }
     if (ctx->timing) {
         IRN_HIP_TRY(hipEventRecord(ev1, stream));

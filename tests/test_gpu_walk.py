@@ -48,7 +48,7 @@ def test_edge_to_affinity_exact(golden, r):
         assert np.array_equal(ab[b], O.edge_to_affinity(eb[b].reshape(-1), pio.path_indices))
 
 
-@pytest.mark.parametrize("variant,tile", [(0, 0), (1, 0), (1, 1), (1, 2), (1, 3)])
+@pytest.mark.parametrize("variant,tile", [(0, 0), (1, 0), (1, 1), (1, 2), (1, 3), (1, 4), (1, 5), (1, 6), (1, 7)])
 def test_propagate_to_edge_vs_reference_golden(golden, variant, tile):
     from irn_amd.misc import indexing
     wk, names = _cases(golden)
@@ -119,9 +119,10 @@ def test_ragged_batch_equals_single_images(golden):
     for i in (0, 4):
         st = O.propagate_to_edge_stencil(cams[i].cpu().numpy(), edges[i].cpu().numpy(), 5, 10, 5)
         assert np.abs(batch[i] - st).max() <= TOL_F64
-    walker.set_option("xcd_map", 0)
-    again = walker(edges, cams, beta=10, exp_times=5)
-    assert all(np.array_equal(a.cpu().numpy(), b) for a, b in zip(again, batch))
+    for opt in ("xcd_map", "streams"):
+        walker.set_option(opt, 0)
+        again = walker(edges, cams, beta=10, exp_times=5)
+        assert all(np.array_equal(a.cpu().numpy(), b) for a, b in zip(again, batch)), opt
     walker.close()
 
 
@@ -158,7 +159,9 @@ def test_instance_split_channels(golden):
 
 @pytest.mark.parametrize("r,h,w,c,tile", [(10, 128, 128, 3, 0), (5, 128, 128, 3, 0), (10, 94, 125, 2, 0),
                                           (10, 256, 256, 5, 0), (10, 94, 125, 7, 1), (10, 128, 128, 4, 2),
-                                          (5, 94, 125, 6, 2), (10, 125, 94, 3, 3), (5, 128, 128, 1, 3)])
+                                          (5, 94, 125, 6, 2), (10, 125, 94, 3, 3), (5, 128, 128, 1, 3),
+                                          (10, 94, 125, 5, 4), (5, 125, 94, 2, 5), (10, 128, 128, 2, 6),
+                                          (10, 130, 250, 3, 7)])
 def test_full_size_blocked_equals_generic_and_conserves_mass(r, h, w, c, tile):
     from irn_amd import synth
     from irn_amd.misc import indexing
