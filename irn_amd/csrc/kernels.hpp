@@ -11,7 +11,7 @@ struct DeviceTable {
     int *dir_start = nullptr;                   // [n_dirs+1]
     int *cell_dy = nullptr, *cell_dx = nullptr; // [n_cells]
     int *plane_tab = nullptr;                   // [radius][2*radius-1]: index of direction (dy, dx=ix-(radius-1))
-                                                // in this table's order, or n_dirs when (dy,dx) is not in the set
+                                                // in this table's order, or ~(nearest in-set index of the row)
     PathTable host;
 };
 

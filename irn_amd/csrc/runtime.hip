@@ -50,8 +50,24 @@ int get_device_table(int radius, int order, const DeviceTable **out) {
     if (!rc) rc = upload(t->host.start, &t->dir_start);
     if (!rc) rc = upload(t->host.cy, &t->cell_dy);
     if (!rc) rc = upload(t->host.cx, &t->cell_dx);
-    std::vector<int> ptab((size_t)radius * (2 * radius - 1), t->n_dirs);
-    for (int i = 0; i < t->n_dirs; ++i) ptab[(size_t)t->host.dy[i] * (2 * radius - 1) + t->host.dx[i] + radius - 1] = i;
+    // plane_tab[dy][ix], dx = ix - (radius-1): index of direction (dy,dx) if it is in the set; otherwise
+    // ~index of the nearest in-set direction of the same row (the sweep kernel loads that plane — hot in
+    // cache — and multiplies the weight by zero, instead of branching around the slot).
+    const int wcols = 2 * radius - 1;
+    std::vector<int> ptab((size_t)radius * wcols, 0);
+    {
+        std::vector<int> exact((size_t)radius * wcols, -1);
+        for (int i = 0; i < t->n_dirs; ++i) exact[(size_t)t->host.dy[i] * wcols + t->host.dx[i] + radius - 1] = i;
+        for (int dy = 0; dy < radius; ++dy)
+            for (int ix = 0; ix < wcols; ++ix) {
+                int best = -1;
+                for (int step = 0; step < wcols && best < 0; ++step) {
+                    if (ix - step >= 0 && exact[(size_t)dy * wcols + ix - step] >= 0) best = exact[(size_t)dy * wcols + ix - step];
+                    else if (ix + step < wcols && exact[(size_t)dy * wcols + ix + step] >= 0) best = exact[(size_t)dy * wcols + ix + step];
+                }
+                ptab[(size_t)dy * wcols + ix] = exact[(size_t)dy * wcols + ix] >= 0 ? best : ~best;
+            }
+    }
     if (!rc) rc = upload(ptab, &t->plane_tab);
     if (rc) {
         delete t;

@@ -55,18 +55,16 @@ namespace {
 // small per-pixel kernels (grid.y = image)
 // ---------------------------------------------------------------------------------------------
 
-// Zeroes what the affinity kernel does not write: every plane's front pad and tail, and the whole
-// extra plane n_dirs (the "zero plane" that offsets outside the direction set are mapped to).
+// Zeroes what the affinity kernel does not write: every plane's front pad and tail.
 __global__ __launch_bounds__(256) void zero_pad_kernel(const WalkImg *__restrict__ imgs, int n_dirs) {
     const WalkImg I = imgs[blockIdx.y];
     const int d = blockIdx.x;
-    if (d > n_dirs) return;
+    if (d >= n_dirs) return;
     float *plane = I.wts + (long)d * I.plane_stride;
     for (int i = threadIdx.x; i < I.front_pad; i += 256) plane[-1 - i] = 0.f;
     const long n = (long)I.h * I.w;
-    const long first = d == n_dirs ? 0 : n;
     const long end = I.plane_stride - I.front_pad;
-    for (long i = first + threadIdx.x; i < end; i += 256) plane[i] = 0.f;
+    for (long i = n + threadIdx.x; i < end; i += 256) plane[i] = 0.f;
 }
 
 // deg(p) = 1 + sum_d [ w_d(p) + w_d(p-d) ] in fp64; stores 1/deg.  (Column sum of
@@ -264,9 +262,9 @@ __device__ __forceinline__ void sweep_body(const WalkImg &I, const BlockEnt &B, 
     const int y = B.ty0 + trow, x = B.tx0 + tcol;
     const bool live = y < h && x < w;
     const unsigned p0 = live ? (unsigned)(y * w + x) : 0u;   // lane offset (elements) into a plane
-    // record 0 of the resource is the start of plane 0's front pad; plane n_dirs is all zeros
+    // record 0 of the resource is the start of plane 0's front pad
     const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(
-        (void *)(I.wts - I.front_pad), 0, (int)((I.n_dirs + 1) * I.plane_stride * 4), 0x00020000);
+        (void *)(I.wts - I.front_pad), 0, (int)(I.n_dirs * I.plane_stride * 4), 0x00020000);
     const int voff = (int)(p0 * 4u);
     const int ps4 = (int)(I.plane_stride * 4);
     const int fp4 = I.front_pad * 4;
@@ -282,8 +280,9 @@ __device__ __forceinline__ void sweep_body(const WalkImg &I, const BlockEnt &B, 
     // the body stays a few KB and lives in the instruction cache.  The fully expanded form (10-20k
     // instructions of straight-line code) was instruction-fetch bound: 50-100 us per workgroup
     // regardless of how many workgroups were resident (profiles/r01_s2_*).  Offsets (dy,dx) that
-    // are not in the direction set read the all-zero plane instead of branching, so the 2(2H+1)
-    // loads of a row are issued together.
+    // are not in the direction set do not branch: they load the nearest in-set plane of the row (hot
+    // in cache) and scale the weight by 0, so the 2(2H+1) loads of a row are issued together.  (A
+    // dedicated all-zero plane for those slots cost +40 % fabric traffic, profiles/r01_s3_*.)
     const float *xrow = &xs[(trow + H) * LW + tcol];
 #pragma unroll 1
     for (int dy = 0; dy <= H; ++dy) {
@@ -300,10 +299,17 @@ __device__ __forceinline__ void sweep_body(const WalkImg &I, const BlockEnt &B, 
         const int *prow = plane_tab + dy * (2 * H + 1);
         static_for<2 * H + 1>([&](auto ix) __attribute__((always_inline)) {
             constexpr int dx = decltype(ix)::value - H;
-            const int soff = fp4 + prow[dx + H] * ps4;                    // scalar: table entry * plane bytes
+            const int ent = prow[dx + H];                                 // scalar table entry
+            const int soff = fp4 + (ent < 0 ? ~ent : ent) * ps4;
+            const float keep = ent < 0 ? 0.f : 1.f;
             float wf[P], wb[P];
             load_w<P>(wf, wrsrc, voff, soff);                             // w_d(p)    pairs p with p+d
             load_w<P>(wb, wrsrc, voff, soff - rowoff4 - dx * 4);          // w_d(p-d)  pairs p with p-d
+#pragma unroll
+            for (int j = 0; j < P; ++j) {
+                wf[j] *= keep;
+                wb[j] *= keep;
+            }
 #pragma unroll
             for (int c = 0; c < CH; ++c)
 #pragma unroll
@@ -344,10 +350,33 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, MAXW))) 
     const int4 e = block_map[blockIdx.x];
     if (e.x < 0) return;
     const WalkImg I = imgs[e.x];
-    const BlockEnt B{e.x, e.y, e.z, e.w};
+    const BlockEnt B{e.x, e.y, e.z, e.w & 0xffff};
     const float *src = (phase & 1) ? I.xb : I.xa;
     float *dst = last ? I.out : ((phase & 1) ? I.xa : I.xb);
     sweep_body<R, CH, P, TH, TW>(I, B, src, dst, plane_tab, xs);
+}
+
+// All channel-chunk widths of a sweep in ONE launch: the workgroup's width comes from its block-map
+// entry.  The register budget is that of the widest body, which the occupancy cap (MAXW) already
+// grants every width, and the dispatcher balances small and large widths inside one grid instead
+// of the small widths' chains setting the pace on their own streams.
+template <int R, int P, int TH, int TW, int MAXW>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, MAXW))) void sweep_merged_kernel(
+    const WalkImg *__restrict__ imgs, const int4 *__restrict__ block_map, const int *__restrict__ plane_tab, int phase,
+    int last) {
+    extern __shared__ __attribute__((aligned(16))) float xs[];
+    const int4 e = block_map[blockIdx.x];
+    if (e.x < 0) return;
+    const WalkImg I = imgs[e.x];
+    const BlockEnt B{e.x, e.y, e.z, e.w & 0xffff};
+    const float *src = (phase & 1) ? I.xb : I.xa;
+    float *dst = last ? I.out : ((phase & 1) ? I.xa : I.xb);
+    switch (e.w >> 16) {
+        case 1: sweep_body<R, 1, P, TH, TW>(I, B, src, dst, plane_tab, xs); break;
+        case 2: sweep_body<R, 2, P, TH, TW>(I, B, src, dst, plane_tab, xs); break;
+        case 3: sweep_body<R, 3, P, TH, TW>(I, B, src, dst, plane_tab, xs); break;
+        default: sweep_body<R, 4, P, TH, TW>(I, B, src, dst, plane_tab, xs); break;
+    }
 }
 
 // tile shapes selectable with irn_walk_set_option("tile", id)
@@ -368,6 +397,33 @@ int launch_sweep_tile(const WalkImg *imgs, const int4 *map, const int *ptab, int
                        phase, last);
     IRN_LAUNCH_CHECK("sweep_blocked_kernel");
     return IRN_OK;
+}
+
+template <int R, int T>
+int launch_merged_tile(const WalkImg *imgs, const int4 *map, const int *ptab, int nb, int max_nch, int phase, int last,
+                       hipStream_t stream) {
+    constexpr int P = kTiles[T].P, TH = kTiles[T].TH, TW = kTiles[T].TW, MAXW = kTiles[T].MAXW;
+    using G = Geo<R, P, TH, TW>;
+    const size_t lds = sizeof(float) * max_nch * G::LH * G::LW;
+    hipLaunchKernelGGL((sweep_merged_kernel<R, P, TH, TW, MAXW>), dim3(nb), dim3(256), lds, stream, imgs, map, ptab,
+                       phase, last);
+    IRN_LAUNCH_CHECK("sweep_merged_kernel");
+    return IRN_OK;
+}
+
+template <int R>
+int launch_merged(int tile, const WalkImg *imgs, const int4 *map, const int *ptab, int nb, int max_nch, int phase,
+                  int last, hipStream_t stream) {
+    switch (tile) {
+        case 0: return launch_merged_tile<R, 0>(imgs, map, ptab, nb, max_nch, phase, last, stream);
+        case 1: return launch_merged_tile<R, 1>(imgs, map, ptab, nb, max_nch, phase, last, stream);
+        case 2: return launch_merged_tile<R, 2>(imgs, map, ptab, nb, max_nch, phase, last, stream);
+        case 3: return launch_merged_tile<R, 3>(imgs, map, ptab, nb, max_nch, phase, last, stream);
+        case 4: return launch_merged_tile<R, 4>(imgs, map, ptab, nb, max_nch, phase, last, stream);
+        case 5: return launch_merged_tile<R, 5>(imgs, map, ptab, nb, max_nch, phase, last, stream);
+        case 6: return launch_merged_tile<R, 6>(imgs, map, ptab, nb, max_nch, phase, last, stream);
+        default: return launch_merged_tile<R, 7>(imgs, map, ptab, nb, max_nch, phase, last, stream);
+    }
 }
 
 template <int R, int CH>
@@ -417,7 +473,10 @@ struct irn_walk_ctx {
     AffJob *jobs_dev = nullptr;
     int4 *map_dev = nullptr;
     int cap_imgs = 0, cap_map = 0;
-    int cls_off[6] = {0, 0, 0, 0, 0, 0};   // block-map slice of channel-chunk class k: [cls_off[k], cls_off[k+1])
+    int cls_begin[5] = {0, 0, 0, 0, 0};    // block-map slice of channel-chunk width k: [cls_begin[k], +cls_count[k])
+    int cls_count[5] = {0, 0, 0, 0, 0};
+    int map_len = 0, max_nch = 1;
+    int merged = 1;                        // one launch per sweep for all widths (else one launch per width)
     // pinned staging for the per-run descriptors (2 slots, guarded by events)
     void *stage[2] = {nullptr, nullptr};
     size_t stage_cap = 0;
@@ -472,6 +531,8 @@ extern "C" int irn_walk_set_option(irn_walk_ctx *ctx, const char *name, int valu
         ctx->variant = value;
     } else if (!strcmp(name, "xcd_map")) {
         ctx->xcd_map = value ? 1 : 0;
+    } else if (!strcmp(name, "merged")) {
+        ctx->merged = value ? 1 : 0;
     } else if (!strcmp(name, "streams")) {
         ctx->use_streams = value ? 1 : 0;
     } else if (!strcmp(name, "tile")) {
@@ -537,7 +598,7 @@ extern "C" int irn_walk_configure(irn_walk_ctx *ctx, int n_images, const int32_t
         ctx->front_pad[i] = fp;
         ctx->plane_stride[i] = ps;
         ctx->off_wts[i] = off;
-        off += round_up(sizeof(float) * ps * (ctx->tab->n_dirs + 1), 256);
+        off += round_up(sizeof(float) * ps * ctx->tab->n_dirs, 256);
         ctx->off_deg[i] = off;
         off += round_up(sizeof(double) * npx, 256);
         ctx->off_xa[i] = off;
@@ -557,11 +618,13 @@ extern "C" int irn_walk_configure(irn_walk_ctx *ctx, int n_images, const int32_t
     // XCD b % 8 (observed dispatch order; speed only): every image is pinned to one XCD so that the
     // halo / "-d" re-reads of its weight planes hit that XCD's L2.
     std::vector<int4> map;
-    for (int k = 0; k < 6; ++k) ctx->cls_off[k] = 0;
+    for (int k = 0; k < 5; ++k) ctx->cls_begin[k] = ctx->cls_count[k] = 0;
+    ctx->max_nch = 1;
     if (blocked_ok) {
         const int NX = ctx->xcd_map ? 8 : 1;
-        for (int cls = 1; cls <= 4; ++cls) {
-            ctx->cls_off[cls] = (int)map.size();
+        for (int cls = 4; cls >= 1; --cls) {          // widest first: its workgroups run longest
+            while (map.size() % NX) map.push_back(make_int4(-1, 0, 0, 0));   // keep block b on XCD b % 8
+            ctx->cls_begin[cls] = (int)map.size();
             std::vector<std::vector<int4>> q(NX);
             std::vector<size_t> load(NX, 0);
             for (int i = 0; i < n_images; ++i) {
@@ -571,9 +634,10 @@ extern "C" int irn_walk_configure(irn_walk_ctx *ctx, int n_images, const int32_t
                 for (int c0 = 0; c0 < c[i]; c0 += ctx->max_chunk) {
                     const int nch = std::min(ctx->max_chunk, c[i] - c0);
                     if (nch != cls) continue;
+                    ctx->max_nch = std::max(ctx->max_nch, nch);
                     for (int ty = 0; ty < h[i]; ty += kTiles[ctx->tile].TH)
                         for (int tx = 0; tx < w[i]; tx += kTiles[ctx->tile].TW) {
-                            q[best].push_back(make_int4(i, ty, tx, c0));
+                            q[best].push_back(make_int4(i, ty, tx, c0 | (nch << 16)));
                             ++load[best];
                         }
                 }
@@ -581,12 +645,13 @@ extern "C" int irn_walk_configure(irn_walk_ctx *ctx, int n_images, const int32_t
             size_t depth = 0;
             for (auto &v : q) depth = std::max(depth, v.size());
             const size_t begin = map.size();
-            for (size_t s = 0; s < depth; ++s)
-                for (int k = 0; k < NX; ++k) map.push_back(s < q[k].size() ? q[k][s] : make_int4(-1, 0, 0, 0));
+            for (size_t sl = 0; sl < depth; ++sl)
+                for (int k = 0; k < NX; ++k) map.push_back(sl < q[k].size() ? q[k][sl] : make_int4(-1, 0, 0, 0));
             while (map.size() > begin && map.back().x < 0) map.pop_back();
+            ctx->cls_count[cls] = (int)(map.size() - begin);
         }
-        ctx->cls_off[5] = (int)map.size();
     }
+    ctx->map_len = (int)map.size();
 
     if (n_images > ctx->cap_imgs) {
         if (ctx->imgs_dev) (void)hipFree(ctx->imgs_dev);
@@ -622,9 +687,9 @@ extern "C" int irn_walk_configure(irn_walk_ctx *ctx, int n_images, const int32_t
 
 template <int R, int CH>
 static int launch_blocked_cls(irn_walk_ctx *ctx, int phase, int last, hipStream_t stream) {
-    const int nb = ctx->cls_off[CH + 1] - ctx->cls_off[CH];
+    const int nb = ctx->cls_count[CH];
     if (nb <= 0) return IRN_OK;
-    return launch_sweep<R, CH>(ctx->tile, ctx->imgs_dev, ctx->map_dev + ctx->cls_off[CH], ctx->tab->plane_tab, nb,
+    return launch_sweep<R, CH>(ctx->tile, ctx->imgs_dev, ctx->map_dev + ctx->cls_begin[CH], ctx->tab->plane_tab, nb,
                                phase, last, stream);
 }
 
@@ -633,6 +698,9 @@ static int launch_blocked_cls(irn_walk_ctx *ctx, int phase, int last, hipStream_
 // of workgroups then overlaps the big one instead of costing a full kernel latency per sweep.
 template <int R>
 static int launch_blocked(irn_walk_ctx *ctx, int phase, int last, hipStream_t const *st) {
+    if (ctx->merged)
+        return launch_merged<R>(ctx->tile, ctx->imgs_dev, ctx->map_dev, ctx->tab->plane_tab, ctx->map_len, ctx->max_nch,
+                                phase, last, st[0]);
     int rc = launch_blocked_cls<R, 1>(ctx, phase, last, st[0]);
     if (!rc) rc = launch_blocked_cls<R, 2>(ctx, phase, last, st[1]);
     if (!rc) rc = launch_blocked_cls<R, 3>(ctx, phase, last, st[2]);
@@ -694,7 +762,7 @@ extern "C" int irn_walk_run(irn_walk_ctx *ctx, const float *const *edge_dev, con
     IRN_HIP_TRY(hipEventRecord(ctx->stage_ev[slot], stream));
 
     const DeviceTable &tab = *ctx->tab;
-    hipLaunchKernelGGL(zero_pad_kernel, dim3(tab.n_dirs + 1, n), dim3(256), 0, stream, ctx->imgs_dev, tab.n_dirs);
+    hipLaunchKernelGGL(zero_pad_kernel, dim3(tab.n_dirs, n), dim3(256), 0, stream, ctx->imgs_dev, tab.n_dirs);
     IRN_LAUNCH_CHECK("zero_pad_kernel");
     int rc = launch_affinity(ctx->jobs_dev, n, ctx->max_h, ctx->max_w, tab, true, beta, stream);
     if (rc) return rc;
@@ -709,12 +777,12 @@ extern "C" int irn_walk_run(irn_walk_ctx *ctx, const float *const *edge_dev, con
     // stream of every channel-chunk class: the class with most workgroups stays on the caller's stream
     hipStream_t st[4] = {stream, stream, stream, stream};
     int n_side = 0;
-    if (blocked && ctx->use_streams && n_sweeps > 0) {
+    if (blocked && !ctx->merged && ctx->use_streams && n_sweeps > 0) {
         int big = 1;
         for (int k = 2; k <= 4; ++k)
-            if (ctx->cls_off[k + 1] - ctx->cls_off[k] > ctx->cls_off[big + 1] - ctx->cls_off[big]) big = k;
+            if (ctx->cls_count[k] > ctx->cls_count[big]) big = k;
         for (int k = 1; k <= 4; ++k) {
-            if (k == big || ctx->cls_off[k + 1] == ctx->cls_off[k]) continue;
+            if (k == big || ctx->cls_count[k] == 0) continue;
             if (!ctx->side[n_side]) {
                 IRN_HIP_TRY(hipStreamCreateWithFlags(&ctx->side[n_side], hipStreamNonBlocking));
                 IRN_HIP_TRY(hipEventCreateWithFlags(&ctx->ev_join[n_side], hipEventDisableTiming));

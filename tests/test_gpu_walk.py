@@ -119,7 +119,7 @@ def test_ragged_batch_equals_single_images(golden):
     for i in (0, 4):
         st = O.propagate_to_edge_stencil(cams[i].cpu().numpy(), edges[i].cpu().numpy(), 5, 10, 5)
         assert np.abs(batch[i] - st).max() <= TOL_F64
-    for opt in ("xcd_map", "streams"):
+    for opt in ("xcd_map", "merged", "streams"):
         walker.set_option(opt, 0)
         again = walker(edges, cams, beta=10, exp_times=5)
         assert all(np.array_equal(a.cpu().numpy(), b) for a, b in zip(again, batch)), opt
