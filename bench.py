@@ -40,12 +40,12 @@ def parse():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="walk", choices=["walk", "walk_r5", "ins", "coco"])
     ap.add_argument("--batch", type=int, default=0, help="images per GPU per step (0 = workload default)")
-    ap.add_argument("--unique", type=int, default=64, help="distinct synthetic images per GPU")
+    ap.add_argument("--unique", type=int, default=96, help="distinct synthetic images per GPU")
     ap.add_argument("--variant", type=int, default=1)
     ap.add_argument("--xcd-map", type=int, default=1)
-    ap.add_argument("--tile", type=int, default=0, help="sweep tile shape id (irn_walk_set_option 'tile')")
+    ap.add_argument("--tile", type=int, default=7, help="sweep tile shape id (irn_walk_set_option 'tile')")
     ap.add_argument("--streams", type=int, default=1, help="channel-chunk classes on separate streams (merged=0)")
-    ap.add_argument("--merged", type=int, default=1, help="all channel-chunk widths in one launch per sweep")
+    ap.add_argument("--merged", type=int, default=0, help="all channel-chunk widths in one launch per sweep")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-images", type=int, default=8)
     ap.add_argument("--json-out", default=None)
@@ -54,8 +54,8 @@ def parse():
 
 WORKLOADS = {
     #            h    w    radius beta exp  out      default batch
-    "walk":    (128, 128, 10, 10.0, 8, (512, 512), 64),     # BASELINE configs[2]
-    "walk_r5": (128, 128, 5, 10.0, 8, (512, 512), 128),     # configs[0]'s operator setting at full batch
+    "walk":    (128, 128, 10, 10.0, 8, (512, 512), 192),     # BASELINE configs[2]
+    "walk_r5": (128, 128, 5, 10.0, 8, (512, 512), 256),     # configs[0]'s operator setting at full batch
     "ins":     (128, 128, 10, 10.0, 8, (512, 512), 32),     # configs[3]: C*K instance channels
     "coco":    (256, 256, 10, 10.0, 8, (1024, 1024), 2),    # configs[4]: 80 classes, 1024^2
 }

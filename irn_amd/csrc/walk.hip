@@ -454,7 +454,7 @@ struct irn_walk_ctx {
     const DeviceTable *tab = nullptr;   // raster order
     int variant = 1;                    // 0 generic, 1 blocked (radius 5/10 only)
     int xcd_map = 1;                    // keep all tiles of an image on one XCD
-    int tile = 0;                       // index into kTiles
+    int tile = 7;                       // index into kTiles (8x128 tile, 4 px/thread: best measured)
     int use_streams = 1;                // run the channel-chunk classes of a sweep on separate streams
     hipStream_t side[3] = {nullptr, nullptr, nullptr};
     hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
@@ -476,7 +476,7 @@ struct irn_walk_ctx {
     int cls_begin[5] = {0, 0, 0, 0, 0};    // block-map slice of channel-chunk width k: [cls_begin[k], +cls_count[k])
     int cls_count[5] = {0, 0, 0, 0, 0};
     int map_len = 0, max_nch = 1;
-    int merged = 1;                        // one launch per sweep for all widths (else one launch per width)
+    int merged = 0;                        // 1: one launch per sweep for all widths; 0: one launch per width, on streams
     // pinned staging for the per-run descriptors (2 slots, guarded by events)
     void *stage[2] = {nullptr, nullptr};
     size_t stage_cap = 0;
