@@ -43,9 +43,10 @@ def parse():
     ap.add_argument("--unique", type=int, default=96, help="distinct synthetic images per GPU")
     ap.add_argument("--variant", type=int, default=1)
     ap.add_argument("--xcd-map", type=int, default=1)
-    ap.add_argument("--tile", type=int, default=7, help="sweep tile shape id (irn_walk_set_option 'tile')")
+    ap.add_argument("--tile", type=int, default=8, help="sweep tile shape id (irn_walk_set_option 'tile')")
     ap.add_argument("--streams", type=int, default=1, help="channel-chunk classes on separate streams (merged=0)")
     ap.add_argument("--merged", type=int, default=0, help="all channel-chunk widths in one launch per sweep")
+    ap.add_argument("--probe", type=int, default=0, help="diagnostic: time the weight-streaming skeleton instead")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-images", type=int, default=8)
     ap.add_argument("--json-out", default=None)
@@ -148,6 +149,7 @@ def main():
     walker.set_option("tile", a.tile)
     walker.set_option("streams", a.streams)
     walker.set_option("merged", a.merged)
+    walker.set_option("probe", a.probe)
     walker.enable_timing(True)
     outs = [torch.empty((s[2], 1, h, w), device=device) for s in shapes]
 
@@ -210,7 +212,7 @@ def main():
                                    "label histogram; inputs resident in HBM" %
                                    (a.workload, out_hw[0], out_hw[1], h, w, radius, beta, exp_times),
                        "images_per_gpu_per_step": batch, "sharding": "images strided over ranks, no collective",
-                       "variant": a.variant, "tile": a.tile, "streams": a.streams, "merged": a.merged, "mean_channels": float(np.mean([s[2] for s in shapes]))},
+                       "variant": a.variant, "tile": a.tile, "streams": a.streams, "merged": a.merged, "probe": a.probe, "mean_channels": float(np.mean([s[2] for s in shapes]))},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "kernel": "sweep_blocked_kernel<%d,CH> (one sweep over the batch = 1 launch per channel-chunk width)" % radius,

@@ -246,14 +246,31 @@ __device__ __forceinline__ void sweep_body(const WalkImg &I, const BlockEnt &B, 
     const gf_t dst = (gf_t)dst_ + (size_t)B.c0 * n;
 
     // ---- stage state tile + halo for CH channels (zero outside the image) ----
-    for (int i = tid; i < CH * LH * LW; i += 256) {
-        const int c = i / (LH * LW);
-        const int r = i - c * (LH * LW);
-        const int ly = r / LW, lx = r - ly * LW;
-        const int gy = B.ty0 - H + ly, gx = B.tx0 - H + lx;
-        float v = 0.f;
-        if (gy >= 0 && gy < h && gx >= 0 && gx < w) v = src[(unsigned)c * n + (unsigned)(gy * w + gx)];
-        xs[i] = v;
+    // Loads are gathered eight at a time into registers before the LDS writes so that they are in
+    // flight together (one load -> one ds_write per iteration serialises on the L2 latency).
+    {
+        constexpr int TOT = CH * LH * LW;
+        constexpr int NIT = (TOT + 255) / 256;
+        constexpr int GRP = 8;
+#pragma unroll 1
+        for (int it0 = 0; it0 < NIT; it0 += GRP) {
+            float v[GRP];
+#pragma unroll
+            for (int k = 0; k < GRP; ++k) {
+                const int i = tid + (it0 + k) * 256;
+                const int c = i / (LH * LW);
+                const int r = i - c * (LH * LW);
+                const int ly = r / LW, lx = r - ly * LW;
+                const int gy = B.ty0 - H + ly, gx = B.tx0 - H + lx;
+                const bool ok = i < TOT && gy >= 0 && gy < h && gx >= 0 && gx < w;
+                v[k] = ok ? src[(unsigned)c * n + (unsigned)(gy * w + gx)] : 0.f;
+            }
+#pragma unroll
+            for (int k = 0; k < GRP; ++k) {
+                const int i = tid + (it0 + k) * 256;
+                if (i < TOT) xs[i] = v[k];
+            }
+        }
     }
     __syncthreads();
 
@@ -356,6 +373,57 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, MAXW))) 
     sweep_body<R, CH, P, TH, TW>(I, B, src, dst, plane_tab, xs);
 }
 
+// Diagnostic kernel (irn_walk_set_option("probe", mode)): the weight-streaming skeleton of the sweep
+// without state staging, LDS windows or the fp64 epilogue — measures what the access pattern itself
+// sustains.  mode 1: forward + backward loads (as the sweep issues them); mode 2: forward loads only
+// (aligned, each byte once); mode 3: as 1 but every load waits for the previous pair (no overlap);
+// mode 4: as 1 with the backward column shift rounded to a multiple of 4 (16-byte aligned loads).
+template <int R, int P, int TH, int TW, int MAXW, int MODE>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, MAXW))) void probe_kernel(
+    const WalkImg *__restrict__ imgs, const int4 *__restrict__ block_map, const int *__restrict__ plane_tab, int phase,
+    int last) {
+    constexpr int H = R - 1;
+    const int4 e = block_map[blockIdx.x];
+    if (e.x < 0) return;
+    const WalkImg I = imgs[e.x];
+    const int tid = threadIdx.x;
+    const int trow = tid / (TW / P), tcol = (tid % (TW / P)) * P;
+    const int y = e.y + trow, x = e.z + tcol;
+    const bool live = y < I.h && x < I.w;
+    const unsigned p0 = live ? (unsigned)(y * I.w + x) : 0u;
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(
+        (void *)(I.wts - I.front_pad), 0, (int)(I.n_dirs * I.plane_stride * 4), 0x00020000);
+    const int voff = (int)(p0 * 4u), ps4 = (int)(I.plane_stride * 4), fp4 = I.front_pad * 4, w4 = I.w * 4;
+    float acc[P];
+#pragma unroll
+    for (int j = 0; j < P; ++j) acc[j] = 0.f;
+#pragma unroll 1
+    for (int dy = 0; dy <= H; ++dy) {
+        const int rowoff4 = dy * w4;
+        const int *prow = plane_tab + dy * (2 * H + 1);
+        static_for<2 * H + 1>([&](auto ix) __attribute__((always_inline)) {
+            constexpr int dx = decltype(ix)::value - H;
+            const int ent = prow[dx + H];
+            const int soff = fp4 + (ent < 0 ? ~ent : ent) * ps4;
+            float wf[P], wb[P];
+            load_w<P>(wf, wrsrc, voff, soff);
+            if constexpr (MODE == 4) load_w<P>(wb, wrsrc, voff, soff - rowoff4 - (dx & ~3) * 4);
+            else if constexpr (MODE != 2) load_w<P>(wb, wrsrc, voff, soff - rowoff4 - dx * 4);
+#pragma unroll
+            for (int j = 0; j < P; ++j) {
+                acc[j] += wf[j];
+                if constexpr (MODE != 2) acc[j] += wb[j];
+            }
+            if constexpr (MODE == 3) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        });
+    }
+    float *dst = last ? I.out : ((phase & 1) ? I.xa : I.xb);
+    if (live)
+#pragma unroll
+        for (int j = 0; j < P; ++j)
+            if (x + j < I.w) dst[(unsigned)(e.w & 0xffff) * (unsigned)(I.h * I.w) + p0 + j] = acc[j];
+}
+
 // All channel-chunk widths of a sweep in ONE launch: the workgroup's width comes from its block-map
 // entry.  The register budget is that of the widest body, which the occupancy cap (MAXW) already
 // grants every width, and the dispatcher balances small and large widths inside one grid instead
@@ -384,7 +452,8 @@ struct TileShape {
     int P, TH, TW, MAXW;
 };
 constexpr TileShape kTiles[] = {{4, 16, 64, 4}, {4, 16, 64, 8}, {2, 16, 32, 4}, {1, 8, 32, 4},
-                                {1, 8, 32, 8},  {4, 32, 32, 4}, {2, 16, 32, 8}, {4, 8, 128, 4}};
+                                {1, 8, 32, 8},  {4, 32, 32, 4}, {2, 16, 32, 8}, {4, 8, 128, 4},
+                                {4, 8, 128, 2}, {4, 8, 128, 3}, {4, 4, 256, 4}, {2, 8, 64, 2}};
 constexpr int kNumTiles = sizeof(kTiles) / sizeof(kTiles[0]);
 
 template <int R, int CH, int T>
@@ -422,8 +491,19 @@ int launch_merged(int tile, const WalkImg *imgs, const int4 *map, const int *pta
         case 4: return launch_merged_tile<R, 4>(imgs, map, ptab, nb, max_nch, phase, last, stream);
         case 5: return launch_merged_tile<R, 5>(imgs, map, ptab, nb, max_nch, phase, last, stream);
         case 6: return launch_merged_tile<R, 6>(imgs, map, ptab, nb, max_nch, phase, last, stream);
-        default: return launch_merged_tile<R, 7>(imgs, map, ptab, nb, max_nch, phase, last, stream);
+        case 7: return launch_merged_tile<R, 7>(imgs, map, ptab, nb, max_nch, phase, last, stream);
+        default: return fail(IRN_ERR_ARG, "merged launch exists for tiles 0-7");
     }
+}
+
+template <int R, int MODE>
+int launch_probe(const WalkImg *imgs, const int4 *map, const int *ptab, int nb, int phase, int last, hipStream_t stream) {
+    constexpr int T = 7;
+    constexpr int P = kTiles[T].P, TH = kTiles[T].TH, TW = kTiles[T].TW, MAXW = kTiles[T].MAXW;
+    hipLaunchKernelGGL((probe_kernel<R, P, TH, TW, MAXW, MODE>), dim3(nb), dim3(256), 0, stream, imgs, map, ptab, phase,
+                       last);
+    IRN_LAUNCH_CHECK("probe_kernel");
+    return IRN_OK;
 }
 
 template <int R, int CH>
@@ -437,7 +517,11 @@ int launch_sweep(int tile, const WalkImg *imgs, const int4 *map, const int *ptab
         case 4: return launch_sweep_tile<R, CH, 4>(imgs, map, ptab, nb, phase, last, stream);
         case 5: return launch_sweep_tile<R, CH, 5>(imgs, map, ptab, nb, phase, last, stream);
         case 6: return launch_sweep_tile<R, CH, 6>(imgs, map, ptab, nb, phase, last, stream);
-        default: return launch_sweep_tile<R, CH, 7>(imgs, map, ptab, nb, phase, last, stream);
+        case 7: return launch_sweep_tile<R, CH, 7>(imgs, map, ptab, nb, phase, last, stream);
+        case 8: return launch_sweep_tile<R, CH, 8>(imgs, map, ptab, nb, phase, last, stream);
+        case 9: return launch_sweep_tile<R, CH, 9>(imgs, map, ptab, nb, phase, last, stream);
+        case 10: return launch_sweep_tile<R, CH, 10>(imgs, map, ptab, nb, phase, last, stream);
+        default: return launch_sweep_tile<R, CH, 11>(imgs, map, ptab, nb, phase, last, stream);
     }
 }
 
@@ -454,7 +538,7 @@ struct irn_walk_ctx {
     const DeviceTable *tab = nullptr;   // raster order
     int variant = 1;                    // 0 generic, 1 blocked (radius 5/10 only)
     int xcd_map = 1;                    // keep all tiles of an image on one XCD
-    int tile = 7;                       // index into kTiles (8x128 tile, 4 px/thread: best measured)
+    int tile = 8;                       // index into kTiles (8x128 tile, 4 px/thread, MAXW 2: best measured)
     int use_streams = 1;                // run the channel-chunk classes of a sweep on separate streams
     hipStream_t side[3] = {nullptr, nullptr, nullptr};
     hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
@@ -476,6 +560,7 @@ struct irn_walk_ctx {
     int cls_begin[5] = {0, 0, 0, 0, 0};    // block-map slice of channel-chunk width k: [cls_begin[k], +cls_count[k])
     int cls_count[5] = {0, 0, 0, 0, 0};
     int map_len = 0, max_nch = 1;
+    int probe = 0;                         // diagnostic: replace the sweeps by the streaming skeleton (tile 7 only)
     int merged = 0;                        // 1: one launch per sweep for all widths; 0: one launch per width, on streams
     // pinned staging for the per-run descriptors (2 slots, guarded by events)
     void *stage[2] = {nullptr, nullptr};
@@ -531,6 +616,9 @@ extern "C" int irn_walk_set_option(irn_walk_ctx *ctx, const char *name, int valu
         ctx->variant = value;
     } else if (!strcmp(name, "xcd_map")) {
         ctx->xcd_map = value ? 1 : 0;
+    } else if (!strcmp(name, "probe")) {
+        if (value < 0 || value > 4) return fail(IRN_ERR_ARG, "probe must be in [0,4]");
+        ctx->probe = value;
     } else if (!strcmp(name, "merged")) {
         ctx->merged = value ? 1 : 0;
     } else if (!strcmp(name, "streams")) {
@@ -698,6 +786,19 @@ static int launch_blocked_cls(irn_walk_ctx *ctx, int phase, int last, hipStream_
 // of workgroups then overlaps the big one instead of costing a full kernel latency per sweep.
 template <int R>
 static int launch_blocked(irn_walk_ctx *ctx, int phase, int last, hipStream_t const *st) {
+    if (ctx->probe) {   // timing skeleton over the whole block map (results are meaningless)
+        if (kTiles[ctx->tile].TH != 8 || kTiles[ctx->tile].TW != 128)
+            return fail(IRN_ERR_ARG, "probe needs an 8x128 tile (7, 8 or 9)");
+        const WalkImg *im = ctx->imgs_dev;
+        const int4 *mp = ctx->map_dev;
+        const int *pt = ctx->tab->plane_tab;
+        switch (ctx->probe) {
+            case 1: return launch_probe<R, 1>(im, mp, pt, ctx->map_len, phase, last, st[0]);
+            case 2: return launch_probe<R, 2>(im, mp, pt, ctx->map_len, phase, last, st[0]);
+            case 3: return launch_probe<R, 3>(im, mp, pt, ctx->map_len, phase, last, st[0]);
+            default: return launch_probe<R, 4>(im, mp, pt, ctx->map_len, phase, last, st[0]);
+        }
+    }
     if (ctx->merged)
         return launch_merged<R>(ctx->tile, ctx->imgs_dev, ctx->map_dev, ctx->tab->plane_tab, ctx->map_len, ctx->max_nch,
                                 phase, last, st[0]);
@@ -777,7 +878,7 @@ extern "C" int irn_walk_run(irn_walk_ctx *ctx, const float *const *edge_dev, con
     // stream of every channel-chunk class: the class with most workgroups stays on the caller's stream
     hipStream_t st[4] = {stream, stream, stream, stream};
     int n_side = 0;
-    if (blocked && !ctx->merged && ctx->use_streams && n_sweeps > 0) {
+    if (blocked && !ctx->merged && !ctx->probe && ctx->use_streams && n_sweeps > 0) {
         int big = 1;
         for (int k = 2; k <= 4; ++k)
             if (ctx->cls_count[k] > ctx->cls_count[big]) big = k;

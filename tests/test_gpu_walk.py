@@ -48,7 +48,7 @@ def test_edge_to_affinity_exact(golden, r):
         assert np.array_equal(ab[b], O.edge_to_affinity(eb[b].reshape(-1), pio.path_indices))
 
 
-@pytest.mark.parametrize("variant,tile", [(0, 0), (1, 0), (1, 1), (1, 2), (1, 3), (1, 4), (1, 5), (1, 6), (1, 7)])
+@pytest.mark.parametrize("variant,tile", [(0, 0), (1, 0), (1, 1), (1, 2), (1, 3), (1, 4), (1, 5), (1, 6), (1, 7), (1, 8), (1, 9), (1, 10), (1, 11)])
 def test_propagate_to_edge_vs_reference_golden(golden, variant, tile):
     from irn_amd.misc import indexing
     wk, names = _cases(golden)
@@ -161,7 +161,8 @@ def test_instance_split_channels(golden):
                                           (10, 256, 256, 5, 0), (10, 94, 125, 7, 1), (10, 128, 128, 4, 2),
                                           (5, 94, 125, 6, 2), (10, 125, 94, 3, 3), (5, 128, 128, 1, 3),
                                           (10, 94, 125, 5, 4), (5, 125, 94, 2, 5), (10, 128, 128, 2, 6),
-                                          (10, 130, 250, 3, 7)])
+                                          (10, 130, 250, 3, 7), (10, 128, 128, 3, 8), (5, 94, 125, 4, 8),
+                                          (10, 94, 125, 2, 9), (10, 40, 300, 1, 10), (10, 125, 94, 4, 11)])
 def test_full_size_blocked_equals_generic_and_conserves_mass(r, h, w, c, tile):
     from irn_amd import synth
     from irn_amd.misc import indexing
