@@ -38,7 +38,7 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="walk", choices=["walk", "walk_r5", "ins", "coco"])
+    ap.add_argument("--workload", default="walk", choices=["walk", "walk_r5", "ins", "coco", "cam", "e2e"])
     ap.add_argument("--batch", type=int, default=0, help="images per GPU per step (0 = workload default)")
     ap.add_argument("--unique", type=int, default=96, help="distinct synthetic images per GPU")
     ap.add_argument("--variant", type=int, default=1)
@@ -115,6 +115,96 @@ def cpu_baseline(workload, n_images, seed0):
                       "OpenMP, %.1f s)" % (n_images, dt)}
 
 
+def backbone_bench(a, rank, world, device, dist, parallel):
+    """Secondary legs (no hand-written kernel dominates them, so no roofline object):
+    `cam`  BASELINE configs[1]: multi-scale CAM inference — ResNet-50 CAM on {1.0,0.5,1.5,2.0}x512^2 with
+           h-flip, merge to the stride-4 / full-resolution maps (step/make_cam.py:26-56), PyTorch-ROCm fp32.
+    `e2e`  cam + EdgeDisplacement forward + random walk (radius 10, beta 10, 2^8) + label epilogue."""
+    import torch.nn.functional as F
+    from irn_amd import ops, synth
+    from irn_amd.misc import indexing
+    from irn_amd.net import resnet50_cam, resnet50_irn, weights
+    from irn_amd.step import make_cam
+
+    os.environ.setdefault("MIOPEN_FIND_MODE", "2")
+    batch = a.batch or 8
+    H = W = 512
+    scales = (1.0, 0.5, 1.5, 2.0)
+    g = torch.Generator().manual_seed(1234 + rank)
+    cam_net = resnet50_cam.CAM()
+    cam_net.load_state_dict(weights.random_cam_state(1))
+    cam_net = cam_net.to(device).eval()
+    imgs = {s: torch.randn(batch, 3, int(round(H * s)), int(round(W * s)), generator=g).to(device) for s in scales}
+    labels = []
+    for i in range(batch):
+        lab = torch.zeros(20)
+        lab[torch.from_numpy(synth.voc_keys(synth.voc_num_classes(i + 7), i + 7))] = 1
+        labels.append(lab.to(device))
+    irn = walker = None
+    if a.workload == "e2e":
+        irn = resnet50_irn.EdgeDisplacement()
+        irn.load_state_dict(weights.random_irn_state(2), strict=False)
+        irn = irn.to(device).eval()
+        walker = indexing.RandomWalk(10, device)
+
+    def cam_stage():
+        outs = []
+        for s in scales:
+            x = imgs[s]
+            f = F.relu(F.conv2d(cam_net.features(torch.cat([x, x.flip(-1)], 0)), cam_net.classifier.weight))
+            outs.append(f[:batch] + f[batch:].flip(-1))                     # [B,20,hs,ws]
+        res = []
+        for i in range(batch):
+            res.append(make_cam.merge_scales([o[i] for o in outs], (H, W), labels[i]))
+        return res
+
+    def step():
+        with torch.no_grad():
+            cams = cam_stage()
+            if a.workload == "cam":
+                return cams
+            x = imgs[1.0]
+            edges = []
+            for i in range(batch):
+                e, _dp = irn(torch.stack([x[i], x[i].flip(-1)]))
+                edges.append(e)
+            rws = walker(edges, [c[1] for c in cams], beta=10.0, exp_times=8)
+            return ops.label_epilogue(rws, [(H, W)] * batch, 0.25, keys=[c[0] for c in cams])["labels"]
+
+    for _ in range(a.warmup):
+        step()
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = parallel.max_over_ranks(time.perf_counter() - t0, dist, device)
+    if rank == 0:
+        res = {"metric": "images/sec for CAM+random-walk label gen, VOC12 512^2 (%s)" %
+                         ("multi-scale CAM inference stage" if a.workload == "cam" else "CAM + IRNet + walk + labels, end to end"),
+               "value": a.steps * batch * world / elapsed, "unit": "images/s", "n_gpus": world, "steps": a.steps,
+               "warmup": a.warmup, "ms_per_step": 1e3 * elapsed / a.steps, "higher_is_better": True, "scaling": "weak",
+               "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "config": {"workload": "%s: synthetic 512x512 images, ResNet-50 CAM at scales %s + flip (random-init weights, "
+                                      "fp32, MIOpen)%s" % (a.workload, scales, "" if a.workload == "cam" else
+                                                           "; EdgeDisplacement forward; walk radius 10 beta 10 2^8; label epilogue"),
+                          "images_per_gpu_per_step": batch},
+               "roofline": None, "cpu_baseline": None}
+        line = json.dumps(res)
+        print(line, flush=True)
+        if a.json_out:
+            with open(a.json_out, "w") as f:
+                f.write(line + "\n")
+    if dist:
+        dist.destroy_process_group()
+
+
 def main():
     a = parse()
     rank = int(os.environ.get("RANK", "0"))
@@ -126,6 +216,9 @@ def main():
     device = torch.device("cuda", local_rank)
     from irn_amd import parallel
     dist = parallel.init_process_group(backend="nccl", device=device)      # nccl == RCCL on ROCm; None at N=1
+
+    if a.workload in ("cam", "e2e"):
+        return backbone_bench(a, rank, world, device, dist, parallel)
 
     from irn_amd import ops
     from irn_amd.misc import indexing
