@@ -81,3 +81,16 @@ def test_dataset_msf(tmp_path):
     assert [tuple(x.shape) for x in item["img"]] == [(2, 3, 37, 50), (2, 3, 18, 25), (2, 3, 74, 100)]
     assert np.array_equal(item["img"][0][1], item["img"][0][0][..., ::-1])
     assert dataloader.decode_int_filename(2007000032) == "2007_000032"
+
+
+def test_cam_merge_matches_reference_golden(golden):
+    """step/make_cam.py:32-52 through our merge (torch ops, CPU here) against the reference's outputs."""
+    from irn_amd.step import make_cam
+    cm = golden("cam_merge")
+    for name in "ab":
+        outs = [torch.from_numpy(cm["%s_out%d" % (name, i)]) for i in range(4)]
+        keys, cam, hi = make_cam.merge_scales(outs, tuple(int(v) for v in cm[name + "_size"]),
+                                              torch.from_numpy(cm[name + "_label"]))
+        assert np.array_equal(keys.numpy(), cm[name + "_keys"])
+        assert np.abs(cam.numpy() - cm[name + "_cam"]).max() <= 1e-6
+        assert np.abs(hi.numpy() - cm[name + "_high_res"]).max() <= 1e-6
