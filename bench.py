@@ -272,6 +272,7 @@ def main():
 
     # HIP events recorded inside the timed region on the launch stream, read out after it
     sweep_ms, sweep_launches = walker.last_sweep_ms()
+    walker.check()                               # resident walk: no tile gave up waiting
     checksum = int(sum(int(l.sum().item()) for l in labels[:4]))
     if rank == 0:
         n_dirs = N_DIRS[radius]
@@ -308,7 +309,9 @@ def main():
                        "variant": a.variant, "tile": a.tile, "streams": a.streams, "merged": a.merged, "probe": a.probe, "mean_channels": float(np.mean([s[2] for s in shapes]))},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel": "sweep_blocked_kernel<%d,CH> (one sweep over the batch = 1 launch per channel-chunk width)" % radius,
+                         "kernel": ("resident_kernel<%d> (weights-stationary persistent walk; launch time / sweeps)" % radius)
+                                   if a.variant == 2 else
+                                   ("sweep_blocked_kernel<%d,CH> (one sweep over the batch = 1 launch per channel-chunk width)" % radius),
                          "algorithmic_bytes_per_launch": per_sweep_bytes, "avg_launch_ms": avg_sweep_ms,
                          "launches_timed": sweep_launches,
                          "sweep_share_of_step": sweep_ms / (1e3 * elapsed)},

@@ -99,6 +99,12 @@ int irn_walk_run(irn_walk_ctx *ctx, const float *const *edge_dev, const float *c
  * table-driven sweep, 1 = register-blocked sweep for radius 5/10 (default).  Unknown names fail. */
 int irn_walk_set_option(irn_walk_ctx *ctx, const char *name, int value);
 
+/* The weights-stationary persistent kernel ("variant" = 2) polls neighbouring tiles with a bounded
+ * wait; if a launch ever gave up, the first irn_walk_check after the stream has been synchronised
+ * returns IRN_ERR_STATE (and the outputs of that run are invalid).  Always IRN_OK for the streaming
+ * variants. */
+int irn_walk_check(irn_walk_ctx *ctx);
+
 /* Kernel timing hook for bench.py: when enabled, every irn_walk_run brackets its sweep kernels
  * with a pair of HIP events on `stream` (no synchronisation).  irn_walk_last_sweep_ms waits for the
  * pairs recorded since its previous call, returns their summed elapsed time and the number of

@@ -30,24 +30,11 @@
 // an image on one XCD so those hit its L2 instead of HBM.
 #include <algorithm>
 #include <mutex>
-#include <utility>
 
-#include "kernels.hpp"
+#include "walk_ctx.hpp"
 
 namespace irn {
 
-struct WalkImg {
-    const float *edge;   // [h,w]
-    const float *cam;    // [C/k_inst, h, w]
-    const int *inst;     // [h,w] cluster map or null
-    float *out;          // [C,h,w]
-    float *wts;          // plane 0 / pixel 0 (front pad lies before it)
-    double *inv_deg;     // [h*w]
-    float *xa, *xb;      // [C, h*w]
-    int h, w, C, k_inst;
-    long plane_stride;
-    int front_pad, n_dirs;
-};
 
 namespace {
 
@@ -151,9 +138,6 @@ __global__ __launch_bounds__(256) void sweep_generic_kernel(const WalkImg *__res
 typedef float f4a __attribute__((ext_vector_type(4)));
 typedef float f2a __attribute__((ext_vector_type(2)));
 
-// Pointers read out of a descriptor in memory are generic ("flat") to the compiler; the kernel
-// wants global_load / buffer_load, so say what they are.
-#define IRN_GLOBAL __attribute__((address_space(1)))
 typedef const float IRN_GLOBAL *gcf_t;
 typedef float IRN_GLOBAL *gf_t;
 typedef const double IRN_GLOBAL *gcd_t;
@@ -167,37 +151,9 @@ struct Geo {
     static constexpr int LW = ((TW - P + WIN + 3) / 4) * 4;      // LDS row length
 };
 
-template <int R>
-__host__ __device__ constexpr bool in_set(int dy, int dx) {     // (dy,dx) in S, dy >= 0
-    return dy == 0 ? (dx >= 1 && dx < R) : (dy < R && dx > -R && dx < R && dx * dx + dy * dy < R * R);
-}
-
-template <int R>
-__host__ __device__ constexpr int plane_of(int dy, int dx) {    // raster index of (dy,dx) in S
-    int n = 0;
-    for (int y = 0; y < R; ++y)
-        for (int x = -R + 1; x < R; ++x) {
-            if (y == dy && x == dx) return n;
-            if (in_set<R>(y, x)) ++n;
-        }
-    return -1;
-}
-
 struct BlockEnt {
     int img, ty0, tx0, c0;   // img < 0 : idle block
 };
-
-// compile-time loop: f(integral_constant<int,0>) ... f(integral_constant<int,N-1>).  The neighbour
-// loops MUST be expanded at compile time (plane numbers, window offsets and the disc test all fold
-// to constants); `#pragma unroll` gives up on the nest of radius 10.
-template <int... Is, typename F>
-__device__ __forceinline__ void static_for_impl(std::integer_sequence<int, Is...>, F &&f) {
-    (f(std::integral_constant<int, Is>{}), ...);
-}
-template <int N, typename F>
-__device__ __forceinline__ void static_for(F &&f) {
-    static_for_impl(std::make_integer_sequence<int, N>{}, f);
-}
 
 // P consecutive weights of one plane through the buffer resource: wave-uniform base in the
 // descriptor, plane/row offset in an SGPR, lane offset in one VGPR -> no per-load VALU address math.
@@ -533,46 +489,6 @@ int launch_sweep(int tile, const WalkImg *imgs, const int4 *map, const int *ptab
 // ------------------------------------------------------------------------------------------------
 using namespace irn;
 
-struct irn_walk_ctx {
-    int radius = 0;
-    const DeviceTable *tab = nullptr;   // raster order
-    int variant = 1;                    // 0 generic, 1 blocked (radius 5/10 only)
-    int xcd_map = 1;                    // keep all tiles of an image on one XCD
-    int tile = 8;                       // index into kTiles (8x128 tile, 4 px/thread, MAXW 2: best measured)
-    int use_streams = 1;                // run the channel-chunk classes of a sweep on separate streams
-    hipStream_t side[3] = {nullptr, nullptr, nullptr};
-    hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
-    int max_chunk = 4;
-    // batch
-    int n = 0;
-    std::vector<int> h, w, c;
-    std::vector<size_t> off_wts, off_deg, off_xa, off_xb;   // byte offsets into the workspace
-    std::vector<long> plane_stride;
-    std::vector<int> front_pad;
-    size_t ws_bytes = 0;
-    int max_h = 0, max_w = 0, max_n = 0;
-    bool all_blocked_ok = false;
-    // device-side descriptor storage (library-private)
-    WalkImg *imgs_dev = nullptr;
-    AffJob *jobs_dev = nullptr;
-    int4 *map_dev = nullptr;
-    int cap_imgs = 0, cap_map = 0;
-    int cls_begin[5] = {0, 0, 0, 0, 0};    // block-map slice of channel-chunk width k: [cls_begin[k], +cls_count[k])
-    int cls_count[5] = {0, 0, 0, 0, 0};
-    int map_len = 0, max_nch = 1;
-    int probe = 0;                         // diagnostic: replace the sweeps by the streaming skeleton (tile 7 only)
-    int merged = 0;                        // 1: one launch per sweep for all widths; 0: one launch per width, on streams
-    // pinned staging for the per-run descriptors (2 slots, guarded by events)
-    void *stage[2] = {nullptr, nullptr};
-    size_t stage_cap = 0;
-    hipEvent_t stage_ev[2] = {nullptr, nullptr};
-    int stage_next = 0;
-    // timing: one event pair per timed run since the last irn_walk_last_sweep_ms call
-    int timing = 0;
-    std::vector<hipEvent_t> ev_pool;       // all events ever created (reused)
-    size_t ev_used = 0;                    // events handed out since the last read-out
-    int pending_launches = 0;
-};
 
 extern "C" int irn_walk_create(int radius, irn_walk_ctx **ctx_out) {
     if (!ctx_out || radius < 2 || radius > IRN_MAX_RADIUS)
@@ -599,6 +515,7 @@ extern "C" int irn_walk_destroy(irn_walk_ctx *ctx) {
         if (ctx->ev_join[k]) (void)hipEventDestroy(ctx->ev_join[k]);
     }
     if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
+    resident_destroy(ctx);
     for (int k = 0; k < 2; ++k) {
         if (ctx->stage[k]) (void)hipHostFree(ctx->stage[k]);
         if (ctx->stage_ev[k]) (void)hipEventDestroy(ctx->stage_ev[k]);
@@ -612,8 +529,13 @@ extern "C" int irn_walk_set_option(irn_walk_ctx *ctx, const char *name, int valu
     if (!strcmp(name, "variant")) {
         if (value == 1 && !(ctx->radius == 5 || ctx->radius == 10))
             return fail(IRN_ERR_ARG, "blocked sweep exists for radius 5 and 10 only");
-        if (value < 0 || value > 1) return fail(IRN_ERR_ARG, "variant must be 0 or 1");
+        if (value == 2 && !resident_supported(ctx))
+            return fail(IRN_ERR_ARG, "resident walk exists for radius 5 and 10 only");
+        if (value < 0 || value > 2) return fail(IRN_ERR_ARG, "variant must be 0, 1 or 2");
         ctx->variant = value;
+    } else if (!strcmp(name, "sweeps_per_launch")) {
+        if (value < 0) return fail(IRN_ERR_ARG, "sweeps_per_launch must be >= 0");
+        ctx->res_sweeps_per_launch = value;
     } else if (!strcmp(name, "xcd_map")) {
         ctx->xcd_map = value ? 1 : 0;
     } else if (!strcmp(name, "probe")) {
@@ -676,7 +598,7 @@ extern "C" int irn_walk_configure(irn_walk_ctx *ctx, int n_images, const int32_t
     ctx->front_pad.resize(n_images);
     size_t off = 0;
     ctx->max_h = ctx->max_w = ctx->max_n = 0;
-    bool blocked_ok = ctx->variant == 1;
+    bool blocked_ok = ctx->variant >= 1;
     for (int i = 0; i < n_images; ++i) {
         if (h[i] < 1 || w[i] < 1 || c[i] < 1 || c[i] > 0xffff)
             return fail(IRN_ERR_ARG, "irn_walk_configure: image %d has invalid size %dx%d c=%d", i, h[i], w[i], c[i]);
@@ -690,9 +612,10 @@ extern "C" int irn_walk_configure(irn_walk_ctx *ctx, int n_images, const int32_t
         ctx->off_deg[i] = off;
         off += round_up(sizeof(double) * npx, 256);
         ctx->off_xa[i] = off;
-        off += round_up(sizeof(float) * npx * c[i] + 64, 256);
+        // 8 bytes per pixel and channel: the resident kernel keeps {tag, value} granules here
+        off += round_up(8 * npx * c[i] + 64, 256);
         ctx->off_xb[i] = off;
-        off += round_up(sizeof(float) * npx * c[i] + 64, 256);
+        off += round_up(8 * npx * c[i] + 64, 256);
         ctx->max_h = std::max(ctx->max_h, (int)h[i]);
         ctx->max_w = std::max(ctx->max_w, (int)w[i]);
         ctx->max_n = std::max(ctx->max_n, (int)npx);
@@ -768,6 +691,12 @@ extern "C" int irn_walk_configure(irn_walk_ctx *ctx, int n_images, const int32_t
     }
     if (!map.empty())
         IRN_HIP_TRY(hipMemcpy(ctx->map_dev, map.data(), sizeof(int4) * map.size(), hipMemcpyHostToDevice));
+    if (ctx->variant == 2) {
+        const int rc = resident_configure(ctx);
+        if (rc) return rc;
+    } else {
+        ctx->res_ok = false;
+    }
     ctx->n = n_images;
     *workspace_bytes = ctx->ws_bytes;
     return IRN_OK;
@@ -871,14 +800,17 @@ extern "C" int irn_walk_run(irn_walk_ctx *ctx, const float *const *edge_dev, con
     hipLaunchKernelGGL(degree_kernel, dim3(pix_blocks, n), dim3(256), 0, stream, ctx->imgs_dev, tab.dir_dy,
                        tab.dir_dx, tab.n_dirs);
     IRN_LAUNCH_CHECK("degree_kernel");
-    hipLaunchKernelGGL(x0_kernel, dim3(pix_blocks, n), dim3(256), 0, stream, ctx->imgs_dev, n_sweeps == 0 ? 1 : 0);
-    IRN_LAUNCH_CHECK("x0_kernel");
+    const bool resident = ctx->variant == 2 && ctx->res_ok && n_sweeps > 0;
+    if (!resident) {
+        hipLaunchKernelGGL(x0_kernel, dim3(pix_blocks, n), dim3(256), 0, stream, ctx->imgs_dev, n_sweeps == 0 ? 1 : 0);
+        IRN_LAUNCH_CHECK("x0_kernel");
+    }
 
-    const bool blocked = ctx->variant == 1 && ctx->all_blocked_ok;
+    const bool blocked = ctx->variant >= 1 && ctx->all_blocked_ok;
     // stream of every channel-chunk class: the class with most workgroups stays on the caller's stream
     hipStream_t st[4] = {stream, stream, stream, stream};
     int n_side = 0;
-    if (blocked && !ctx->merged && !ctx->probe && ctx->use_streams && n_sweeps > 0) {
+    if (blocked && !resident && !ctx->merged && !ctx->probe && ctx->use_streams && n_sweeps > 0) {
         int big = 1;
         for (int k = 2; k <= 4; ++k)
             if (ctx->cls_count[k] > ctx->cls_count[big]) big = k;
@@ -907,7 +839,11 @@ extern "C" int irn_walk_run(irn_walk_ctx *ctx, const float *const *edge_dev, con
         IRN_HIP_TRY(hipEventRecord(ctx->ev_fork, stream));
         for (int k = 0; k < n_side; ++k) IRN_HIP_TRY(hipStreamWaitEvent(ctx->side[k], ctx->ev_fork, 0));
     }
-    for (int t = 0; t < n_sweeps; ++t) {
+    if (resident) {
+        rc = resident_run(ctx, n_sweeps, stream);
+        if (rc) return rc;
+    }
+    for (int t = 0; t < (resident ? 0 : n_sweeps); ++t) {
         const int last = (t == n_sweeps - 1) ? 1 : 0;
         if (blocked) {
             rc = ctx->radius == 5 ? launch_blocked<5>(ctx, t, last, st) : launch_blocked<10>(ctx, t, last, st);
@@ -926,6 +862,18 @@ extern "C" int irn_walk_run(irn_walk_ctx *ctx, const float *const *edge_dev, con
         IRN_HIP_TRY(hipEventRecord(ev1, stream));
         ctx->ev_used += 2;
         ctx->pending_launches += n_sweeps;
+    }
+    return IRN_OK;
+}
+
+extern "C" int irn_walk_check(irn_walk_ctx *ctx) {
+    if (!ctx) return fail(IRN_ERR_ARG, "null ctx");
+    if (!ctx->res_err_host) return IRN_OK;
+    if (ctx->res_err_host[0] != 0) {
+        const unsigned img = ctx->res_err_host[1], t = ctx->res_err_host[2], wg = ctx->res_err_host[3];
+        ctx->res_err_host[0] = 0;
+        return fail(IRN_ERR_STATE, "resident walk timed out: workgroup %u waiting for state of sweep %u of image %u "
+                                   "(a neighbouring tile never published it)", wg, t, img);
     }
     return IRN_OK;
 }

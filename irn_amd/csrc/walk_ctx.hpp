@@ -1,0 +1,115 @@
+// Batch descriptors and the host-side context of the random walk, shared by the streaming sweeps
+// (walk.hip) and the weights-stationary persistent kernel (walk_resident.hip).
+#pragma once
+#include <utility>
+#include <vector>
+
+#include "kernels.hpp"
+
+namespace irn {
+
+struct WalkImg {
+    const float *edge;   // [h,w]
+    const float *cam;    // [C/k_inst, h, w]
+    const int *inst;     // [h,w] cluster map or null
+    float *out;          // [C,h,w]
+    float *wts;          // plane 0 / pixel 0 (front pad lies before it)
+    double *inv_deg;     // [h*w]
+    float *xa, *xb;      // [C, h*w] ping-pong state: fp32 (streaming sweeps) or 8-byte {tag,value} granules (resident)
+    int h, w, C, k_inst;
+    long plane_stride;
+    int front_pad, n_dirs;
+};
+
+// Pointers read out of a descriptor in memory are generic ("flat") to the compiler; the kernels
+// want global_load / buffer_load, so say what they are.
+#define IRN_GLOBAL __attribute__((address_space(1)))
+
+template <int R>
+__host__ __device__ constexpr bool in_set(int dy, int dx) {     // (dy,dx) in S, dy >= 0
+    return dy == 0 ? (dx >= 1 && dx < R) : (dy < R && dx > -R && dx < R && dx * dx + dy * dy < R * R);
+}
+
+template <int R>
+__host__ __device__ constexpr int plane_of(int dy, int dx) {    // raster index of (dy,dx) in S
+    int n = 0;
+    for (int y = 0; y < R; ++y)
+        for (int x = -R + 1; x < R; ++x) {
+            if (y == dy && x == dx) return n;
+            if (in_set<R>(y, x)) ++n;
+        }
+    return -1;
+}
+
+// compile-time loop: f(integral_constant<int,0>) ... f(integral_constant<int,N-1>).  The neighbour
+// loops MUST be expanded at compile time (plane numbers, window offsets and the disc test all fold
+// to constants); `#pragma unroll` gives up on the nest of radius 10.
+template <int... Is, typename F>
+__device__ __forceinline__ void static_for_impl(std::integer_sequence<int, Is...>, F &&f) {
+    (f(std::integral_constant<int, Is>{}), ...);
+}
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F &&f) {
+    static_for_impl(std::make_integer_sequence<int, N>{}, f);
+}
+
+}  // namespace irn
+
+struct irn_walk_ctx {
+    using DeviceTable = irn::DeviceTable;
+    using WalkImg = irn::WalkImg;
+    using AffJob = irn::AffJob;
+    int radius = 0;
+    const DeviceTable *tab = nullptr;   // raster order
+    int variant = 1;                    // 0 generic, 1 blocked (radius 5/10 only)
+    int xcd_map = 1;                    // keep all tiles of an image on one XCD
+    int tile = 8;                       // index into kTiles (8x128 tile, 4 px/thread, MAXW 2: best measured)
+    int use_streams = 1;                // run the channel-chunk classes of a sweep on separate streams
+    hipStream_t side[3] = {nullptr, nullptr, nullptr};
+    hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
+    int max_chunk = 4;
+    // batch
+    int n = 0;
+    std::vector<int> h, w, c;
+    std::vector<size_t> off_wts, off_deg, off_xa, off_xb;   // byte offsets into the workspace
+    std::vector<long> plane_stride;
+    std::vector<int> front_pad;
+    size_t ws_bytes = 0;
+    int max_h = 0, max_w = 0, max_n = 0;
+    bool all_blocked_ok = false;
+    // device-side descriptor storage (library-private)
+    WalkImg *imgs_dev = nullptr;
+    AffJob *jobs_dev = nullptr;
+    int4 *map_dev = nullptr;
+    int cap_imgs = 0, cap_map = 0;
+    int cls_begin[5] = {0, 0, 0, 0, 0};    // block-map slice of channel-chunk width k: [cls_begin[k], +cls_count[k])
+    int cls_count[5] = {0, 0, 0, 0, 0};
+    int map_len = 0, max_nch = 1;
+    int probe = 0;                         // diagnostic: replace the sweeps by the streaming skeleton (tile 7 only)
+    int merged = 0;                        // 1: one launch per sweep for all widths; 0: one launch per width, on streams
+    // pinned staging for the per-run descriptors (2 slots, guarded by events)
+    void *stage[2] = {nullptr, nullptr};
+    size_t stage_cap = 0;
+    hipEvent_t stage_ev[2] = {nullptr, nullptr};
+    int stage_next = 0;
+    // timing: one event pair per timed run since the last irn_walk_last_sweep_ms call
+    int timing = 0;
+    std::vector<hipEvent_t> ev_pool;       // all events ever created (reused)
+    size_t ev_used = 0;                    // events handed out since the last read-out
+    int pending_launches = 0;
+    // weights-stationary persistent kernel (variant 2, walk_resident.hip)
+    int4 *res_jobs_dev = nullptr;          // [res_rounds][res_nwg] (image, tile row0, tile col0, -)
+    int res_cap_jobs = 0, res_rounds = 0, res_nwg = 0;
+    unsigned *res_err_dev = nullptr;       // [4] time-out diagnostics written by the kernel
+    unsigned *res_err_host = nullptr;      // pinned mirror
+    bool res_ok = false;                   // the configured batch fits the resident kernel
+    int res_sweeps_per_launch = 0;         // 0 = all sweeps in one launch; k = relaunch every k sweeps (test hook)
+};
+
+namespace irn {
+// walk_resident.hip: weights-stationary persistent walk (variant 2)
+bool resident_supported(const irn_walk_ctx *ctx);
+int resident_configure(irn_walk_ctx *ctx);
+int resident_run(irn_walk_ctx *ctx, int n_sweeps, hipStream_t stream);
+void resident_destroy(irn_walk_ctx *ctx);
+}  // namespace irn

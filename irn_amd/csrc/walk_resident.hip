@@ -1,0 +1,489 @@
+// Weights-stationary persistent random walk (gfx950) — "variant 2" of irn_walk_run.
+//
+// The transition operator of an image is the same in every one of the 2^exp_times sweeps
+// (reference misc/indexing.py:136-137 squares ONE matrix).  The streaming sweeps of walk.hip re-read
+// its |S| weight planes from HBM every sweep (4*|S|*N bytes: the HBM roofline of SURVEY.md §8d).
+// This kernel reads them ONCE per image: every workgroup keeps the 2|S| directed weights of its
+// pixels in VGPRs for the whole walk, so a sweep moves only the state (8*C*N bytes per image, all of
+// it L2/fabric traffic between neighbouring workgroups) and the chip's 128 MB of register file is the
+// cache the weights live in.
+//
+// Decomposition (radius 10: 304 directed neighbours per pixel)
+//   * one workgroup = 512 threads = 8 waves, one per CU (256 VGPRs per lane), resident for the launch;
+//   * a "slab" is 8 rows x 32 columns of pixels = 64 lanes x 4 consecutive pixels; Q waves share a
+//     slab and split the neighbour disc between them in raster order (radius 10: Q = 8 waves x 38
+//     neighbours x 4 px = 152 weight registers per lane; radius 5: Q = 2 x 34, four slabs per
+//     workgroup).  Each wave's part of the disc is a different, fully expanded instruction stream
+//     (wave-uniform switch), so every weight has a fixed register;
+//   * per sweep a wave forms, per neighbour row, an fp32 FMA chain (<= 19 terms) over a register
+//     window of the LDS-staged state and folds it into fp64; the Q partial sums of a pixel meet in
+//     LDS, get the centre term and 1/deg in fp64 (same numerics contract as walk.hip).
+//
+// Exchange between workgroups (tiles of one image; no kernel boundary between sweeps)
+//   state buffers hold one 8-byte granule {tag = sweep + 1, fp32 value} per pixel and channel, written
+//   by ONE agent-scope (sc1, write-through) store and polled with agent-scope loads until the tag
+//   matches: the data is its own flag (MI355X guide, Guideline 16 form R2), so a sweep costs one
+//   store->load hop and no fence.  Ping-pong buffers are WAR-safe: a workgroup overwrites x_t of its
+//   tile (while producing x_{t+2}) only after it has seen x_{t+1} of every tile within the halo, i.e.
+//   after every reader of its x_t has finished reading.  Polls are bounded (wall clock): a
+//   workgroup that cannot make progress reports through `err` and the launch fails loudly.
+//
+// Scheduling: grid = one workgroup per CU.  The host packs images into rounds of <= #CU tiles
+// (tile = 8x32 px at radius 10, 16x64 at radius 5); workgroup b runs job[round][b] for every round.
+// Tiles of an image sit on consecutive slots of one XCD (slot -> block id b = idx*8 + xcd; observed
+// placement, speed only).  No grid-wide barrier exists, so rounds pipeline.
+#include <algorithm>
+
+#include "walk_ctx.hpp"
+
+namespace irn {
+namespace {
+
+typedef unsigned long long u64;
+typedef u64 IRN_GLOBAL *gu64_t;
+typedef const double IRN_GLOBAL *gcd_t;
+typedef float IRN_GLOBAL *gf_t;
+typedef float f4a __attribute__((ext_vector_type(4)));
+
+constexpr int kSlabH = 8, kSlabW = 32;     // 64 lanes x 4 px
+constexpr int kWaves = 8;                  // 512 threads
+constexpr int kChs = 8;                    // channels staged in LDS at a time
+
+template <int R>
+struct RCfg;
+template <>
+struct RCfg<10> {
+    static constexpr int Q = 8, SL_Y = 1, SL_X = 1;
+};
+template <>
+struct RCfg<5> {
+    static constexpr int Q = 2, SL_Y = 2, SL_X = 2;
+};
+
+// The neighbour disc (dy,dx) != (0,0), dx^2 + dy^2 < R^2, in raster order: the union of the
+// reference's half-plane direction set S (misc/indexing.py:18-56) and its mirror image.
+template <int R>
+struct Disc {
+    int n = 0;
+    signed char dy[4 * R * R] = {}, dx[4 * R * R] = {};
+    constexpr Disc() {
+        for (int y = -(R - 1); y <= R - 1; ++y)
+            for (int x = -(R - 1); x <= R - 1; ++x)
+                if ((y != 0 || x != 0) && x * x + y * y < R * R) {
+                    dy[n] = (signed char)y;
+                    dx[n] = (signed char)x;
+                    ++n;
+                }
+    }
+};
+template <int R>
+inline constexpr Disc<R> kDisc{};
+
+template <int R>
+struct Geom {
+    using C = RCfg<R>;
+    static constexpr int H = R - 1;
+    static constexpr int HP = (H + 3) / 4 * 4;          // LDS column of tile column 0 (16-byte aligned windows)
+    static constexpr int TH = kSlabH * C::SL_Y, TW = kSlabW * C::SL_X;
+    static constexpr int LH = TH + 2 * H, LW = TW + 2 * HP;
+    static constexpr int LWU = TW + 2 * H;               // columns actually staged
+    static constexpr int RG = LH * LWU;                  // staged pixels per channel
+    static constexpr int D = kDisc<R>.n;
+    static constexpr int Q = C::Q;
+    static constexpr int NS = D / Q;                     // neighbours per wave
+    static constexpr int SLABS = C::SL_Y * C::SL_X;
+    static_assert(D % Q == 0, "disc must split evenly over the waves of a slab");
+    static_assert(SLABS * Q == kWaves, "8 waves per workgroup");
+    // LDS carve (bytes)
+    static constexpr int XS_BYTES = kChs * LH * LW * 4;
+    static constexpr int PART_BYTES = 2 * kWaves * 4 * 64 * 8;      // [2][wave][j][lane] fp64
+    static constexpr int INVD_BYTES = SLABS * 4 * 64 * 8;           // [slab][j][lane] fp64
+    static constexpr int LDS_BYTES = XS_BYTES + PART_BYTES + INVD_BYTES + 16;
+};
+
+// first / last neighbour of row dy inside wave part QI (raster order => contiguous), or lo > hi
+template <int R, int QI>
+constexpr int row_lo(int dy) {
+    constexpr int NS = Geom<R>::NS;
+    for (int s = QI * NS; s < (QI + 1) * NS; ++s)
+        if (kDisc<R>.dy[s] == dy) return s;
+    return 1 << 20;
+}
+template <int R, int QI>
+constexpr int row_hi(int dy) {
+    constexpr int NS = Geom<R>::NS;
+    for (int s = (QI + 1) * NS - 1; s >= QI * NS; --s)
+        if (kDisc<R>.dy[s] == dy) return s;
+    return -1;
+}
+constexpr int floor4(int v) { return v >= 0 ? v / 4 * 4 : -((-v + 3) / 4 * 4); }
+
+struct Job {
+    int img, ty0, tx0, pad;
+};
+
+// ---- per-job: weights of this lane's 4 pixels for the wave's part of the disc -> registers ----
+template <int R, int QI>
+__device__ __forceinline__ void load_weights(float (&wr)[Geom<R>::NS][4], const WalkImg &I, int gy, int gx) {
+    using G = Geom<R>;
+    const bool row_ok = gy < I.h && gx < I.w;
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        (void *)(I.wts - I.front_pad), 0, (int)(I.n_dirs * I.plane_stride * 4), 0x00020000);
+    // out-of-image lanes read beyond num_records: the buffer load returns 0.  The front pad goes into
+    // the scalar offset so that it stays >= 0 for backward reads of plane 0 (the hardware adds it
+    // as an unsigned 32-bit number).
+    const int p4 = row_ok ? (gy * I.w + gx) * 4 : 0x7ffffff0;
+    const int ps4 = (int)(I.plane_stride * 4);
+    const int fp4 = I.front_pad * 4;
+    static_for<G::NS>([&](auto is) __attribute__((always_inline)) {
+        constexpr int s = QI * G::NS + decltype(is)::value;
+        constexpr int dy = kDisc<R>.dy[s], dx = kDisc<R>.dx[s];
+        constexpr bool fwd = dy > 0 || (dy == 0 && dx > 0);
+        // forward neighbour p+d uses w_d(p); backward neighbour p-d' (d' = -d in S) uses w_d'(p-d')
+        constexpr int plane = fwd ? plane_of<R>(dy, dx) : plane_of<R>(-dy, -dx);
+        const int soff = fp4 + plane * ps4 + (fwd ? 0 : (dy * I.w + dx) * 4);
+        const f4a v = __builtin_bit_cast(f4a, __builtin_amdgcn_raw_buffer_load_b128(rsrc, p4, soff, 0));
+        wr[decltype(is)::value][0] = v.x;
+        wr[decltype(is)::value][1] = gx + 1 < I.w ? v.y : 0.f;
+        wr[decltype(is)::value][2] = gx + 2 < I.w ? v.z : 0.f;
+        wr[decltype(is)::value][3] = gx + 3 < I.w ? v.w : 0.f;
+    });
+}
+
+// ---- per sweep and channel: this wave's partial sums for its 4 pixels ----
+template <int R, int QI>
+__device__ __forceinline__ void partial_sums(const float (&wr)[Geom<R>::NS][4], const float *xrow, double (&acc)[4]) {
+    using G = Geom<R>;
+    constexpr int H = G::H;
+    acc[0] = acc[1] = acc[2] = acc[3] = 0.0;
+    static_for<2 * H + 1>([&](auto iy) __attribute__((always_inline)) {
+        constexpr int dy = decltype(iy)::value - H;
+        constexpr int lo = row_lo<R, QI>(dy), hi = row_hi<R, QI>(dy);
+        if constexpr (lo <= hi) {
+            constexpr int dxlo = kDisc<R>.dx[lo], dxhi = kDisc<R>.dx[hi];
+            constexpr int c_lo = floor4(dxlo), c_hi = dxhi + 3;
+            constexpr int N4 = (c_hi - c_lo) / 4 + 1;
+            float win[4 * N4];
+            const float *row = xrow + dy * G::LW + c_lo;
+#pragma unroll
+            for (int k = 0; k < N4; ++k) {
+                const f4a v = *reinterpret_cast<const f4a *>(row + 4 * k);
+                win[4 * k] = v.x; win[4 * k + 1] = v.y; win[4 * k + 2] = v.z; win[4 * k + 3] = v.w;
+            }
+            float pf[4] = {0.f, 0.f, 0.f, 0.f};
+            static_for<hi - lo + 1>([&](auto is) __attribute__((always_inline)) {
+                constexpr int s = lo + decltype(is)::value;
+                constexpr int dx = kDisc<R>.dx[s];
+                constexpr int k = s - QI * G::NS;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) pf[j] = fmaf(wr[k][j], win[dx + j - c_lo], pf[j]);
+            });
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[j] += (double)pf[j];
+        }
+    });
+}
+
+__device__ __forceinline__ u64 ld_granule(const gu64_t p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st_granule(gu64_t p, unsigned tag, float v) {
+    __hip_atomic_store(p, ((u64)tag << 32) | (u64)__float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// x_0 = cam * (1 - edge) (misc/indexing.py:162; instance split step/make_ins_seg_labels.py:77-80) as
+// granules with tag 1 into xa; xb's tags are cleared so that no stale tag of an earlier run matches.
+__global__ __launch_bounds__(256) void x0_granule_kernel(const WalkImg *__restrict__ imgs) {
+    const WalkImg I = imgs[blockIdx.y];
+    const long n = (long)I.h * I.w;
+    const long p = (long)blockIdx.x * 256 + threadIdx.x;
+    if (p >= n) return;
+    const float one_minus = 1.0f - I.edge[p];
+    const int k = I.inst ? I.k_inst : 1;
+    const int id = I.inst ? I.inst[p] : 0;
+    u64 *xa = (u64 *)I.xa, *xb = (u64 *)I.xb;
+    for (int c = 0; c < I.C; ++c) {
+        const int cls = c / k, kk = c - cls * k;
+        float v = I.cam[(long)cls * n + p];
+        if (I.inst) v = v * (id == kk ? 1.0f : 0.0f);
+        xa[(long)c * n + p] = ((u64)1 << 32) | (u64)__float_as_uint(v * one_minus);
+        xb[(long)c * n + p] = 0;
+    }
+}
+
+template <int R>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void resident_kernel(
+    const WalkImg *__restrict__ imgs, const int4 *__restrict__ jobs, int n_rounds, int t_first, int t_count,
+    int t_total, unsigned *err, long long timeout_ticks) {
+    using G = Geom<R>;
+    constexpr int H = G::H, HP = G::HP, LH = G::LH, LW = G::LW, LWU = G::LWU, RG = G::RG, Q = G::Q;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float *xs = reinterpret_cast<float *>(smem);
+    double *part = reinterpret_cast<double *>(smem + G::XS_BYTES);
+    double *invd = reinterpret_cast<double *>(smem + G::XS_BYTES + G::PART_BYTES);
+    int *abort_flag = reinterpret_cast<int *>(smem + G::XS_BYTES + G::PART_BYTES + G::INVD_BYTES);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int slab = wv / Q, qi = wv % Q;
+    const int ly = (slab / G::C::SL_X) * kSlabH + (lane >> 3);
+    const int lx = (slab % G::C::SL_X) * kSlabW + (lane & 7) * 4;
+    if (tid == 0) *abort_flag = 0;
+
+    float wr[G::NS][4];
+
+#pragma unroll 1
+    for (int round = 0; round < n_rounds; ++round) {
+        const int4 je = jobs[round * gridDim.x + blockIdx.x];
+        if (je.x < 0) continue;
+        const WalkImg I = imgs[je.x];
+        const int ty0 = je.y, tx0 = je.z;
+        const int h = I.h, w = I.w;
+        const unsigned n = (unsigned)(h * w);
+        const int gy = ty0 + ly, gx = tx0 + lx;
+
+        switch (qi) {
+            case 0: load_weights<R, 0>(wr, I, gy, gx); break;
+            case 1: load_weights<R, 1 % Q>(wr, I, gy, gx); break;
+            case 2: load_weights<R, 2 % Q>(wr, I, gy, gx); break;
+            case 3: load_weights<R, 3 % Q>(wr, I, gy, gx); break;
+            case 4: load_weights<R, 4 % Q>(wr, I, gy, gx); break;
+            case 5: load_weights<R, 5 % Q>(wr, I, gy, gx); break;
+            case 6: load_weights<R, 6 % Q>(wr, I, gy, gx); break;
+            default: load_weights<R, 7 % Q>(wr, I, gy, gx); break;
+        }
+        // 1/deg of the tile: [slab][j][lane]
+        __syncthreads();   // previous job's readers of invd / xs are done
+#pragma unroll
+        for (int i = tid; i < G::SLABS * 256; i += 512) {
+            const int s2 = i >> 8, j = (i >> 6) & 3, l2 = i & 63;
+            const int yy = ty0 + (s2 / G::C::SL_X) * kSlabH + (l2 >> 3);
+            const int xx = tx0 + (s2 % G::C::SL_X) * kSlabW + (l2 & 7) * 4 + j;
+            invd[i] = (yy < h && xx < w) ? ((gcd_t)I.inv_deg)[yy * w + xx] : 0.0;
+        }
+
+#pragma unroll 1
+        for (int t = t_first; t < t_first + t_count; ++t) {
+            const gu64_t src = (gu64_t)((t & 1) ? I.xb : I.xa);
+            const gu64_t dst = (gu64_t)((t & 1) ? I.xa : I.xb);
+            const bool last = (t + 1 == t_total);
+            const unsigned want = (unsigned)(t + 1);
+#pragma unroll 1
+            for (int c0 = 0; c0 < I.C; c0 += kChs) {
+                const int nch = min(kChs, I.C - c0);
+                // ---- poll + stage x_t of the tile and its halo (zero outside the image) ----
+                const int n_items = nch * RG;
+#pragma unroll 1
+                for (int base = 0; base < n_items; base += 512 * 8) {
+                    unsigned goff[8];
+                    int lidx[8];
+                    unsigned pend = 0;
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        const int i = base + k * 512 + tid;
+                        const int c = i / RG;
+                        const int r = i - c * RG;
+                        const int ry = r / LWU, rx = r - ry * LWU;
+                        const int yy = ty0 - H + ry, xx = tx0 - H + rx;
+                        lidx[k] = (c * LH + ry) * LW + rx + (HP - H);
+                        goff[k] = (unsigned)(c0 + c) * n + (unsigned)(yy * w + xx);
+                        if (i < n_items) {
+                            if (yy >= 0 && yy < h && xx >= 0 && xx < w) pend |= 1u << k;
+                            else xs[lidx[k]] = 0.f;
+                        }
+                    }
+                    long long t_start = 0;
+                    while (pend) {
+                        u64 v[8];
+#pragma unroll
+                        for (int k = 0; k < 8; ++k)
+                            if (pend & (1u << k)) v[k] = ld_granule(src + goff[k]);
+#pragma unroll
+                        for (int k = 0; k < 8; ++k)
+                            if ((pend & (1u << k)) && (unsigned)(v[k] >> 32) == want) {
+                                xs[lidx[k]] = __uint_as_float((unsigned)v[k]);
+                                pend &= ~(1u << k);
+                            }
+                        if (pend) {
+                            __builtin_amdgcn_s_sleep(2);
+                            const long long now = wall_clock64();
+                            if (t_start == 0) t_start = now;
+                            else if (now - t_start > timeout_ticks ||
+                                     __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+                                if (atomicCAS(err, 0u, 1u) == 0u) {
+                                    err[1] = (unsigned)je.x;
+                                    err[2] = (unsigned)t;
+                                    err[3] = blockIdx.x;
+                                }
+                                *abort_flag = 1;
+                                break;
+                            }
+                        }
+                    }
+                }
+                __syncthreads();
+                if (*abort_flag) return;
+
+                // ---- channels of the chunk: partial sums -> LDS -> fp64 combine -> store ----
+#pragma unroll 1
+                for (int c = 0; c < nch; ++c) {
+                    const float *xrow = xs + (c * LH + ly + H) * LW + lx + HP;
+                    double acc[4];
+                    switch (qi) {
+                        case 0: partial_sums<R, 0>(wr, xrow, acc); break;
+                        case 1: partial_sums<R, 1 % Q>(wr, xrow, acc); break;
+                        case 2: partial_sums<R, 2 % Q>(wr, xrow, acc); break;
+                        case 3: partial_sums<R, 3 % Q>(wr, xrow, acc); break;
+                        case 4: partial_sums<R, 4 % Q>(wr, xrow, acc); break;
+                        case 5: partial_sums<R, 5 % Q>(wr, xrow, acc); break;
+                        case 6: partial_sums<R, 6 % Q>(wr, xrow, acc); break;
+                        default: partial_sums<R, 7 % Q>(wr, xrow, acc); break;
+                    }
+                    double *pw = part + (c & 1) * (kWaves * 256) + wv * 256 + lane;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) pw[j * 64] = acc[j];
+                    __syncthreads();
+#pragma unroll
+                    for (int i = tid; i < G::SLABS * 256; i += 512) {
+                        const int s2 = i >> 8, j = (i >> 6) & 3, l2 = i & 63;
+                        const int py = (s2 / G::C::SL_X) * kSlabH + (l2 >> 3);
+                        const int px = (s2 % G::C::SL_X) * kSlabW + (l2 & 7) * 4 + j;
+                        const double *pr = part + (c & 1) * (kWaves * 256) + (s2 * Q) * 256 + j * 64 + l2;
+                        double sum = (double)xs[(c * LH + py + H) * LW + px + HP];
+#pragma unroll
+                        for (int q = 0; q < Q; ++q) sum += pr[q * 256];
+                        const float res = (float)(sum * invd[i]);
+                        const int yy = ty0 + py, xx = tx0 + px;
+                        if (yy < h && xx < w) {
+                            const unsigned o = (unsigned)(c0 + c) * n + (unsigned)(yy * w + xx);
+                            if (last) ((gf_t)I.out)[o] = res;
+                            else st_granule(dst + o, want + 1, res);
+                        }
+                    }
+                }
+                __syncthreads();   // xs is rewritten by the next chunk / sweep
+            }
+        }
+    }
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------
+static void tile_shape(int radius, int *th, int *tw) {
+    if (radius == 10) { *th = Geom<10>::TH; *tw = Geom<10>::TW; }
+    else { *th = Geom<5>::TH; *tw = Geom<5>::TW; }
+}
+
+bool resident_supported(const irn_walk_ctx *ctx) { return ctx->radius == 5 || ctx->radius == 10; }
+
+void resident_destroy(irn_walk_ctx *ctx) {
+    if (ctx->res_jobs_dev) (void)hipFree(ctx->res_jobs_dev);
+    if (ctx->res_err_dev) (void)hipFree(ctx->res_err_dev);
+    if (ctx->res_err_host) (void)hipHostFree(ctx->res_err_host);
+    ctx->res_jobs_dev = nullptr;
+    ctx->res_err_dev = nullptr;
+    ctx->res_err_host = nullptr;
+}
+
+// Pack the batch into rounds of at most n_wg tiles.  Sets ctx->res_ok = false (not an error) when an
+// image does not fit one round or is narrower than the radius (then irn_walk_run falls back to the
+// streaming sweeps).
+int resident_configure(irn_walk_ctx *ctx) {
+    ctx->res_ok = false;
+    if (!resident_supported(ctx)) return IRN_OK;
+    if (ctx->res_nwg == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        IRN_HIP_TRY(hipGetDevice(&dev));
+        IRN_HIP_TRY(hipGetDeviceProperties(&prop, dev));
+        ctx->res_nwg = prop.multiProcessorCount;
+    }
+    const int n_wg = ctx->res_nwg;
+    int th, tw;
+    tile_shape(ctx->radius, &th, &tw);
+    const int n = (int)ctx->h.size();
+    std::vector<int> tiles(n);
+    for (int i = 0; i < n; ++i) {
+        if (ctx->w[i] < ctx->radius) return IRN_OK;
+        tiles[i] = cdiv(ctx->h[i], th) * cdiv(ctx->w[i], tw);
+        if (tiles[i] > n_wg) return IRN_OK;
+    }
+    // first-fit in input order; slots of an image are consecutive
+    std::vector<std::vector<int4>> rounds;
+    std::vector<int> used;
+    for (int i = 0; i < n; ++i) {
+        size_t r = 0;
+        for (; r < rounds.size(); ++r)
+            if (used[r] + tiles[i] <= n_wg) break;
+        if (r == rounds.size()) {
+            rounds.emplace_back(n_wg, make_int4(-1, 0, 0, 0));
+            used.push_back(0);
+        }
+        for (int ty = 0; ty < ctx->h[i]; ty += th)
+            for (int tx = 0; tx < ctx->w[i]; tx += tw) {
+                const int slot = used[r]++;
+                // consecutive slots share an XCD: block b is dispatched to XCD b % 8 (observed)
+                const int per = (n_wg + 7) / 8;
+                int b = (slot % per) * 8 + slot / per;
+                if (n_wg % 8 != 0 || b >= n_wg) b = slot;
+                rounds[r][b] = make_int4(i, ty, tx, 0);
+            }
+    }
+    const int total = (int)rounds.size() * n_wg;
+    if (total > ctx->res_cap_jobs) {
+        if (ctx->res_jobs_dev) (void)hipFree(ctx->res_jobs_dev);
+        ctx->res_jobs_dev = nullptr;
+        IRN_HIP_TRY(hipMalloc((void **)&ctx->res_jobs_dev, sizeof(int4) * total));
+        ctx->res_cap_jobs = total;
+    }
+    std::vector<int4> flat;
+    flat.reserve(total);
+    for (auto &r : rounds) flat.insert(flat.end(), r.begin(), r.end());
+    IRN_HIP_TRY(hipMemcpy(ctx->res_jobs_dev, flat.data(), sizeof(int4) * total, hipMemcpyHostToDevice));
+    if (!ctx->res_err_dev) {
+        IRN_HIP_TRY(hipMalloc((void **)&ctx->res_err_dev, 4 * sizeof(unsigned)));
+        IRN_HIP_TRY(hipHostMalloc((void **)&ctx->res_err_host, 4 * sizeof(unsigned), hipHostMallocDefault));
+    }
+    ctx->res_rounds = (int)rounds.size();
+    ctx->res_ok = true;
+    return IRN_OK;
+}
+
+template <int R>
+static int launch_resident(irn_walk_ctx *ctx, int t_first, int t_count, int t_total, hipStream_t stream) {
+    using G = Geom<R>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        IRN_HIP_TRY(hipFuncSetAttribute((const void *)resident_kernel<R>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        G::LDS_BYTES));
+        attr_set = true;
+    }
+    const long long timeout_ticks = 200000000LL;   // 2 s of the 100 MHz wall clock
+    hipLaunchKernelGGL((resident_kernel<R>), dim3(ctx->res_nwg), dim3(512), G::LDS_BYTES, stream, ctx->imgs_dev,
+                       ctx->res_jobs_dev, ctx->res_rounds, t_first, t_count, t_total, ctx->res_err_dev, timeout_ticks);
+    IRN_LAUNCH_CHECK("resident_kernel");
+    return IRN_OK;
+}
+
+// x_0 and all sweeps of the configured batch.  The descriptors (imgs_dev) are already uploaded.
+int resident_run(irn_walk_ctx *ctx, int n_sweeps, hipStream_t stream) {
+    const int n = ctx->n;
+    IRN_HIP_TRY(hipMemsetAsync(ctx->res_err_dev, 0, 4 * sizeof(unsigned), stream));
+    hipLaunchKernelGGL(x0_granule_kernel, dim3(cdiv(ctx->max_n, 256), n), dim3(256), 0, stream, ctx->imgs_dev);
+    IRN_LAUNCH_CHECK("x0_granule_kernel");
+    const int step = ctx->res_sweeps_per_launch > 0 ? ctx->res_sweeps_per_launch : n_sweeps;
+    for (int t = 0; t < n_sweeps; t += step) {
+        const int cnt = std::min(step, n_sweeps - t);
+        const int rc = ctx->radius == 10 ? launch_resident<10>(ctx, t, cnt, n_sweeps, stream)
+                                         : launch_resident<5>(ctx, t, cnt, n_sweeps, stream);
+        if (rc) return rc;
+    }
+    IRN_HIP_TRY(hipMemcpyAsync(ctx->res_err_host, ctx->res_err_dev, 4 * sizeof(unsigned), hipMemcpyDeviceToHost, stream));
+    return IRN_OK;
+}
+
+}  // namespace irn

@@ -200,6 +200,12 @@ class RandomWalk:
         check(lib.irn_walk_set_option(self._ctx, name.encode(), int(value)))
         self._sig = None
 
+    def check(self):
+        """Raise if a weights-stationary launch (option variant=2) gave up waiting for a neighbouring
+        tile.  Synchronises the device first (the kernel reports through a pinned word)."""
+        torch.cuda.synchronize(self.device)
+        check(lib.irn_walk_check(self._ctx))
+
     def enable_timing(self, on=True):
         with torch.cuda.device(self.device):
             check(lib.irn_walk_enable_timing(self._ctx, 1 if on else 0))

@@ -1,0 +1,186 @@
+"""GPU parity of the weights-stationary persistent walk (irn_walk option variant=2,
+irn_amd/csrc/walk_resident.hip) — same operator as misc/indexing.py:141-165, weights held in
+registers for all sweeps, tiles of an image exchanging state as tagged granules inside one launch.
+
+Staleness is the failure mode to hunt: late sweeps barely change the state, so a tile that read a
+neighbour's x_{t-2} instead of x_t would pass a loose tolerance at 2^8 sweeps.  Hence (a) few-sweep
+runs, where consecutive states differ by O(0.1), against the full-fp64 generic kernel, and (b)
+bit-equality of the one-launch walk with the same kernel relaunched every sweep (kernel boundaries
+instead of in-launch hand-offs)."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import irn_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+TOL_REF = 1e-4
+TOL_F64 = 1e-5
+
+
+def _dev():
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    return torch.device("cuda", 0)
+
+
+def _walker(r, variant=2, **opts):
+    from irn_amd.misc import indexing
+    wk = indexing.RandomWalk(r, _dev())
+    wk.set_option("variant", variant)
+    for k, v in opts.items():
+        wk.set_option(k, v)
+    return wk
+
+
+def _inputs(shapes, seed0):
+    from irn_amd import synth
+    edges = [torch.from_numpy(synth.edge_field(h, w, seed=seed0 + i)).to(_dev()) for i, (h, w, c) in enumerate(shapes)]
+    cams = [torch.from_numpy(synth.cam_blobs(c, h, w, seed=seed0 + i)).to(_dev()) for i, (h, w, c) in enumerate(shapes)]
+    return edges, cams
+
+
+def test_resident_vs_reference_golden(golden):
+    wk = golden("walk")
+    names = sorted(k[:-3] for k in wk.files if k.endswith("_rw"))
+    done = 0
+    for n in names:
+        h, w, c, r, b, e = (int(v) for v in wk[n + "_params"])
+        if r not in (5, 10):
+            continue
+        walker = _walker(r)
+        cam = torch.from_numpy(wk[n + "_cam"]).to(_dev())
+        if n.endswith("_ck"):
+            cam = cam.view(2, c // 2, h, w)
+        edge = torch.from_numpy(wk[n + "_edge"])[None].to(_dev())
+        rw = walker([edge], [cam], beta=b, exp_times=e)[0]
+        walker.check()
+        rw = rw.cpu().numpy()
+        ref = wk[n + "_rw"]
+        assert rw.shape == ref.shape, n
+        assert np.abs(rw - ref).max() <= TOL_REF, (n, np.abs(rw - ref).max())
+        assert np.array_equal(np.argmax(rw[:, 0], 0), np.argmax(ref[:, 0], 0)), n
+        st = O.propagate_to_edge_stencil(wk[n + "_cam"], wk[n + "_edge"], r, b, e)
+        assert np.abs(rw - st).max() <= TOL_F64, (n, np.abs(rw - st).max())
+        walker.close()
+        done += 1
+    assert done >= 8
+
+
+@pytest.mark.parametrize("r,shapes", [
+    (10, [(128, 128, 1), (128, 128, 2), (128, 128, 3), (128, 128, 1), (128, 128, 4), (128, 128, 1)]),   # 2 rounds
+    (10, [(94, 125, 2), (125, 84, 1), (40, 52, 9), (33, 70, 20), (128, 128, 1), (30, 30, 3), (130, 250, 2)]),
+    (5, [(128, 128, 3), (94, 125, 1), (47, 31, 7), (12, 9, 2), (130, 66, 17), (64, 64, 4)]),
+    (10, [(256, 256, 5)]),                                                                          # all 256 workgroups
+    (5, [(256, 256, 11), (128, 128, 2)]),
+])
+def test_few_sweeps_match_generic_fp64_kernel(r, shapes):
+    edges, cams = _inputs(shapes, 300)
+    res = _walker(r)
+    gen = _walker(r, variant=0)
+    for n_sw in (1, 2, 3, 7):
+        a = res(edges, cams, beta=10, n_sweeps=n_sw)
+        res.check()
+        b = gen(edges, cams, beta=10, n_sweeps=n_sw)
+        for i in range(len(shapes)):
+            d = (a[i] - b[i]).abs().max().item()
+            assert d <= 1e-6, (r, shapes[i], n_sw, d)
+    res.close()
+    gen.close()
+
+
+@pytest.mark.parametrize("r,shapes", [
+    (10, [(128, 128, 1), (128, 128, 3), (94, 125, 2), (125, 94, 12), (128, 128, 2)]),
+    (5, [(128, 128, 2), (94, 125, 9), (125, 94, 1), (60, 200, 3)]),
+])
+def test_one_launch_equals_launch_per_sweep_bitwise(r, shapes):
+    """In-launch hand-offs between tiles vs kernel boundaries: identical arithmetic, so any stale or
+    torn hand-off shows as a bit difference.  Runs twice on the same workspace (stale tags of the
+    previous run must never match)."""
+    edges, cams = _inputs(shapes, 500)
+    per = _walker(r, sweeps_per_launch=1)
+    ref = [o.clone() for o in per(edges, cams, beta=10, n_sweeps=24)]
+    per.check()
+    one = _walker(r)
+    for rep in range(3):
+        out = one(edges, cams, beta=10, n_sweeps=24)
+        one.check()
+        for i in range(len(shapes)):
+            assert torch.equal(out[i], ref[i]), (r, shapes[i], rep)
+    # chunks of 5 sweeps per launch (odd chunk: both buffer parities at launch boundaries)
+    five = _walker(r, sweeps_per_launch=5)
+    out = five(edges, cams, beta=10, n_sweeps=24)
+    five.check()
+    for i in range(len(shapes)):
+        assert torch.equal(out[i], ref[i])
+    for wkr in (per, one, five):
+        wkr.close()
+
+
+def test_uneven_load_many_rounds_batch_equals_single():
+    """40 images with 1..6 channels (10 rounds at radius 10): tiles of light images run ahead of heavy
+    ones inside a round and rounds pipeline; every image must equal its single-image run bit for bit."""
+    shapes = [(128, 128, 1 + (i * 7) % 6) for i in range(40)]
+    edges, cams = _inputs(shapes, 900)
+    wk = _walker(10)
+    batch = [o.clone() for o in wk(edges, cams, beta=10, n_sweeps=40)]
+    wk.check()
+    for i in (0, 5, 17, 39):
+        single = wk([edges[i]], [cams[i]], beta=10, n_sweeps=40)[0]
+        wk.check()
+        assert torch.equal(single, batch[i]), i
+    gen = _walker(10, variant=0)
+    for i in (3, 22):
+        g = gen([edges[i]], [cams[i]], beta=10, n_sweeps=40)[0]
+        assert (g - batch[i]).abs().max().item() <= 2e-6
+    wk.close()
+    gen.close()
+
+
+def test_instance_split_and_full_walk_vs_oracle(golden):
+    ins = golden("instance")
+    for name in "abc":
+        edge, cam = ins[name + "_edge"], ins[name + "_cam"]
+        shape = tuple(ins[name + "_instance_map_shape"])
+        inst = np.unpackbits(ins[name + "_instance_map"])[:int(np.prod(shape))].reshape(shape)
+        cmap = np.argmax(inst, 0).astype(np.int32)
+        wk = _walker(5)
+        rw = wk([torch.from_numpy(edge).to(_dev())], [torch.from_numpy(cam).to(_dev())], beta=10, exp_times=8,
+                inst_maps=[torch.from_numpy(cmap).to(_dev())], k_inst=[shape[0]])[0]
+        wk.check()
+        assert np.abs(rw.cpu().numpy() - ins[name + "_rw"]).max() <= TOL_REF
+        wk.close()
+
+
+def test_full_size_256_sweeps_vs_fp64_oracle_and_streaming_kernel():
+    from irn_amd import synth
+    h = w = 128
+    edge = synth.edge_field(h, w, seed=11)
+    cam = synth.cam_blobs(2, h, w, seed=11)
+    e, c = torch.from_numpy(edge).to(_dev()), torch.from_numpy(cam).to(_dev())
+    wk = _walker(10)
+    rw = wk([e], [c], beta=10, exp_times=8)[0]
+    wk.check()
+    st = O.propagate_to_edge_stencil(cam, edge, 10, 10, 8)
+    assert np.abs(rw.cpu().numpy() - st).max() <= TOL_F64
+    assert np.array_equal(np.argmax(rw.cpu().numpy()[:, 0], 0), np.argmax(st[:, 0], 0))
+    blocked = _walker(10, variant=1)
+    rb = blocked([e], [c], beta=10, exp_times=8)[0]
+    assert (rw - rb).abs().max().item() <= 2e-6
+    wk.close()
+    blocked.close()
+
+
+def test_falls_back_when_an_image_does_not_fit_a_round():
+    """A 264x264 radius-10 image has 33x9 = 297 tiles > 256 workgroups: the run must still be right
+    (streaming sweeps take over) — and so must a narrow image (w < radius)."""
+    for r, shp in ((10, (264, 264, 2)), (5, (20, 4, 2))):
+        edges, cams = _inputs([shp], 40)
+        wk = _walker(r)
+        a = wk(edges, cams, beta=10, n_sweeps=8)[0]
+        wk.check()
+        gen = _walker(r, variant=0)
+        b = gen(edges, cams, beta=10, n_sweeps=8)[0]
+        assert (a - b).abs().max().item() <= 2e-6
+        wk.close()
+        gen.close()
