@@ -105,6 +105,11 @@ int irn_walk_set_option(irn_walk_ctx *ctx, const char *name, int value);
  * variants. */
 int irn_walk_check(irn_walk_ctx *ctx);
 
+/* Diagnostic (option "profile" = 1, resident walk only): per-sweep time stamps of two workgroups of
+ * the first round — host_out is int64 [2][256][4] = {sweep start, state staged, first partial sums
+ * in LDS, sweep stored} in ticks of the 100 MHz wall clock.  Synchronises the device. */
+int irn_walk_read_profile(irn_walk_ctx *ctx, long long *host_out);
+
 /* Kernel timing hook for bench.py: when enabled, every irn_walk_run brackets its sweep kernels
  * with a pair of HIP events on `stream` (no synchronisation).  irn_walk_last_sweep_ms waits for the
  * pairs recorded since its previous call, returns their summed elapsed time and the number of

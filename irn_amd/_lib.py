@@ -38,6 +38,7 @@ _SIGS = {
     "irn_walk_run": (i32, [vp, ppv, ppv, ppv, pi32, ppv, f32, i32, vp, sz, vp]),
     "irn_walk_set_option": (i32, [vp, C.c_char_p, i32]),
     "irn_walk_check": (i32, [vp]),
+    "irn_walk_read_profile": (i32, [vp, vp]),
     "irn_walk_enable_timing": (i32, [vp, i32]),
     "irn_walk_last_sweep_ms": (i32, [vp, C.POINTER(f32), C.POINTER(i32)]),
     "irn_walk_export_weights": (i32, [vp, i32, vp, vp, vp, vp]),

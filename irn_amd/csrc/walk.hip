@@ -536,6 +536,20 @@ extern "C" int irn_walk_set_option(irn_walk_ctx *ctx, const char *name, int valu
     } else if (!strcmp(name, "sweeps_per_launch")) {
         if (value < 0) return fail(IRN_ERR_ARG, "sweeps_per_launch must be >= 0");
         ctx->res_sweeps_per_launch = value;
+    } else if (!strcmp(name, "poll_delay")) {
+        if (value < 0 || value > 1000) return fail(IRN_ERR_ARG, "poll_delay must be in [0,1000]");
+        ctx->res_poll_delay = value;
+    } else if (!strcmp(name, "poll_stagger")) {
+        if (value < 0 || value > 1000) return fail(IRN_ERR_ARG, "poll_stagger must be in [0,1000]");
+        ctx->res_poll_stagger = value;
+    } else if (!strcmp(name, "profile")) {
+        if (value && !ctx->res_prof_dev) {
+            IRN_HIP_TRY(hipMalloc((void **)&ctx->res_prof_dev, 2 * 256 * 4 * sizeof(long long)));
+            IRN_HIP_TRY(hipMemset(ctx->res_prof_dev, 0, 2 * 256 * 4 * sizeof(long long)));
+        } else if (!value && ctx->res_prof_dev) {
+            (void)hipFree(ctx->res_prof_dev);
+            ctx->res_prof_dev = nullptr;
+        }
     } else if (!strcmp(name, "xcd_map")) {
         ctx->xcd_map = value ? 1 : 0;
     } else if (!strcmp(name, "probe")) {
@@ -875,6 +889,13 @@ extern "C" int irn_walk_check(irn_walk_ctx *ctx) {
         return fail(IRN_ERR_STATE, "resident walk timed out: workgroup %u waiting for state of sweep %u of image %u "
                                    "(a neighbouring tile never published it)", wg, t, img);
     }
+    return IRN_OK;
+}
+
+extern "C" int irn_walk_read_profile(irn_walk_ctx *ctx, long long *host_out) {
+    if (!ctx || !host_out) return fail(IRN_ERR_ARG, "null argument");
+    if (!ctx->res_prof_dev) return fail(IRN_ERR_STATE, "option 'profile' is off");
+    IRN_HIP_TRY(hipMemcpy(host_out, ctx->res_prof_dev, 2 * 256 * 4 * sizeof(long long), hipMemcpyDeviceToHost));
     return IRN_OK;
 }
 

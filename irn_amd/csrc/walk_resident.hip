@@ -85,7 +85,12 @@ struct Geom {
     static constexpr int H = R - 1;
     static constexpr int HP = (H + 3) / 4 * 4;          // LDS column of tile column 0 (16-byte aligned windows)
     static constexpr int TH = kSlabH * C::SL_Y, TW = kSlabW * C::SL_X;
-    static constexpr int LH = TH + 2 * H, LW = TW + 2 * HP;
+    // LDS row stride = 32 banks (mod 64): the 16-lane groups of a ds_read_b128 ({0-3,12-15,20-27}, ...)
+    // span four tile rows; with this stride their 16-byte chunks fall on distinct banks
+    // (56 floats, the tight fit, was 2-3-way conflicted: 0.95 us of a 3.1 us sweep).
+    static constexpr int LH = TH + 2 * H, LW = 96;
+    static_assert(LW >= TW + 2 * HP && LW % 64 == 32, "LDS row stride");
+    static constexpr int NK = (LH * (TW + 2 * H) + 511) / 512;   // staged pixels per thread and channel
     static constexpr int LWU = TW + 2 * H;               // columns actually staged
     static constexpr int RG = LH * LWU;                  // staged pixels per channel
     static constexpr int D = kDisc<R>.n;
@@ -170,6 +175,9 @@ __device__ __forceinline__ void partial_sums(const float (&wr)[Geom<R>::NS][4], 
                 const f4a v = *reinterpret_cast<const f4a *>(row + 4 * k);
                 win[4 * k] = v.x; win[4 * k + 1] = v.y; win[4 * k + 2] = v.z; win[4 * k + 3] = v.w;
             }
+            // One fp32 chain per pixel and row segment (<= 19 terms).  The sweep is VALU-throughput
+            // bound here (152 v_fmac per wave, two waves per SIMD), so extra chains for ILP only add
+            // instructions (measured: slower).
             float pf[4] = {0.f, 0.f, 0.f, 0.f};
             static_for<hi - lo + 1>([&](auto is) __attribute__((always_inline)) {
                 constexpr int s = lo + decltype(is)::value;
@@ -184,11 +192,21 @@ __device__ __forceinline__ void partial_sums(const float (&wr)[Geom<R>::NS][4], 
     });
 }
 
-__device__ __forceinline__ u64 ld_granule(const gu64_t p) {
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+// Granule = {fp32 value, tag} in one naturally aligned 8-byte word, moved by ONE agent-scope access:
+// buffer_load/store_dwordx2 with sc1 (aux 16) — the store writes through to memory, the load
+// bypasses this CU's L1 (MI355X guide, Guideline 16 R1/R2).  Buffer addressing keeps the base in
+// SGPRs and needs one 32-bit VGPR per item (64-bit flat addresses cost 2 and pushed the kernel
+// into scratch).
+typedef unsigned u2v __attribute__((ext_vector_type(2)));
+constexpr int kSc1 = 16;
+__device__ __forceinline__ u2v ld_granule(__amdgpu_buffer_rsrc_t rsrc, int voff, int soff) {
+    return __builtin_bit_cast(u2v, __builtin_amdgcn_raw_buffer_load_b64(rsrc, voff, soff, kSc1));
 }
-__device__ __forceinline__ void st_granule(gu64_t p, unsigned tag, float v) {
-    __hip_atomic_store(p, ((u64)tag << 32) | (u64)__float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+__device__ __forceinline__ void st_granule(__amdgpu_buffer_rsrc_t rsrc, int voff, int soff, unsigned tag, float v) {
+    u2v g;
+    g.x = __float_as_uint(v);
+    g.y = tag;
+    __builtin_amdgcn_raw_buffer_store_b64(g, rsrc, voff, soff, kSc1);
 }
 
 // x_0 = cam * (1 - edge) (misc/indexing.py:162; instance split step/make_ins_seg_labels.py:77-80) as
@@ -214,9 +232,10 @@ __global__ __launch_bounds__(256) void x0_granule_kernel(const WalkImg *__restri
 template <int R>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void resident_kernel(
     const WalkImg *__restrict__ imgs, const int4 *__restrict__ jobs, int n_rounds, int t_first, int t_count,
-    int t_total, unsigned *err, long long timeout_ticks) {
+    int t_total, unsigned *err, long long timeout_ticks, long long *prof, int poll_delay, int poll_stagger) {
     using G = Geom<R>;
-    constexpr int H = G::H, HP = G::HP, LH = G::LH, LW = G::LW, LWU = G::LWU, RG = G::RG, Q = G::Q;
+    constexpr int H = G::H, HP = G::HP, LH = G::LH, LW = G::LW, LWU = G::LWU, RG = G::RG, Q = G::Q, NK = G::NK;
+    static_assert(kChs * NK <= 32, "pending mask is 32 bits");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float *xs = reinterpret_cast<float *>(smem);
     double *part = reinterpret_cast<double *>(smem + G::XS_BYTES);
@@ -232,6 +251,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     if (tid == 0) *abort_flag = 0;
 
     float wr[G::NS][4];
+    // Delay of the first poll, in s_sleep(1) = 64 clocks.  Fixed on purpose: steering it from
+    // hits and misses was tried twice and lost both times — a miss usually means a neighbour was
+    // late, not that this workgroup polled early, so every tile backs off together (symmetric
+    // steering: 3.6 us per sweep, late-only steering: 3.5 us and drifting, fixed 12: 2.7-3.0 us).
+    const int delay = poll_delay;
 
 #pragma unroll 1
     for (int round = 0; round < n_rounds; ++round) {
@@ -262,56 +286,107 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             const int xx = tx0 + (s2 % G::C::SL_X) * kSlabW + (l2 & 7) * 4 + j;
             invd[i] = (yy < h && xx < w) ? ((gcd_t)I.inv_deg)[yy * w + xx] : 0.0;
         }
+        // staged pixels of this lane (the same for every channel and sweep of the job); positions
+        // outside the image are zeroed once here and never polled
+        int bgoff[NK];     // byte offset of the granule inside one channel of the state
+        int blidx[NK];
+        unsigned vmask = 0;
+#pragma unroll
+        for (int k = 0; k < NK; ++k) {
+            const int i = tid + k * 512;
+            const int ry = i / LWU, rx = i - ry * LWU;
+            const int yy = ty0 - H + ry, xx = tx0 - H + rx;
+            blidx[k] = ry * LW + rx + (HP - H);
+            bgoff[k] = (yy * w + xx) * 8;
+            if (i < RG && yy >= 0 && yy < h && xx >= 0 && xx < w) vmask |= 1u << k;
+        }
+        for (int i = tid; i < kChs * LH * LW; i += 512) xs[i] = 0.f;
+        __syncthreads();
 
 #pragma unroll 1
         for (int t = t_first; t < t_first + t_count; ++t) {
-            const gu64_t src = (gu64_t)((t & 1) ? I.xb : I.xa);
-            const gu64_t dst = (gu64_t)((t & 1) ? I.xa : I.xb);
+            const int state_bytes = (int)(8u * n * (unsigned)I.C);
+            const __amdgpu_buffer_rsrc_t src =
+                __builtin_amdgcn_make_buffer_rsrc((void *)((t & 1) ? I.xb : I.xa), 0, state_bytes, 0x00020000);
+            const __amdgpu_buffer_rsrc_t dst =
+                __builtin_amdgcn_make_buffer_rsrc((void *)((t & 1) ? I.xa : I.xb), 0, state_bytes, 0x00020000);
+            const int ch_bytes = (int)(8u * n);
             const bool last = (t + 1 == t_total);
             const unsigned want = (unsigned)(t + 1);
+            // diagnostic time stamps (100 MHz wall clock) of round 0 for two workgroups
+            long long *pslot = nullptr;
+            if (prof && round == 0 && tid == 0 && (blockIdx.x == 0 || blockIdx.x == gridDim.x / 2) && t - t_first < 256)
+                pslot = prof + ((blockIdx.x == 0 ? 0 : 256) + (t - t_first)) * 4;
+            if (pslot) pslot[0] = wall_clock64();
 #pragma unroll 1
             for (int c0 = 0; c0 < I.C; c0 += kChs) {
                 const int nch = min(kChs, I.C - c0);
-                // ---- poll + stage x_t of the tile and its halo (zero outside the image) ----
-                const int n_items = nch * RG;
-#pragma unroll 1
-                for (int base = 0; base < n_items; base += 512 * 8) {
-                    unsigned goff[8];
-                    int lidx[8];
+                // ---- poll + stage x_t of the tile and its halo ----
+                // Two poll slots, each NK granules x 2 channels per lane.  All tiles of an image run in
+                // lock step, so nothing is ready right after our own stores: the first poll is delayed
+                // by `poll_delay` so that it samples memory just after the neighbours' stores have
+                // landed, the second follows `poll_stagger` later, and each slot re-polls as soon as it
+                // has been examined (a lone slot quantises the wait to whole ~0.85 us round trips;
+                // polling early is worse than useless — delay 0 measured 4.3 us per sweep against 2.7
+                // at delay 10-12: the early loads pull stale lines that the stores must then displace).
+                {
+                    const int n_pairs = (nch + 1) >> 1;
                     unsigned pend = 0;
+                    unsigned live = 0;                                   // wave-uniform: pairs with pending lanes
+                    for (int c = 0; c < nch; ++c) pend |= vmask << (c * NK);
+                    for (int pr = 0; pr < n_pairs; ++pr)
+                        if (__builtin_amdgcn_ballot_w64(((pend >> (2 * pr * NK)) & ((1u << (2 * NK)) - 1u)) != 0)) live |= 1u << pr;
+                    int rr = 0;
+                    auto pick = [&]() {
+                        int pr = rr;
+                        while (!((live >> pr) & 1u)) pr = (pr + 1 == n_pairs) ? 0 : pr + 1;
+                        rr = (pr + 1 == n_pairs) ? 0 : pr + 1;
+                        return pr;
+                    };
+                    auto issue = [&](u2v (&v)[2 * NK], int pr) __attribute__((always_inline)) {
 #pragma unroll
-                    for (int k = 0; k < 8; ++k) {
-                        const int i = base + k * 512 + tid;
-                        const int c = i / RG;
-                        const int r = i - c * RG;
-                        const int ry = r / LWU, rx = r - ry * LWU;
-                        const int yy = ty0 - H + ry, xx = tx0 - H + rx;
-                        lidx[k] = (c * LH + ry) * LW + rx + (HP - H);
-                        goff[k] = (unsigned)(c0 + c) * n + (unsigned)(yy * w + xx);
-                        if (i < n_items) {
-                            if (yy >= 0 && yy < h && xx >= 0 && xx < w) pend |= 1u << k;
-                            else xs[lidx[k]] = 0.f;
-                        }
-                    }
-                    long long t_start = 0;
-                    while (pend) {
-                        u64 v[8];
+                        for (int ch = 0; ch < 2; ++ch)
 #pragma unroll
-                        for (int k = 0; k < 8; ++k)
-                            if (pend & (1u << k)) v[k] = ld_granule(src + goff[k]);
+                            for (int k = 0; k < NK; ++k)
+                                if ((pend >> ((2 * pr + ch) * NK + k)) & 1u)
+                                    v[ch * NK + k] = ld_granule(src, bgoff[k], (c0 + 2 * pr + ch) * ch_bytes);
+                    };
+                    auto consume = [&](const u2v (&v)[2 * NK], int pr) __attribute__((always_inline)) {
 #pragma unroll
-                        for (int k = 0; k < 8; ++k)
-                            if ((pend & (1u << k)) && (unsigned)(v[k] >> 32) == want) {
-                                xs[lidx[k]] = __uint_as_float((unsigned)v[k]);
-                                pend &= ~(1u << k);
+                        for (int ch = 0; ch < 2; ++ch)
+#pragma unroll
+                            for (int k = 0; k < NK; ++k) {
+                                const unsigned bit = 1u << ((2 * pr + ch) * NK + k);
+                                if ((pend & bit) && v[ch * NK + k].y == want) {
+                                    xs[blidx[k] + (2 * pr + ch) * (LH * LW)] = __uint_as_float(v[ch * NK + k].x);
+                                    pend &= ~bit;
+                                }
                             }
-                        if (pend) {
-                            __builtin_amdgcn_s_sleep(2);
+                        if (!__builtin_amdgcn_ballot_w64(((pend >> (2 * pr * NK)) & ((1u << (2 * NK)) - 1u)) != 0)) live &= ~(1u << pr);
+                    };
+                    if (live) {
+                        u2v va[2 * NK], vb[2 * NK];
+                        for (int d = 0; d < delay; ++d) __builtin_amdgcn_s_sleep(1);
+                        int pa = pick();
+                        issue(va, pa);
+                        for (int d = 0; d < poll_stagger; ++d) __builtin_amdgcn_s_sleep(1);
+                        int pb = pick();
+                        issue(vb, pb);
+                        long long t_start = 0;
+                        for (;;) {
+                            consume(va, pa);
+                            if (!live) break;
+                            pa = pick();
+                            issue(va, pa);
+                            consume(vb, pb);
+                            if (!live) break;
+                            pb = pick();
+                            issue(vb, pb);
                             const long long now = wall_clock64();
                             if (t_start == 0) t_start = now;
                             else if (now - t_start > timeout_ticks ||
                                      __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
-                                if (atomicCAS(err, 0u, 1u) == 0u) {
+                                if (lane == 0 && atomicCAS(err, 0u, 1u) == 0u) {
                                     err[1] = (unsigned)je.x;
                                     err[2] = (unsigned)t;
                                     err[3] = blockIdx.x;
@@ -324,6 +399,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 }
                 __syncthreads();
                 if (*abort_flag) return;
+                if (pslot && c0 == 0) pslot[1] = wall_clock64();
 
                 // ---- channels of the chunk: partial sums -> LDS -> fp64 combine -> store ----
 #pragma unroll 1
@@ -344,6 +420,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
                     for (int j = 0; j < 4; ++j) pw[j * 64] = acc[j];
                     __syncthreads();
+                    if (pslot && c0 == 0 && c == 0) pslot[2] = wall_clock64();
 #pragma unroll
                     for (int i = tid; i < G::SLABS * 256; i += 512) {
                         const int s2 = i >> 8, j = (i >> 6) & 3, l2 = i & 63;
@@ -356,14 +433,14 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                         const float res = (float)(sum * invd[i]);
                         const int yy = ty0 + py, xx = tx0 + px;
                         if (yy < h && xx < w) {
-                            const unsigned o = (unsigned)(c0 + c) * n + (unsigned)(yy * w + xx);
-                            if (last) ((gf_t)I.out)[o] = res;
-                            else st_granule(dst + o, want + 1, res);
+                            if (last) ((gf_t)I.out)[(unsigned)(c0 + c) * n + (unsigned)(yy * w + xx)] = res;
+                            else st_granule(dst, (yy * w + xx) * 8, (c0 + c) * ch_bytes, want + 1, res);
                         }
                     }
                 }
                 __syncthreads();   // xs is rewritten by the next chunk / sweep
             }
+            if (pslot) pslot[3] = wall_clock64();
         }
     }
 }
@@ -384,6 +461,8 @@ void resident_destroy(irn_walk_ctx *ctx) {
     if (ctx->res_jobs_dev) (void)hipFree(ctx->res_jobs_dev);
     if (ctx->res_err_dev) (void)hipFree(ctx->res_err_dev);
     if (ctx->res_err_host) (void)hipHostFree(ctx->res_err_host);
+    if (ctx->res_prof_dev) (void)hipFree(ctx->res_prof_dev);
+    ctx->res_prof_dev = nullptr;
     ctx->res_jobs_dev = nullptr;
     ctx->res_err_dev = nullptr;
     ctx->res_err_host = nullptr;
@@ -464,7 +543,8 @@ static int launch_resident(irn_walk_ctx *ctx, int t_first, int t_count, int t_to
     }
     const long long timeout_ticks = 200000000LL;   // 2 s of the 100 MHz wall clock
     hipLaunchKernelGGL((resident_kernel<R>), dim3(ctx->res_nwg), dim3(512), G::LDS_BYTES, stream, ctx->imgs_dev,
-                       ctx->res_jobs_dev, ctx->res_rounds, t_first, t_count, t_total, ctx->res_err_dev, timeout_ticks);
+                       ctx->res_jobs_dev, ctx->res_rounds, t_first, t_count, t_total, ctx->res_err_dev, timeout_ticks,
+                       ctx->res_prof_dev, ctx->res_poll_delay, ctx->res_poll_stagger);
     IRN_LAUNCH_CHECK("resident_kernel");
     return IRN_OK;
 }

@@ -206,6 +206,14 @@ class RandomWalk:
         torch.cuda.synchronize(self.device)
         check(lib.irn_walk_check(self._ctx))
 
+    def read_profile(self):
+        """int64 [2,256,4] per-sweep time stamps (10 ns ticks) of two workgroups (option profile=1)."""
+        import numpy as np
+        buf = np.zeros((2, 256, 4), np.int64)
+        torch.cuda.synchronize(self.device)
+        check(lib.irn_walk_read_profile(self._ctx, buf.ctypes.data))
+        return buf
+
     def enable_timing(self, on=True):
         with torch.cuda.device(self.device):
             check(lib.irn_walk_enable_timing(self._ctx, 1 if on else 0))

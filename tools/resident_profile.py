@@ -1,0 +1,29 @@
+"""Per-sweep latency breakdown of the resident walk (option profile=1)."""
+import sys
+import numpy as np
+import torch
+sys.path.insert(0, ".")
+from irn_amd import synth
+from irn_amd.misc import indexing
+
+dev = torch.device("cuda", 0)
+r, h, w = int(sys.argv[1]) if len(sys.argv) > 1 else 10, 128, 128
+nimg = int(sys.argv[2]) if len(sys.argv) > 2 else 4
+cch = int(sys.argv[3]) if len(sys.argv) > 3 else 1
+edges = [torch.from_numpy(synth.edge_field(h, w, seed=i)).to(dev) for i in range(nimg)]
+cams = [torch.from_numpy(synth.cam_blobs(cch, h, w, seed=i)).to(dev) for i in range(nimg)]
+wk = indexing.RandomWalk(r, dev)
+wk.set_option("variant", 2)
+wk.set_option("profile", 1)
+for kv in sys.argv[4:]:
+    k, v = kv.split("=")
+    wk.set_option(k, int(v))
+for _ in range(2):
+    wk(edges, cams, beta=10, n_sweeps=256)
+wk.check()
+p = wk.read_profile().astype(np.float64) * 0.01      # us
+for g in range(2):
+    q = p[g, 8:250]
+    tot = np.diff(q[:, 0])
+    print(" ".join(sys.argv[1:]), "wg %d: sweep period %.2f us (min %.2f max %.2f); poll+stage %.2f, first partials %.2f, reduce+store %.2f" %
+          (g, tot.mean(), tot.min(), tot.max(), (q[:, 1] - q[:, 0]).mean(), (q[:, 2] - q[:, 1]).mean(), (q[:, 3] - q[:, 2]).mean()))
