@@ -13,7 +13,7 @@ import os
 import torch  # noqa: F401  (side effect: HIP runtime of the process)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libirn_hip.so")
+LIB_PATH = os.environ.get("IRN_HIP_LIB") or os.path.join(_HERE, "lib", "libirn_hip.so")   # override: A/B runs of two builds
 
 if not os.path.exists(LIB_PATH):
     raise ImportError(

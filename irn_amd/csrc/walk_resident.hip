@@ -47,7 +47,6 @@ typedef float f4a __attribute__((ext_vector_type(4)));
 
 constexpr int kSlabH = 8, kSlabW = 32;     // 64 lanes x 4 px
 constexpr int kWaves = 8;                  // 512 threads
-constexpr int kChs = 8;                    // channels staged in LDS at a time
 
 template <int R>
 struct RCfg;
@@ -90,7 +89,7 @@ struct Geom {
     // (56 floats, the tight fit, was 2-3-way conflicted: 0.95 us of a 3.1 us sweep).
     static constexpr int LH = TH + 2 * H, LW = 96;
     static_assert(LW >= TW + 2 * HP && LW % 64 == 32, "LDS row stride");
-    static constexpr int NK = (LH * (TW + 2 * H) + 511) / 512;   // staged pixels per thread and channel
+    static constexpr int NK = (LH * (TW + 2 * H) + 255) / 256;   // staged pixels per polling lane (waves 4-7)
     static constexpr int LWU = TW + 2 * H;               // columns actually staged
     static constexpr int RG = LH * LWU;                  // staged pixels per channel
     static constexpr int D = kDisc<R>.n;
@@ -100,7 +99,7 @@ struct Geom {
     static_assert(D % Q == 0, "disc must split evenly over the waves of a slab");
     static_assert(SLABS * Q == kWaves, "8 waves per workgroup");
     // LDS carve (bytes)
-    static constexpr int XS_BYTES = kChs * LH * LW * 4;
+    static constexpr int XS_BYTES = 2 * LH * LW * 4;               // [2][LH][LW] fp32, double-buffered per step
     static constexpr int PART_BYTES = 2 * kWaves * 4 * 64 * 8;      // [2][wave][j][lane] fp64
     static constexpr int INVD_BYTES = SLABS * 4 * 64 * 8;           // [slab][j][lane] fp64
     static constexpr int LDS_BYTES = XS_BYTES + PART_BYTES + INVD_BYTES + 16;
@@ -235,7 +234,6 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     int t_total, unsigned *err, long long timeout_ticks, long long *prof, int poll_delay, int poll_stagger) {
     using G = Geom<R>;
     constexpr int H = G::H, HP = G::HP, LH = G::LH, LW = G::LW, LWU = G::LWU, RG = G::RG, Q = G::Q, NK = G::NK;
-    static_assert(kChs * NK <= 32, "pending mask is 32 bits");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float *xs = reinterpret_cast<float *>(smem);
     double *part = reinterpret_cast<double *>(smem + G::XS_BYTES);
@@ -251,11 +249,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     if (tid == 0) *abort_flag = 0;
 
     float wr[G::NS][4];
-    // Delay of the first poll, in s_sleep(1) = 64 clocks.  Fixed on purpose: steering it from
-    // hits and misses was tried twice and lost both times — a miss usually means a neighbour was
-    // late, not that this workgroup polled early, so every tile backs off together (symmetric
-    // steering: 3.6 us per sweep, late-only steering: 3.5 us and drifting, fixed 12: 2.7-3.0 us).
-    const int delay = poll_delay;
+    // poll_delay / poll_stagger: units of s_sleep(1) = 64 clocks.  Fixed on purpose: steering the delay
+    // from hits and misses was tried twice and lost both times — a miss usually means a neighbour
+    // was late, not that this workgroup polled early, so every tile backs off together (symmetric
+    // steering: 3.6 us per sweep, late-only steering: 3.5 us and drifting, fixed: 2.7-3.0 us).
 
 #pragma unroll 1
     for (int round = 0; round < n_rounds; ++round) {
@@ -286,161 +283,162 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             const int xx = tx0 + (s2 % G::C::SL_X) * kSlabW + (l2 & 7) * 4 + j;
             invd[i] = (yy < h && xx < w) ? ((gcd_t)I.inv_deg)[yy * w + xx] : 0.0;
         }
-        // staged pixels of this lane (the same for every channel and sweep of the job); positions
+        // Wave roles: waves 4-7 poll and stage the state, waves 0-3 combine and store it.  A wave
+        // that issued divergent stores after its prefetched poll loads can only wait for those loads
+        // with vmcnt(0), i.e. for the write-through acknowledge of the stores as well (that put the
+        // whole store latency, ~0.5 us, into every step); a polling wave never stores.
+        const bool poller = wv >= 4;
+        // staged pixels of a polling lane (the same for every channel and sweep of the job): byte
+        // offset of the granule inside one channel (high bits) | LDS index (low 12 bits); positions
         // outside the image are zeroed once here and never polled
-        int bgoff[NK];     // byte offset of the granule inside one channel of the state
-        int blidx[NK];
+        unsigned btab[NK];
         unsigned vmask = 0;
 #pragma unroll
         for (int k = 0; k < NK; ++k) {
-            const int i = tid + k * 512;
+            const int i = (tid - 256) + k * 256;
             const int ry = i / LWU, rx = i - ry * LWU;
             const int yy = ty0 - H + ry, xx = tx0 - H + rx;
-            blidx[k] = ry * LW + rx + (HP - H);
-            bgoff[k] = (yy * w + xx) * 8;
-            if (i < RG && yy >= 0 && yy < h && xx >= 0 && xx < w) vmask |= 1u << k;
+            btab[k] = ((unsigned)(yy * w + xx) << 15) | (unsigned)(ry * LW + rx + (HP - H));
+            if (poller && i < RG && yy >= 0 && yy < h && xx >= 0 && xx < w) vmask |= 1u << k;
         }
-        for (int i = tid; i < kChs * LH * LW; i += 512) xs[i] = 0.f;
+        for (int i = tid; i < 2 * LH * LW; i += 512) xs[i] = 0.f;
         __syncthreads();
 
+        // ---- the walk of this tile: a pipeline of steps (sweep t, channel c), c fastest ----
+        // Step k stages x_t[c] into xs[k & 1], forms the partial sums into part[k & 1], combines and
+        // stores x_{t+1}[c].  Channels are independent chains, so with C >= 2 the poll of step k+1
+        // is issued before the arithmetic of step k and its round trip through the fabric is hidden;
+        // with C = 1 the next step's input does not exist before this step's stores have landed in
+        // the neighbouring tiles, and the poll waits `poll_delay` behind our own stores instead.
+        const int C = I.C;
+        const int ch_bytes = (int)(8u * n);
+        const int state_bytes = (int)(8u * n * (unsigned)C);
+        const int n_steps = t_count * C;
+        // delays are counted in s_sleep(1) = 64 clocks; reading a clock instead (s_memrealtime in
+        // every wave, several times per step) cost more than 1 us per step
+        auto nap = [&](int units) {
+            for (int d = 0; d < units; ++d) __builtin_amdgcn_s_sleep(1);
+        };
+        auto state_rsrc = [&](int tt) {
+            return __builtin_amdgcn_make_buffer_rsrc((void *)((tt & 1) ? I.xb : I.xa), 0, state_bytes, 0x00020000);
+        };
+        // One poll slot of NK granules per polling lane.  Loads are unconditional (straight-line code):
+        // a lane's slots that fall outside the image or beyond the region read some other in-range
+        // granule or, out of range, 0 from the bounds-checked buffer — they are never examined.
+        u2v va[NK];
+        auto issue = [&](__amdgpu_buffer_rsrc_t rs, int soff) __attribute__((always_inline)) {
+#pragma unroll
+            for (int kk = 0; kk < NK; ++kk) va[kk] = ld_granule(rs, (int)((btab[kk] >> 15) << 3), soff);
+        };
+        int t = t_first, c = 0;
+        bool fresh = true;             // first step of the job: its input has been there since before the launch
+        bool polled = false;           // the poll of the current step is already in flight
 #pragma unroll 1
-        for (int t = t_first; t < t_first + t_count; ++t) {
-            const int state_bytes = (int)(8u * n * (unsigned)I.C);
-            const __amdgpu_buffer_rsrc_t src =
-                __builtin_amdgcn_make_buffer_rsrc((void *)((t & 1) ? I.xb : I.xa), 0, state_bytes, 0x00020000);
-            const __amdgpu_buffer_rsrc_t dst =
-                __builtin_amdgcn_make_buffer_rsrc((void *)((t & 1) ? I.xa : I.xb), 0, state_bytes, 0x00020000);
-            const int ch_bytes = (int)(8u * n);
+        for (int k = 0; k < n_steps; ++k) {
+            const __amdgpu_buffer_rsrc_t src = state_rsrc(t), dst = state_rsrc(t + 1);
             const bool last = (t + 1 == t_total);
             const unsigned want = (unsigned)(t + 1);
-            // diagnostic time stamps (100 MHz wall clock) of round 0 for two workgroups
-            long long *pslot = nullptr;
-            if (prof && round == 0 && tid == 0 && (blockIdx.x == 0 || blockIdx.x == gridDim.x / 2) && t - t_first < 256)
-                pslot = prof + ((blockIdx.x == 0 ? 0 : 256) + (t - t_first)) * 4;
+            float *xsb = xs + (k & 1) * (LH * LW);
+            long long *pslot = nullptr;   // diagnostic time stamps of round 0 for two workgroups
+            if (prof && round == 0 && tid == 0 && (blockIdx.x == 0 || blockIdx.x == gridDim.x / 2) && k < 256)
+                pslot = prof + ((blockIdx.x == 0 ? 0 : 256) + k) * 4;
             if (pslot) pslot[0] = wall_clock64();
-#pragma unroll 1
-            for (int c0 = 0; c0 < I.C; c0 += kChs) {
-                const int nch = min(kChs, I.C - c0);
-                // ---- poll + stage x_t of the tile and its halo ----
-                // Two poll slots, each NK granules x 2 channels per lane.  All tiles of an image run in
-                // lock step, so nothing is ready right after our own stores: the first poll is delayed
-                // by `poll_delay` so that it samples memory just after the neighbours' stores have
-                // landed, the second follows `poll_stagger` later, and each slot re-polls as soon as it
-                // has been examined (a lone slot quantises the wait to whole ~0.85 us round trips;
-                // polling early is worse than useless — delay 0 measured 4.3 us per sweep against 2.7
-                // at delay 10-12: the early loads pull stale lines that the stores must then displace).
-                {
-                    const int n_pairs = (nch + 1) >> 1;
-                    unsigned pend = 0;
-                    unsigned live = 0;                                   // wave-uniform: pairs with pending lanes
-                    for (int c = 0; c < nch; ++c) pend |= vmask << (c * NK);
-                    for (int pr = 0; pr < n_pairs; ++pr)
-                        if (__builtin_amdgcn_ballot_w64(((pend >> (2 * pr * NK)) & ((1u << (2 * NK)) - 1u)) != 0)) live |= 1u << pr;
-                    int rr = 0;
-                    auto pick = [&]() {
-                        int pr = rr;
-                        while (!((live >> pr) & 1u)) pr = (pr + 1 == n_pairs) ? 0 : pr + 1;
-                        rr = (pr + 1 == n_pairs) ? 0 : pr + 1;
-                        return pr;
-                    };
-                    auto issue = [&](u2v (&v)[2 * NK], int pr) __attribute__((always_inline)) {
-#pragma unroll
-                        for (int ch = 0; ch < 2; ++ch)
-#pragma unroll
-                            for (int k = 0; k < NK; ++k)
-                                if ((pend >> ((2 * pr + ch) * NK + k)) & 1u)
-                                    v[ch * NK + k] = ld_granule(src, bgoff[k], (c0 + 2 * pr + ch) * ch_bytes);
-                    };
-                    auto consume = [&](const u2v (&v)[2 * NK], int pr) __attribute__((always_inline)) {
-#pragma unroll
-                        for (int ch = 0; ch < 2; ++ch)
-#pragma unroll
-                            for (int k = 0; k < NK; ++k) {
-                                const unsigned bit = 1u << ((2 * pr + ch) * NK + k);
-                                if ((pend & bit) && v[ch * NK + k].y == want) {
-                                    xs[blidx[k] + (2 * pr + ch) * (LH * LW)] = __uint_as_float(v[ch * NK + k].x);
-                                    pend &= ~bit;
-                                }
-                            }
-                        if (!__builtin_amdgcn_ballot_w64(((pend >> (2 * pr * NK)) & ((1u << (2 * NK)) - 1u)) != 0)) live &= ~(1u << pr);
-                    };
-                    if (live) {
-                        u2v va[2 * NK], vb[2 * NK];
-                        for (int d = 0; d < delay; ++d) __builtin_amdgcn_s_sleep(1);
-                        int pa = pick();
-                        issue(va, pa);
-                        for (int d = 0; d < poll_stagger; ++d) __builtin_amdgcn_s_sleep(1);
-                        int pb = pick();
-                        issue(vb, pb);
-                        long long t_start = 0;
-                        for (;;) {
-                            consume(va, pa);
-                            if (!live) break;
-                            pa = pick();
-                            issue(va, pa);
-                            consume(vb, pb);
-                            if (!live) break;
-                            pb = pick();
-                            issue(vb, pb);
-                            const long long now = wall_clock64();
-                            if (t_start == 0) t_start = now;
-                            else if (now - t_start > timeout_ticks ||
-                                     __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
-                                if (lane == 0 && atomicCAS(err, 0u, 1u) == 0u) {
-                                    err[1] = (unsigned)je.x;
-                                    err[2] = (unsigned)t;
-                                    err[3] = blockIdx.x;
-                                }
-                                *abort_flag = 1;
-                                break;
-                            }
-                        }
-                    }
-                }
-                __syncthreads();
-                if (*abort_flag) return;
-                if (pslot && c0 == 0) pslot[1] = wall_clock64();
 
-                // ---- channels of the chunk: partial sums -> LDS -> fp64 combine -> store ----
-#pragma unroll 1
-                for (int c = 0; c < nch; ++c) {
-                    const float *xrow = xs + (c * LH + ly + H) * LW + lx + HP;
-                    double acc[4];
-                    switch (qi) {
-                        case 0: partial_sums<R, 0>(wr, xrow, acc); break;
-                        case 1: partial_sums<R, 1 % Q>(wr, xrow, acc); break;
-                        case 2: partial_sums<R, 2 % Q>(wr, xrow, acc); break;
-                        case 3: partial_sums<R, 3 % Q>(wr, xrow, acc); break;
-                        case 4: partial_sums<R, 4 % Q>(wr, xrow, acc); break;
-                        case 5: partial_sums<R, 5 % Q>(wr, xrow, acc); break;
-                        case 6: partial_sums<R, 6 % Q>(wr, xrow, acc); break;
-                        default: partial_sums<R, 7 % Q>(wr, xrow, acc); break;
-                    }
-                    double *pw = part + (c & 1) * (kWaves * 256) + wv * 256 + lane;
+            // ---- [A] poll + stage x_t[c] of the tile and its halo (polling waves) ----
+            // All tiles of an image run in lock step, so nothing is ready right after our own stores:
+            // an unprefetched poll (C = 1) goes out `poll_delay` behind them so that it samples memory
+            // just after the neighbours' stores have landed.  Polling early is worse than useless
+            // (delay 0: 4.3 us per sweep, delay 20: 2.6 — early loads pull stale lines that the
+            // stores must then displace, and a miss costs a whole ~0.85 us round trip).
+            if (poller) {
+                unsigned pend = vmask;
+                if (!polled) {
+                    if (!fresh) nap(poll_delay);
+                    issue(src, c * ch_bytes);
+                }
+                long long t_start = 0;
+                for (;;) {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) pw[j * 64] = acc[j];
-                    __syncthreads();
-                    if (pslot && c0 == 0 && c == 0) pslot[2] = wall_clock64();
-#pragma unroll
-                    for (int i = tid; i < G::SLABS * 256; i += 512) {
-                        const int s2 = i >> 8, j = (i >> 6) & 3, l2 = i & 63;
-                        const int py = (s2 / G::C::SL_X) * kSlabH + (l2 >> 3);
-                        const int px = (s2 % G::C::SL_X) * kSlabW + (l2 & 7) * 4 + j;
-                        const double *pr = part + (c & 1) * (kWaves * 256) + (s2 * Q) * 256 + j * 64 + l2;
-                        double sum = (double)xs[(c * LH + py + H) * LW + px + HP];
-#pragma unroll
-                        for (int q = 0; q < Q; ++q) sum += pr[q * 256];
-                        const float res = (float)(sum * invd[i]);
-                        const int yy = ty0 + py, xx = tx0 + px;
-                        if (yy < h && xx < w) {
-                            if (last) ((gf_t)I.out)[(unsigned)(c0 + c) * n + (unsigned)(yy * w + xx)] = res;
-                            else st_granule(dst, (yy * w + xx) * 8, (c0 + c) * ch_bytes, want + 1, res);
+                    for (int kk = 0; kk < NK; ++kk)
+                        if (((pend >> kk) & 1u) && va[kk].y == want) {
+                            xsb[btab[kk] & 0xfff] = __uint_as_float(va[kk].x);
+                            pend &= ~(1u << kk);
                         }
+                    if (!__builtin_amdgcn_ballot_w64(pend != 0)) break;
+                    issue(src, c * ch_bytes);
+                    const long long now = wall_clock64();
+                    if (t_start == 0) t_start = now;
+                    else if (now - t_start > timeout_ticks ||
+                             __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+                        if (lane == 0 && atomicCAS(err, 0u, 1u) == 0u) {
+                            err[1] = (unsigned)je.x;
+                            err[2] = (unsigned)t;
+                            err[3] = blockIdx.x;
+                        }
+                        *abort_flag = 1;
+                        break;
                     }
                 }
-                __syncthreads();   // xs is rewritten by the next chunk / sweep
             }
+            __syncthreads();
+            if (*abort_flag) return;
+            if (pslot) pslot[1] = wall_clock64();
+
+            // ---- [B] prefetch: the next step's poll is issued as soon as its input can be there ----
+            // chain cn was stored C-1 steps ago: long ago for C >= 3 (issue before the arithmetic), at the
+            // end of the previous step for C = 2 (issue behind the arithmetic, ~1 us after the stores)
+            int tn = t, cn = c + 1;
+            if (cn == C) {
+                cn = 0;
+                ++tn;
+            }
+            polled = C >= 2 && k + 1 < n_steps;
+            if (polled && poller && C >= 3) issue(state_rsrc(tn), cn * ch_bytes);
+
+            // ---- [C] partial sums -> LDS -> fp64 combine -> store ----
+            {
+                const float *xrow = xsb + (ly + H) * LW + lx + HP;
+                double acc[4];
+                switch (qi) {
+                    case 0: partial_sums<R, 0>(wr, xrow, acc); break;
+                    case 1: partial_sums<R, 1 % Q>(wr, xrow, acc); break;
+                    case 2: partial_sums<R, 2 % Q>(wr, xrow, acc); break;
+                    case 3: partial_sums<R, 3 % Q>(wr, xrow, acc); break;
+                    case 4: partial_sums<R, 4 % Q>(wr, xrow, acc); break;
+                    case 5: partial_sums<R, 5 % Q>(wr, xrow, acc); break;
+                    case 6: partial_sums<R, 6 % Q>(wr, xrow, acc); break;
+                    default: partial_sums<R, 7 % Q>(wr, xrow, acc); break;
+                }
+                double *pw = part + (k & 1) * (kWaves * 256) + wv * 256 + lane;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) pw[j * 64] = acc[j];
+                if (polled && poller && C == 2) issue(state_rsrc(tn), cn * ch_bytes);
+                __syncthreads();
+                if (pslot) pslot[2] = wall_clock64();
+#pragma unroll
+                for (int i = tid; i < (poller ? 0 : G::SLABS * 256); i += 256) {
+                    const int s2 = i >> 8, j = (i >> 6) & 3, l2 = i & 63;
+                    const int py = (s2 / G::C::SL_X) * kSlabH + (l2 >> 3);
+                    const int px = (s2 % G::C::SL_X) * kSlabW + (l2 & 7) * 4 + j;
+                    const double *pr = part + (k & 1) * (kWaves * 256) + (s2 * Q) * 256 + j * 64 + l2;
+                    double sum = (double)xsb[(py + H) * LW + px + HP];
+#pragma unroll
+                    for (int q = 0; q < Q; ++q) sum += pr[q * 256];
+                    const float res = (float)(sum * invd[i]);
+                    const int yy = ty0 + py, xx = tx0 + px;
+                    if (yy < h && xx < w) {
+                        if (last) ((gf_t)I.out)[(unsigned)c * n + (unsigned)(yy * w + xx)] = res;
+                        else st_granule(dst, (yy * w + xx) * 8, c * ch_bytes, want + 1, res);
+                    }
+                }
+            }
+            fresh = false;
+            // C = 1: the next poll is timed from our own stores, so every wave has to start its delay
+            // behind them (the waves that do not combine would otherwise poll ~0.2 us early)
+            if (C == 1) __syncthreads();
             if (pslot) pslot[3] = wall_clock64();
+            t = tn;
+            c = cn;
         }
     }
 }

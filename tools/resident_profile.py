@@ -25,5 +25,12 @@ p = wk.read_profile().astype(np.float64) * 0.01      # us
 for g in range(2):
     q = p[g, 8:250]
     tot = np.diff(q[:, 0])
-    print(" ".join(sys.argv[1:]), "wg %d: sweep period %.2f us (min %.2f max %.2f); poll+stage %.2f, first partials %.2f, reduce+store %.2f" %
+    print(" ".join(sys.argv[1:]), "wg %d: step period %.2f us (min %.2f max %.2f); poll+stage %.2f, first partials %.2f, reduce+store %.2f" %
           (g, tot.mean(), tot.min(), tot.max(), (q[:, 1] - q[:, 0]).mean(), (q[:, 2] - q[:, 1]).mean(), (q[:, 3] - q[:, 2]).mean()))
+
+import os
+if os.environ.get("RAW"):
+    q = p[0, 100:124]
+    base = q[0, 0]
+    for row in q:
+        print("  start %7.2f  staged +%5.2f  partials +%5.2f  stored +%5.2f" % (row[0] - base, row[1] - row[0], row[2] - row[1], row[3] - row[2]))
