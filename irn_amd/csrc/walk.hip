@@ -499,7 +499,9 @@ extern "C" int irn_walk_create(int radius, irn_walk_ctx **ctx_out) {
     irn_walk_ctx *c = new irn_walk_ctx();
     c->radius = radius;
     c->tab = tab;
-    c->variant = (radius == 5 || radius == 10) ? 1 : 0;
+    // radius 5 / 10: weights-stationary persistent walk (falls back to the streaming sweeps per batch
+    // when an image does not fit one round); other radii: generic table-driven sweep
+    c->variant = (radius == 5 || radius == 10) ? 2 : 0;
     *ctx_out = c;
     return IRN_OK;
 }
@@ -771,6 +773,10 @@ extern "C" int irn_walk_run(irn_walk_ctx *ctx, const float *const *edge_dev, con
     const int slot = ctx->stage_next;
     ctx->stage_next ^= 1;
     IRN_HIP_TRY(hipEventSynchronize(ctx->stage_ev[slot]));   // previous upload from this slot has landed
+    if (ctx->res_err_host && ctx->res_err_host[0] != 0) {    // an earlier resident launch gave up: do not go on silently
+        const int rc_prev = irn_walk_check(ctx);
+        if (rc_prev) return rc_prev;
+    }
     WalkImg *imgs = (WalkImg *)ctx->stage[slot];
     AffJob *jobs = (AffJob *)(imgs + n);
     char *ws = (char *)workspace_dev;

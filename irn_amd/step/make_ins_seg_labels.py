@@ -37,6 +37,7 @@ def instance_labels(walker, edge, dp, cams, keys, size, beta, exp_times, bg_thre
     rw = walker([edge], [cams], beta=beta, exp_times=exp_times, inst_maps=[cmap], k_inst=[k])[0]
     ep = ops.label_epilogue([rw], [size], bg_thres, want_labels=False, want_argmax=True, want_rw_up=True)
     class_ids = np.repeat(np.asarray(keys.cpu()), k)
+    walker.check()                          # the persistent walk reports a stuck tile instead of hanging
     return ops.detect_instance(ep["rw_up"][0], ep["argmax"][0], class_ids, n_cls * k,
                                max_fragment_size=size[0] * size[1] * 0.01)
 

@@ -31,8 +31,10 @@ def _flush(walker, pend, args):
                  beta=float(args.beta), exp_times=int(args.exp_times))
     out = ops.label_epilogue(rws, [p["size"] for p in pend], float(args.sem_seg_bg_thres),
                              keys=[p["keys"] for p in pend])
-    for p, lab in zip(pend, out["labels"]):
-        Image.fromarray(lab.cpu().numpy()).save(os.path.join(args.sem_seg_out_dir, p["name"] + ".png"))
+    labels = [lab.cpu().numpy() for lab in out["labels"]]
+    walker.check()                          # the persistent walk reports a stuck tile instead of hanging
+    for p, lab in zip(pend, labels):
+        Image.fromarray(lab).save(os.path.join(args.sem_seg_out_dir, p["name"] + ".png"))
     pend.clear()
 
 
