@@ -2,7 +2,8 @@
 import sys
 import numpy as np
 import torch
-sys.path.insert(0, ".")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from irn_amd import synth
 from irn_amd.misc import indexing
 
