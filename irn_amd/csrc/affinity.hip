@@ -16,8 +16,8 @@ namespace irn {
 
 namespace {
 
-constexpr int AFF_TH = 8;    // source rows per workgroup
-constexpr int AFF_TW = 32;   // source cols per workgroup (one wave covers two rows)
+constexpr int AFF_TH = kAffTileH;   // source rows per workgroup
+constexpr int AFF_TW = kAffTileW;   // source cols per workgroup (one wave covers two rows)
 
 __device__ __forceinline__ float pow_beta(float a, float beta, int beta_int) {
     // torch.pow(fp32, beta) is a <=1-ulp powf; the fp64 power rounded once to fp32 is the
@@ -38,9 +38,8 @@ __device__ __forceinline__ float pow_beta(float a, float beta, int beta_int) {
 
 template <bool POW>
 __global__ __launch_bounds__(256) void affinity_kernel(const AffJob *__restrict__ jobs,
-                                                       const int *__restrict__ dir_start,
-                                                       const int *__restrict__ cell_dy,
-                                                       const int *__restrict__ cell_dx, int n_dirs,
+                                                       const int *__restrict__ dir_start8,
+                                                       const int *__restrict__ cell_off8, int n_dirs,
                                                        int radius, float beta, int beta_int) {
     extern __shared__ float tile[];
     const AffJob J = jobs[blockIdx.y];
@@ -72,10 +71,22 @@ __global__ __launch_bounds__(256) void affinity_kernel(const AffJob *__restrict_
     const int base = ly * LW + lx + halo;
     float *out = J.out + (long)sy * J.sw + sx;
 
+    // Eight path cells per scalar load of their (wave-uniform) LDS offsets.  The first version
+    // fetched dy and dx of one cell at a time: two scalar loads, a multiply and a wait that also
+    // drained the LDS reads per cell — latency-bound, ~10x off the LDS/VALU bound of the kernel.
+    const float *tb = tile + base;
     for (int d = 0; d < n_dirs; ++d) {
-        const int k0 = dir_start[d], k1 = dir_start[d + 1];
-        float m = -INFINITY;
-        for (int k = k0; k < k1; ++k) m = fmaxf(m, tile[base + cell_dy[k] * LW + cell_dx[k]]);
+        const int k0 = dir_start8[d], k1 = dir_start8[d + 1];
+        float m0 = -INFINITY, m1 = -INFINITY;
+        for (int k = k0; k < k1; k += 8) {
+            const int4 oa = *reinterpret_cast<const int4 *>(cell_off8 + k);
+            const int4 ob = *reinterpret_cast<const int4 *>(cell_off8 + k + 4);
+            const float a0 = tb[oa.x], a1 = tb[oa.y], a2 = tb[oa.z], a3 = tb[oa.w];
+            const float b0 = tb[ob.x], b1 = tb[ob.y], b2 = tb[ob.z], b3 = tb[ob.w];
+            m0 = fmaxf(m0, fmaxf(fmaxf(a0, a1), fmaxf(a2, a3)));
+            m1 = fmaxf(m1, fmaxf(fmaxf(b0, b1), fmaxf(b2, b3)));
+        }
+        const float m = fmaxf(m0, m1);
         float a = 1.0f - m;
         if (POW) a = pow_beta(a, beta, beta_int);
         if (valid) out[(long)d * J.plane_stride] = a;
@@ -93,11 +104,11 @@ int launch_affinity(const AffJob *jobs_dev, int n_jobs, int max_sh, int max_sw, 
     int beta_int = 0;
     if (with_pow && beta == (float)(int)beta && beta >= 1.0f && beta <= 64.0f) beta_int = (int)beta;
     if (with_pow)
-        hipLaunchKernelGGL(affinity_kernel<true>, grid, dim3(256), lds, stream, jobs_dev, tab.dir_start,
-                           tab.cell_dy, tab.cell_dx, tab.n_dirs, tab.radius, beta, beta_int);
+        hipLaunchKernelGGL(affinity_kernel<true>, grid, dim3(256), lds, stream, jobs_dev, tab.dir_start8,
+                           tab.cell_off8, tab.n_dirs, tab.radius, beta, beta_int);
     else
-        hipLaunchKernelGGL(affinity_kernel<false>, grid, dim3(256), lds, stream, jobs_dev, tab.dir_start,
-                           tab.cell_dy, tab.cell_dx, tab.n_dirs, tab.radius, beta, beta_int);
+        hipLaunchKernelGGL(affinity_kernel<false>, grid, dim3(256), lds, stream, jobs_dev, tab.dir_start8,
+                           tab.cell_off8, tab.n_dirs, tab.radius, beta, beta_int);
     IRN_LAUNCH_CHECK("affinity_kernel");
     return IRN_OK;
 }

@@ -10,6 +10,8 @@ struct DeviceTable {
     int *dir_dy = nullptr, *dir_dx = nullptr;   // [n_dirs]
     int *dir_start = nullptr;                   // [n_dirs+1]
     int *cell_dy = nullptr, *cell_dx = nullptr; // [n_cells]
+    int *cell_off8 = nullptr;                   // LDS word offset of every path cell in the affinity kernel's edge
+    int *dir_start8 = nullptr;                  // tile, each path padded to a multiple of 8 cells; [n_dirs+1]
     int *plane_tab = nullptr;                   // [radius][2*radius-1]: index of direction (dy, dx=ix-(radius-1))
                                                 // in this table's order, or ~(nearest in-set index of the row)
     PathTable host;
@@ -24,6 +26,9 @@ int scratch_upload(const void *host, size_t bytes, void **dev_out, hipStream_t s
 // Record, on `stream`, that the kernels reading the scratch have been enqueued; the next
 // scratch_upload waits for them before it overwrites the buffers.
 int scratch_release(hipStream_t stream);
+
+// tile of the affinity kernel: source rows x cols per workgroup (one wave covers two rows)
+constexpr int kAffTileH = 8, kAffTileW = 32;
 
 // One grid handed to the affinity kernel.
 struct AffJob {

@@ -50,6 +50,21 @@ int get_device_table(int radius, int order, const DeviceTable **out) {
     if (!rc) rc = upload(t->host.start, &t->dir_start);
     if (!rc) rc = upload(t->host.cy, &t->cell_dy);
     if (!rc) rc = upload(t->host.cx, &t->cell_dx);
+    // Affinity kernel: LDS offsets of the path cells inside its edge tile (row length depends on the
+    // radius only), every path padded to a multiple of 8 by repeating its last cell (max is
+    // idempotent) so that the kernel fetches eight offsets per scalar load.
+    {
+        const int lw = kAffTileW + 2 * (radius - 1);
+        std::vector<int> off8, start8(1, 0);
+        for (int d = 0; d < t->n_dirs; ++d) {
+            const int k0 = t->host.start[d], k1 = t->host.start[d + 1];
+            for (int k = k0; k < k1; ++k) off8.push_back(t->host.cy[k] * lw + t->host.cx[k]);
+            while (off8.size() % 8) off8.push_back(off8.back());
+            start8.push_back((int)off8.size());
+        }
+        if (!rc) rc = upload(off8, &t->cell_off8);
+        if (!rc) rc = upload(start8, &t->dir_start8);
+    }
     // plane_tab[dy][ix], dx = ix - (radius-1): index of direction (dy,dx) if it is in the set; otherwise
     // ~index of the nearest in-set direction of the same row (the sweep kernel loads that plane — hot in
     // cache — and multiplies the weight by zero, instead of branching around the slot).

@@ -489,10 +489,20 @@ int resident_configure(irn_walk_ctx *ctx) {
         tiles[i] = cdiv(ctx->h[i], th) * cdiv(ctx->w[i], tw);
         if (tiles[i] > n_wg) return IRN_OK;
     }
-    // first-fit in input order; slots of an image are consecutive
+    // First-fit over the images in descending cost order (channels = steps per sweep, then tiles);
+    // slots of an image are consecutive.  Workgroups run their rounds back to back without a grid
+    // barrier, so what matters is that the tile groups sharing a round carry similar work (equal
+    // channel counts) and that the light images form the tail.  Results do not depend on the order.
+    std::vector<int> order(n);
+    for (int i = 0; i < n; ++i) order[i] = i;
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
+        if (ctx->c[a] != ctx->c[b]) return ctx->c[a] > ctx->c[b];
+        return tiles[a] > tiles[b];
+    });
     std::vector<std::vector<int4>> rounds;
     std::vector<int> used;
-    for (int i = 0; i < n; ++i) {
+    for (int oi = 0; oi < n; ++oi) {
+        const int i = order[oi];
         size_t r = 0;
         for (; r < rounds.size(); ++r)
             if (used[r] + tiles[i] <= n_wg) break;
