@@ -48,6 +48,9 @@ _SIGS = {
     "irn_cluster_centroids": (i32, [vp, vp, i32, i32, f32, vp, C.POINTER(i32), vp, vp]),
     "irn_ccl_scratch_bytes": (sz, [i32, i32, i32]),
     "irn_label4": (i32, [vp, i32, i32, i32, vp, vp, vp, vp]),
+    "irn_detect_scratch_bytes": (sz, [i32, i32, i32]),
+    "irn_detect_instance_count": (i32, [vp, vp, i32, i32, i32, C.POINTER(i32), vp, vp]),
+    "irn_detect_instance_emit": (i32, [i32, i32, i32, i32, C.c_double, vp, vp, vp, vp, vp]),
 }
 
 EXPORTS = tuple(_SIGS)

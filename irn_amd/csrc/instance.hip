@@ -199,6 +199,126 @@ __global__ __launch_bounds__(256) void remap_kernel(const int32_t *__restrict__ 
     cluster_map[p] = newid[picked[p]];
 }
 
+// ---------------------------------------------------------------------------------------------
+// detect_instance (reference step/make_ins_seg_labels.py:82-105) on the device.
+//
+// The reference labels the 4-connected components of every channel's mask separately; the masks are
+// the one-hot planes of ONE argmax map (:145-147), so they are disjoint and all components come
+// out of a single labelling pass over the class map (neighbours join when their classes agree).
+// Detections are ordered like the reference's: channel ascending, then skimage's label order =
+// raster order of each component's first pixel = of its union-find root.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void det_init_kernel(const int32_t *__restrict__ cls, int *__restrict__ parent, int npx) {
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p < npx) parent[p] = cls[p] > 0 ? p : -1;
+}
+
+__global__ __launch_bounds__(256) void det_merge_kernel(const int32_t *__restrict__ cls, int *__restrict__ parent, int h, int w) {
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= h * w) return;
+    const int c = cls[p];
+    if (c <= 0) return;
+    const int y = p / w, x = p - y * w;
+    if (x > 0 && cls[p - 1] == c) uf_union(parent, p, p - 1);
+    if (y > 0 && cls[p - w] == c) uf_union(parent, p, p - w);
+}
+
+// One workgroup per channel: rank[root] = 1 + #roots of this channel before it (raster order);
+// counts[channel] = #components.
+__global__ __launch_bounds__(1024) void det_rank_kernel(const int32_t *__restrict__ cls, const int *__restrict__ parent,
+                                                        int *__restrict__ rank, int *__restrict__ counts, int npx) {
+    __shared__ int sums[1024];
+    const int want = blockIdx.x + 1;
+    const int chunk = (npx + 1023) / 1024;
+    const int lo = min(npx, (int)threadIdx.x * chunk), hi = min(npx, lo + chunk);
+    int cnt = 0;
+    for (int p = lo; p < hi; ++p) cnt += (parent[p] == p && cls[p] == want);
+    sums[threadIdx.x] = cnt;
+    __syncthreads();
+    for (int s = 1; s < 1024; s <<= 1) {
+        const int v = threadIdx.x >= s ? sums[threadIdx.x - s] : 0;
+        __syncthreads();
+        sums[threadIdx.x] += v;
+        __syncthreads();
+    }
+    int run = sums[threadIdx.x] - cnt;
+    for (int p = lo; p < hi; ++p)
+        if (parent[p] == p && cls[p] == want) rank[p] = ++run;
+    if (threadIdx.x == 1023) counts[blockIdx.x] = sums[1023];
+}
+
+// exclusive scan of the per-channel counts (n_ch <= 65535): offsets[0..n_ch], zeroes the statistics
+__global__ __launch_bounds__(1024) void det_offsets_kernel(const int *__restrict__ counts, int *__restrict__ offsets, int n_ch,
+                                                           int *__restrict__ area, int *__restrict__ score_bits, int cap) {
+    __shared__ int sums[1024];
+    const int chunk = (n_ch + 1023) / 1024;
+    const int lo = min(n_ch, (int)threadIdx.x * chunk), hi = min(n_ch, lo + chunk);
+    int cnt = 0;
+    for (int c = lo; c < hi; ++c) cnt += counts[c];
+    sums[threadIdx.x] = cnt;
+    __syncthreads();
+    for (int s = 1; s < 1024; s <<= 1) {
+        const int v = threadIdx.x >= s ? sums[threadIdx.x - s] : 0;
+        __syncthreads();
+        sums[threadIdx.x] += v;
+        __syncthreads();
+    }
+    int run = sums[threadIdx.x] - cnt;
+    for (int c = lo; c < hi; ++c) {
+        offsets[c] = run;
+        run += counts[c];
+    }
+    if (threadIdx.x == 1023) offsets[n_ch] = sums[1023];
+    const int total = sums[1023];
+    for (int i = threadIdx.x; i < min(total, cap); i += 1024) {
+        area[i] = 0;
+        score_bits[i] = 0;
+    }
+}
+
+// det[p] = index of the detection pixel p belongs to (-1 for background); area and max score per
+// detection.  Scores are compared as int bit patterns: the reference takes max(score * mask), which
+// is >= 0 whatever the scores are, and so is a maximum that starts from +0.
+__global__ __launch_bounds__(256) void det_stats_kernel(const int32_t *__restrict__ cls, const int *__restrict__ parent,
+                                                        const int *__restrict__ rank, const int *__restrict__ offsets,
+                                                        const float *__restrict__ rw_up, int *__restrict__ det,
+                                                        int *__restrict__ area, int *__restrict__ score_bits, int npx) {
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= npx) return;
+    const int c = cls[p];
+    if (c <= 0) {
+        det[p] = -1;
+        return;
+    }
+    const int d = offsets[c - 1] + rank[parent[p]] - 1;
+    det[p] = d;
+    atomicAdd(area + d, 1);
+    const float sc = rw_up[(long)(c - 1) * npx + p];
+    if (sc > 0.f) atomicMax(score_bits + d, __float_as_int(sc));
+}
+
+__global__ __launch_bounds__(256) void det_emit_kernel(const int *__restrict__ det, uint8_t *__restrict__ mask, int npx) {
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= npx) return;
+    const int d = det[p];
+    if (d >= 0) mask[(long)d * npx + p] = 1;
+}
+
+__global__ __launch_bounds__(256) void det_final_kernel(const int *__restrict__ offsets, int n_ch, const int *__restrict__ area,
+                                                        const int *__restrict__ score_bits, double min_area,
+                                                        float *__restrict__ score, int32_t *__restrict__ channel, int n_det) {
+    const int d = blockIdx.x * 256 + threadIdx.x;
+    if (d >= n_det) return;
+    score[d] = ((double)area[d] < min_area) ? 0.f : __int_as_float(score_bits[d]);
+    int lo = 0, hi = n_ch;               // channel of detection d: offsets[c] <= d < offsets[c+1]
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (offsets[mid] <= d) lo = mid;
+        else hi = mid;
+    }
+    channel[d] = lo;
+}
+
 int run_label4(const uint8_t *mask, int n, int h, int w, int32_t *labels, int32_t *n_labels, void *scratch,
                hipStream_t stream) {
     const int npx = h * w;
@@ -292,5 +412,78 @@ extern "C" int irn_cluster_centroids(const int32_t *centroids_dev, const float *
     IRN_LAUNCH_CHECK("remap_kernel");
     IRN_HIP_TRY(hipMemcpyAsync(k_out, k_dev, sizeof(int), hipMemcpyDeviceToHost, stream));
     IRN_HIP_TRY(hipStreamSynchronize(stream));
+    return IRN_OK;
+}
+
+// scratch layout of irn_detect_instance_*: [parent npx][rank npx][det npx][area npx][score_bits npx]
+//                                          [counts n_ch][offsets n_ch+1]   (all int32)
+extern "C" size_t irn_detect_scratch_bytes(int n_channels, int h, int w) {
+    if (n_channels < 1 || h < 1 || w < 1) return 0;
+    const size_t npx = (size_t)h * w;
+    return round_up(4 * npx, 256) * 5 + round_up(4 * (size_t)n_channels, 256) + round_up(4 * ((size_t)n_channels + 1), 256);
+}
+
+namespace {
+struct DetScratch {
+    int *parent, *rank, *det, *area, *score_bits, *counts, *offsets;
+};
+DetScratch det_carve(void *scratch, int n_channels, size_t npx) {
+    char *b = (char *)scratch;
+    DetScratch s;
+    const size_t a = round_up(4 * npx, 256);
+    s.parent = (int *)b;
+    s.rank = (int *)(b + a);
+    s.det = (int *)(b + 2 * a);
+    s.area = (int *)(b + 3 * a);
+    s.score_bits = (int *)(b + 4 * a);
+    s.counts = (int *)(b + 5 * a);
+    s.offsets = (int *)(b + 5 * a + round_up(4 * (size_t)n_channels, 256));
+    return s;
+}
+}  // namespace
+
+extern "C" int irn_detect_instance_count(const float *rw_up_dev, const int32_t *argmax_dev, int n_channels, int h,
+                                         int w, int *n_det_out, void *scratch_dev, void *stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!rw_up_dev || !argmax_dev || !n_det_out || !scratch_dev || n_channels < 1 || n_channels > 65535 || h < 1 || w < 1)
+        return fail(IRN_ERR_ARG, "irn_detect_instance_count: bad argument");
+    if ((long)h * w > (1L << 30)) return fail(IRN_ERR_ARG, "irn_detect_instance_count: image too large");
+    const int npx = h * w;
+    const DetScratch s = det_carve(scratch_dev, n_channels, (size_t)npx);
+    const int nb = cdiv(npx, 256);
+    hipLaunchKernelGGL(det_init_kernel, dim3(nb), dim3(256), 0, stream, argmax_dev, s.parent, npx);
+    IRN_LAUNCH_CHECK("det_init_kernel");
+    hipLaunchKernelGGL(det_merge_kernel, dim3(nb), dim3(256), 0, stream, argmax_dev, s.parent, h, w);
+    IRN_LAUNCH_CHECK("det_merge_kernel");
+    hipLaunchKernelGGL(ccl_flatten_kernel, dim3(nb), dim3(256), 0, stream, s.parent, npx, (long)npx);
+    IRN_LAUNCH_CHECK("ccl_flatten_kernel");
+    hipLaunchKernelGGL(det_rank_kernel, dim3(n_channels), dim3(1024), 0, stream, argmax_dev, s.parent, s.rank, s.counts, npx);
+    IRN_LAUNCH_CHECK("det_rank_kernel");
+    hipLaunchKernelGGL(det_offsets_kernel, dim3(1), dim3(1024), 0, stream, s.counts, s.offsets, n_channels, s.area,
+                       s.score_bits, npx);
+    IRN_LAUNCH_CHECK("det_offsets_kernel");
+    hipLaunchKernelGGL(det_stats_kernel, dim3(nb), dim3(256), 0, stream, argmax_dev, s.parent, s.rank, s.offsets, rw_up_dev,
+                       s.det, s.area, s.score_bits, npx);
+    IRN_LAUNCH_CHECK("det_stats_kernel");
+    int n_det = 0;
+    IRN_HIP_TRY(hipMemcpyAsync(&n_det, s.offsets + n_channels, sizeof(int), hipMemcpyDeviceToHost, stream));
+    IRN_HIP_TRY(hipStreamSynchronize(stream));
+    *n_det_out = n_det;
+    return IRN_OK;
+}
+
+extern "C" int irn_detect_instance_emit(int n_channels, int h, int w, int n_det, double min_area, float *score_dev,
+                                        int32_t *channel_dev, uint8_t *mask_dev, void *scratch_dev, void *stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!score_dev || !channel_dev || !mask_dev || !scratch_dev || n_channels < 1 || h < 1 || w < 1 || n_det < 1)
+        return fail(IRN_ERR_ARG, "irn_detect_instance_emit: bad argument");
+    const int npx = h * w;
+    const DetScratch s = det_carve(scratch_dev, n_channels, (size_t)npx);
+    IRN_HIP_TRY(hipMemsetAsync(mask_dev, 0, (size_t)n_det * npx, stream));
+    hipLaunchKernelGGL(det_emit_kernel, dim3(cdiv(npx, 256)), dim3(256), 0, stream, s.det, mask_dev, npx);
+    IRN_LAUNCH_CHECK("det_emit_kernel");
+    hipLaunchKernelGGL(det_final_kernel, dim3(cdiv(n_det, 256)), dim3(256), 0, stream, s.offsets, n_channels, s.area,
+                       s.score_bits, min_area, score_dev, channel_dev, n_det);
+    IRN_LAUNCH_CHECK("det_final_kernel");
     return IRN_OK;
 }

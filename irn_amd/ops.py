@@ -120,32 +120,35 @@ def detect_instance(rw_up, argmax, class_ids, n_channels, max_fragment_size=0):
     """Pixel-wise instance ids -> detections (reference step/make_ins_seg_labels.py:82-105), on GPU.
 
     rw_up: fp32 [C',H,W] normalised scores; argmax: int32 [H,W] (0 = bg, c+1 = channel c);
-    class_ids: int64 [C'] (np.repeat(keys, K)).  For every non-empty channel mask, every 4-connected
-    segment becomes a detection: score = max(rw_up[c] over the segment), or 0 when the segment has
-    fewer than max_fragment_size pixels.  Returns numpy dict {'score','mask','class'} ordered like the
-    reference (channel ascending, segment id ascending).  Raises ValueError when nothing is detected
-    (the reference crashes in np.stack([]) — SURVEY.md §3.5)."""
+    class_ids: int64 [C'] (np.repeat(keys, K)).  Every 4-connected component of every channel's
+    mask becomes a detection: score = max(rw_up[c] over the component), or 0 when it has fewer than
+    max_fragment_size pixels.  Labelling, areas, scores and the [N,H,W] masks are produced by
+    libirn_hip.so (irn_detect_instance_count / _emit): one pass over the class map, one 4-byte sync
+    for N, one transfer of the result.  Returns the reference's numpy dict {'score','mask','class'}
+    in its order (channel ascending, component ascending by first pixel).  Raises ValueError when
+    nothing is detected (the reference crashes in np.stack([]) — SURVEY.md §3.5)."""
+    _need_cuda(rw_up, "rw_up")
+    _need_cuda(argmax, "argmax")
     dev = rw_up.device
-    masks = (argmax[None] == torch.arange(1, n_channels + 1, device=dev, dtype=argmax.dtype)[:, None, None])
-    nonempty = torch.nonzero(masks.flatten(1).any(dim=1))[:, 0]
-    if nonempty.numel() == 0:
-        raise ValueError("detect_instance: no foreground pixel in any channel")
-    labels, counts = label4(masks[nonempty])
-    counts = counts.cpu().numpy()
-    scores, out_masks, classes = [], [], []
+    sc = rw_up.contiguous().float()
+    am = argmax.to(torch.int32).contiguous()
+    n_channels = int(n_channels)
+    h, w = am.shape
+    if sc.shape != (n_channels, h, w):
+        raise ValueError("rw_up must be [%d,%d,%d], got %s" % (n_channels, h, w, tuple(sc.shape)))
     class_ids = np.asarray(class_ids)
-    for j, ch in enumerate(nonempty.cpu().numpy()):
-        lab = labels[j]
-        sc = rw_up[ch]
-        for seg in range(1, int(counts[j]) + 1):
-            m = lab == seg
-            area = int(m.sum().item())
-            if area < max_fragment_size:
-                scores.append(0.0)
-            else:
-                scores.append(float(torch.max(sc * m).item()))
-            out_masks.append(m.cpu().numpy())
-            classes.append(class_ids[ch])
-    return {"score": np.asarray(scores, np.float32),
-            "mask": np.stack(out_masks, 0),
-            "class": np.stack(classes, 0)}
+    scratch = torch.empty(lib.irn_detect_scratch_bytes(n_channels, h, w), dtype=torch.uint8, device=dev)
+    n = C.c_int()
+    with torch.cuda.device(dev):
+        check(lib.irn_detect_instance_count(sc.data_ptr(), am.data_ptr(), n_channels, h, w, C.byref(n),
+                                            scratch.data_ptr(), _stream()))
+        if n.value == 0:
+            raise ValueError("detect_instance: no foreground pixel in any channel")
+        score = torch.empty(n.value, dtype=torch.float32, device=dev)
+        chan = torch.empty(n.value, dtype=torch.int32, device=dev)
+        mask = torch.empty((n.value, h, w), dtype=torch.uint8, device=dev)
+        check(lib.irn_detect_instance_emit(n_channels, h, w, n.value, float(max_fragment_size), score.data_ptr(),
+                                           chan.data_ptr(), mask.data_ptr(), scratch.data_ptr(), _stream()))
+    return {"score": score.cpu().numpy(),
+            "mask": mask.cpu().numpy().astype(bool),
+            "class": class_ids[chan.cpu().numpy()]}

@@ -117,3 +117,31 @@ def test_instance_labels_end_to_end_vs_reference(golden, name):
     assert np.array_equal(det["class"], ins[name + "_det_class"])
     assert np.abs(det["score"] - ins[name + "_det_score"]).max() <= 1e-4
     walker.close()
+
+
+def test_detect_instance_on_device_vs_oracle_random_maps():
+    """irn_detect_instance_* against the line-by-line restatement of step/make_ins_seg_labels.py:82-105
+    on random class maps (many small components, empty channels, area filter on and off)."""
+    from irn_amd import ops
+    rng = np.random.RandomState(5)
+    for (h, w, c, p_bg, thr) in ((37, 41, 5, 0.4, 0.0), (64, 80, 12, 0.2, 6.5), (128, 128, 3, 0.7, 163.84),
+                                 (16, 16, 2, 0.0, 0.0), (33, 9, 40, 0.5, 2.0)):
+        blocks = rng.randint(0, c + 1, size=((h + 3) // 4, (w + 3) // 4))
+        blocks[:, 0] = np.where(blocks[:, 0] == 2, 0, blocks[:, 0])           # make channel 1 rare / empty at times
+        cls = np.kron(blocks, np.ones((4, 4), int))[:h, :w]
+        cls[rng.rand(h, w) < p_bg] = 0
+        score = rng.rand(c, h, w).astype(np.float32)
+        class_ids = np.repeat(np.arange(100, 100 + (c + 1) // 2), 2)[:c]
+        one_hot = np.stack([cls == k + 1 for k in range(c)])
+        if not one_hot.any():
+            continue
+        ref = O.detect_instance(score, one_hot, class_ids, max_fragment_size=thr)
+        got = ops.detect_instance(torch.from_numpy(score).to(_dev()), torch.from_numpy(cls.astype(np.int32)).to(_dev()),
+                                  class_ids, c, max_fragment_size=thr)
+        assert got["mask"].shape == ref["mask"].shape, (h, w, c)
+        assert np.array_equal(got["mask"], ref["mask"].astype(bool))
+        assert np.array_equal(got["class"], ref["class"])
+        assert np.array_equal(got["score"], np.asarray(ref["score"], np.float32))
+    with pytest.raises(ValueError):
+        ops.detect_instance(torch.zeros((2, 8, 8), device=_dev()), torch.zeros((8, 8), dtype=torch.int32, device=_dev()),
+                            np.arange(2), 2)
