@@ -142,6 +142,18 @@ int irn_label_epilogue(int n_images, const float *const *rw_dev, const int32_t *
                        void *stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Multi-scale CAM merge  (replaces step/make_cam.py:38-52).  src[s]: dev fp32 [n_classes, hs[s], ws[s]]
+ * activation maps of scale s (original + flipped-back, net/resnet50_cam.py:66-70); keys: dev int64
+ * [n_keys] present classes (torch.nonzero(label)).  Writes
+ *   cam      dev fp32 [n_keys, ceil(out_h/4), ceil(out_w/4)]   sum over scales of bilinear resizes
+ *   high_res dev fp32 [n_keys, out_h, out_w]                   same at 16*ceil(./16), cropped
+ * each channel divided by (its maximum + 1e-5).  scratch: 8 * n_keys bytes.  At most 8 scales.
+ * ------------------------------------------------------------------------------------------- */
+int irn_cam_merge(int n_scales, const float *const *src_dev, const int32_t *hs, const int32_t *ws, int n_classes,
+                  const int64_t *keys_dev, int n_keys, int out_h, int out_w, float *cam_dev, float *high_res_dev,
+                  void *scratch_dev, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Instance front-end
  *   irn_find_centroids   replaces step/make_ins_seg_labels.py:18-56
  *       dp dev [2,h,w] -> centroids dev int32 [2,h,w]; float32 state, float64 increment in the

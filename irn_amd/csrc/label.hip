@@ -17,6 +17,13 @@
 // 2.7 GB streamed by the walk — not a bottleneck.
 #include "kernels.hpp"
 
+// Every rounding in this file is part of the contract (labels and CAMs must reproduce ATen's values).
+// HIP's __fmul_rn / __fsub_rn are inline `x * y` / `x - y` compiled under the HEADER's contraction
+// mode, so after inlining scale * (dst + 0.5) - 0.5 still becomes an fma — invisible for the dyadic
+// x4 scale of the label epilogue, a few ulp off for the arbitrary scales of the CAM merge.  Hence:
+// plain operators under this pragma for every separately rounded step, fmaf where ATen fuses.
+#pragma clang fp contract(off)
+
 namespace irn {
 
 struct LabelJob {
@@ -46,22 +53,25 @@ struct Taps {
 
 __device__ __forceinline__ Taps taps_x4(int dst, int n_in) {
     // area_pixel_compute_source_index(scale = 1/4, align_corners = false), clamped at 0
-    float src = __fsub_rn(__fmul_rn(__fadd_rn((float)dst, 0.5f), 0.25f), 0.5f);
+    float src = ((float)dst + 0.5f) * 0.25f;
+    src = src - 0.5f;
     src = src < 0.f ? 0.f : src;
     Taps t;
     t.i0 = min((int)src, n_in - 1);
     t.i1 = min(t.i0 + 1, n_in - 1);
-    t.l1 = __fsub_rn(src, (float)t.i0);
-    t.l0 = __fsub_rn(1.0f, t.l1);
+    t.l1 = src - (float)t.i0;
+    t.l0 = 1.0f - t.l1;
     return t;
 }
 
 __device__ __forceinline__ float bilerp(const float *__restrict__ plane, int w, const Taps &ty, const Taps &tx) {
     const float v00 = plane[ty.i0 * w + tx.i0], v01 = plane[ty.i0 * w + tx.i1];
     const float v10 = plane[ty.i1 * w + tx.i0], v11 = plane[ty.i1 * w + tx.i1];
-    const float top = __fmaf_rn(v00, tx.l0, __fmul_rn(v01, tx.l1));
-    const float bot = __fmaf_rn(v10, tx.l0, __fmul_rn(v11, tx.l1));
-    return __fmaf_rn(ty.l0, top, __fmul_rn(ty.l1, bot));
+    const float p01 = v01 * tx.l1, p11 = v11 * tx.l1;
+    const float top = __builtin_fmaf(v00, tx.l0, p01);
+    const float bot = __builtin_fmaf(v10, tx.l0, p11);
+    const float pb = ty.l1 * bot;
+    return __builtin_fmaf(ty.l0, top, pb);
 }
 
 __global__ __launch_bounds__(256) void upsample_max_kernel(const LabelJob *__restrict__ jobs) {
@@ -93,7 +103,7 @@ __global__ __launch_bounds__(256) void label_argmax_kernel(const LabelJob *__res
         float best = bg;
         int idx = 0;
         for (int c = 0; c < J.c; ++c) {
-            const float v = __fdiv_rn(bilerp(J.rw + (long)c * J.h * J.w, J.w, ty, tx), gmax);
+            const float v = bilerp(J.rw + (long)c * J.h * J.w, J.w, ty, tx) / gmax;
             if (J.rw_up) J.rw_up[(long)c * npx + o] = v;
             if (v > best) {
                 best = v;
@@ -103,6 +113,77 @@ __global__ __launch_bounds__(256) void label_argmax_kernel(const LabelJob *__res
         if (J.argmax) J.argmax[o] = idx;
         if (J.labels) J.labels[o] = idx == 0 ? (uint8_t)0 : (uint8_t)(J.keys[idx - 1] + 1);
     }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Multi-scale CAM merge (reference step/make_cam.py:38-52): for both target grids — the stride-4
+// grid (ceil(H/4), ceil(W/4)) and the stride-16-rounded full size cropped to (H, W) — sum over the
+// scales of F.interpolate(size=..., bilinear, align_corners=False), keep the present classes, divide
+// every channel by (its max + 1e-5).  The reference issues 2 x n_scales interpolate launches, two
+// stacks + sums, two adaptive_max_pool2d (one serial thread per channel on the GPU: 24 ms at 512^2)
+// and two divides; here: one pass that writes the sums and the channel maxima, one that divides.
+// Arithmetic = ATen's CPU kernel as restated in oracle/irn_oracle.py (resize_bilinear, cam_merge).
+// ---------------------------------------------------------------------------------------------
+constexpr int kMaxScales = 8;
+struct MergeArgs {
+    const float *src[kMaxScales];   // [n_cls, hs, ws]
+    int hs[kMaxScales], ws[kMaxScales];
+    int n_scales, n_cls, k;
+    const int64_t *keys;            // [k] present classes
+    float *lo, *hi;                 // [k, lh, lw], [k, H, W]
+    int lh, lw, uh, uw, H, W;       // (uh, uw): interpolation target of `hi` before the crop to (H, W)
+    unsigned *max_slots;            // [2k] ordered encoding: lo maxima, then hi maxima
+};
+
+__device__ __forceinline__ Taps taps_resize(int dst, int n_in, int n_out) {
+    // area_pixel_compute_source_index(scale = n_in / n_out in fp32, align_corners = false), clamped at 0
+    const float scale = (float)n_in / (float)n_out;
+    float src = scale * ((float)dst + 0.5f);
+    src = src - 0.5f;
+    src = src < 0.f ? 0.f : src;
+    Taps t;
+    t.i0 = min((int)src, n_in - 1);
+    t.i1 = min(t.i0 + 1, n_in - 1);
+    t.l1 = src - (float)t.i0;
+    t.l0 = 1.0f - t.l1;
+    return t;
+}
+
+__global__ __launch_bounds__(256) void cam_merge_sum_kernel(const MergeArgs A) {
+    const int kk = blockIdx.y;
+    const bool is_hi = blockIdx.z == 1;
+    const int oh = is_hi ? A.H : A.lh, ow = is_hi ? A.W : A.lw;      // written (cropped) extent
+    const int th = is_hi ? A.uh : A.lh, tw = is_hi ? A.uw : A.lw;    // interpolation target
+    float *out = (is_hi ? A.hi : A.lo) + (long)kk * oh * ow;
+    const int cls = (int)A.keys[kk];
+    float m = -INFINITY;
+    for (long o = (long)blockIdx.x * 256 + threadIdx.x; o < (long)oh * ow; o += (long)gridDim.x * 256) {
+        const int oy = (int)(o / ow), ox = (int)(o - (long)oy * ow);
+        float acc = 0.f;
+        for (int s = 0; s < A.n_scales; ++s) {
+            const Taps ty = taps_resize(oy, A.hs[s], th), tx = taps_resize(ox, A.ws[s], tw);
+            acc = acc + bilerp(A.src[s] + (long)cls * A.hs[s] * A.ws[s], A.ws[s], ty, tx);
+        }
+        out[o] = acc;
+        m = fmaxf(m, acc);
+    }
+    for (int s = 32; s > 0; s >>= 1) m = fmaxf(m, __shfl_xor(m, s));
+    __shared__ float wmax[4];
+    if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        m = fmaxf(fmaxf(wmax[0], wmax[1]), fmaxf(wmax[2], wmax[3]));
+        if (m > -INFINITY) atomicMax(A.max_slots + (is_hi ? A.k : 0) + kk, enc_ordered(m));
+    }
+}
+
+__global__ __launch_bounds__(256) void cam_merge_norm_kernel(const MergeArgs A) {
+    const int kk = blockIdx.y;
+    const bool is_hi = blockIdx.z == 1;
+    const long n = is_hi ? (long)A.H * A.W : (long)A.lh * A.lw;
+    float *out = (is_hi ? A.hi : A.lo) + (long)kk * n;
+    const float den = dec_ordered(A.max_slots[(is_hi ? A.k : 0) + kk]) + 1e-5f;
+    for (long o = (long)blockIdx.x * 256 + threadIdx.x; o < n; o += (long)gridDim.x * 256) out[o] = out[o] / den;
 }
 
 }  // namespace
@@ -147,4 +228,40 @@ extern "C" int irn_label_epilogue(int n_images, const float *const *rw_dev, cons
     hipLaunchKernelGGL(label_argmax_kernel, dim3(bx, n_images), dim3(256), 0, stream, jobs_dev, bg_thres);
     IRN_LAUNCH_CHECK("label_argmax_kernel");
     return scratch_release(stream);
+}
+
+extern "C" int irn_cam_merge(int n_scales, const float *const *src_dev, const int32_t *hs, const int32_t *ws, int n_classes,
+                             const int64_t *keys_dev, int n_keys, int out_h, int out_w, float *cam_dev,
+                             float *high_res_dev, void *scratch_dev, void *stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (n_scales < 1 || n_scales > kMaxScales || !src_dev || !hs || !ws || n_classes < 1 || !keys_dev || n_keys < 1 ||
+        out_h < 1 || out_w < 1 || !cam_dev || !high_res_dev || !scratch_dev)
+        return fail(IRN_ERR_ARG, "irn_cam_merge: bad argument (1..%d scales, >= 1 key)", kMaxScales);
+    MergeArgs A;
+    for (int s = 0; s < n_scales; ++s) {
+        if (!src_dev[s] || hs[s] < 1 || ws[s] < 1) return fail(IRN_ERR_ARG, "irn_cam_merge: scale %d: bad input", s);
+        A.src[s] = src_dev[s];
+        A.hs[s] = hs[s];
+        A.ws[s] = ws[s];
+    }
+    A.n_scales = n_scales;
+    A.n_cls = n_classes;
+    A.k = n_keys;
+    A.keys = keys_dev;
+    A.lo = cam_dev;
+    A.hi = high_res_dev;
+    A.H = out_h;
+    A.W = out_w;
+    A.lh = (out_h - 1) / 4 + 1;              // misc/imutils.py get_strided_size(size, 4)
+    A.lw = (out_w - 1) / 4 + 1;
+    A.uh = ((out_h - 1) / 16 + 1) * 16;      // get_strided_up_size(size, 16)
+    A.uw = ((out_w - 1) / 16 + 1) * 16;
+    A.max_slots = (unsigned *)scratch_dev;
+    IRN_HIP_TRY(hipMemsetAsync(scratch_dev, 0, sizeof(unsigned) * 2 * n_keys, stream));
+    const int bx = (int)std::min<long>(((long)out_h * out_w + 255) / 256, 256);
+    hipLaunchKernelGGL(cam_merge_sum_kernel, dim3(bx, n_keys, 2), dim3(256), 0, stream, A);
+    IRN_LAUNCH_CHECK("cam_merge_sum_kernel");
+    hipLaunchKernelGGL(cam_merge_norm_kernel, dim3(bx, n_keys, 2), dim3(256), 0, stream, A);
+    IRN_LAUNCH_CHECK("cam_merge_norm_kernel");
+    return IRN_OK;
 }

@@ -69,6 +69,32 @@ def label_epilogue(rws, out_sizes, bg_thres, keys=None, want_labels=True, want_a
     return out
 
 
+def cam_merge(outputs, size, label):
+    """Multi-scale CAM merge of reference step/make_cam.py:38-52 (irn_cam_merge).
+
+    outputs: list of GPU fp32 [n_classes, hs, ws] (one per scale); size = (H, W) of the image;
+    label: [n_classes] multi-hot image-level label.  Returns (keys int64 [K] on the same device,
+    cam fp32 [K, ceil(H/4), ceil(W/4)], high_res fp32 [K, H, W]), each channel divided by its max + 1e-5."""
+    for o in outputs:
+        _need_cuda(o, "CAM output")
+    dev = outputs[0].device
+    outs = [o.contiguous().float() for o in outputs]
+    n_cls = outs[0].shape[0]
+    H, W = int(size[0]), int(size[1])
+    keys = torch.nonzero(torch.as_tensor(label).to(dev))[:, 0].to(torch.int64).contiguous()
+    k = int(keys.numel())
+    if k == 0:
+        raise ValueError("cam_merge: the image-level label has no positive class")
+    cam = torch.empty((k, (H - 1) // 4 + 1, (W - 1) // 4 + 1), dtype=torch.float32, device=dev)
+    hi = torch.empty((k, H, W), dtype=torch.float32, device=dev)
+    scratch = torch.empty(2 * k, dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        check(lib.irn_cam_merge(len(outs), ptr_array([o.data_ptr() for o in outs]), i32_array([o.shape[1] for o in outs]),
+                                i32_array([o.shape[2] for o in outs]), n_cls, keys.data_ptr(), k, H, W, cam.data_ptr(),
+                                hi.data_ptr(), scratch.data_ptr(), _stream()))
+    return keys, cam, hi
+
+
 def find_centroids_with_refinement(displacement, iterations=300):
     """dp GPU fp32 [2,h,w] -> GPU int32 [2,h,w] (cy, cx); bit-identical to the reference's numpy
     (step/make_ins_seg_labels.py:18-56)."""

@@ -6,7 +6,7 @@ Writes args.cam_out_dir/<name>.npy = {"keys": LongTensor[K], "cam": FloatTensor[
        "high_res": float32 ndarray [K,H,W]}   (same pickle schema as step/make_cam.py:55-56)
 
 The ResNet-50 forward passes run on PyTorch-ROCm (MIOpen); the merge (step/make_cam.py:38-52) is
-torch ops on the GPU.  One process per GPU over strided shards, no communication.
+one HIP kernel pair (irn_cam_merge).  One process per GPU over strided shards, no communication.
 """
 import os
 
@@ -21,8 +21,18 @@ from . import _common
 
 
 def merge_scales(outputs, size, label):
-    """outputs: per-scale [20,hs,ws] activation maps -> (keys, cam [K,h/4,w/4], high_res [K,H,W])
-    (step/make_cam.py:32-52)."""
+    """outputs: per-scale GPU [20,hs,ws] activation maps -> (keys, cam [K,ceil(H/4),ceil(W/4)],
+    high_res [K,H,W]) — step/make_cam.py:38-52 in two launches of libirn_hip.so (irn_cam_merge).
+    GPU tensors only; `merge_scales_torch` below is the torch-op restatement the CPU tests use."""
+    from .. import ops
+    return ops.cam_merge(outputs, size, label)
+
+
+def merge_scales_torch(outputs, size, label):
+    """The reference's own op sequence (step/make_cam.py:32-52) on whatever device the tensors live
+    on.  Not on the product path (which is `merge_scales`): kept as the host-logic mirror that
+    tests/test_host_logic.py checks against the reference's golden output on CPU, and as the
+    cross-check of the HIP kernel in the GPU tests."""
     size = (int(size[0]), int(size[1]))
     strided_size = imutils.get_strided_size(size, 4)
     strided_up_size = imutils.get_strided_up_size(size, 16)

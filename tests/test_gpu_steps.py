@@ -84,3 +84,38 @@ def test_steps_end_to_end(tmp_path):
         assert len(d["score"]) == len(d["mask"]) == len(d["class"])
         # masks of one image never overlap (they come from an argmax)
         assert d["mask"].sum(0).max() <= 1
+
+
+def test_cam_merge_kernel_vs_oracle_and_reference_golden(golden):
+    """irn_cam_merge (step/make_cam.py:38-52) bit for bit against the oracle's restatement, against the
+    reference's own output (1e-6; bar 1e-4) and against the torch-op mirror on the GPU."""
+    from irn_amd import ops
+    from irn_amd.step import make_cam
+    from oracle import irn_oracle as O
+    dev = torch.device("cuda", 0)
+    cm = golden("cam_merge")
+    for name in "ab":
+        outs = [cm["%s_out%d" % (name, i)] for i in range(4)]
+        size = tuple(int(v) for v in cm[name + "_size"])
+        keys, cam, hi = ops.cam_merge([torch.from_numpy(o).to(dev) for o in outs], size, torch.from_numpy(cm[name + "_label"]))
+        ok, olo, ohi = O.cam_merge(outs, size, cm[name + "_label"])
+        assert np.array_equal(keys.cpu().numpy(), ok) and np.array_equal(ok, cm[name + "_keys"])
+        assert np.array_equal(cam.cpu().numpy(), olo)
+        assert np.array_equal(hi.cpu().numpy(), ohi)
+        assert np.abs(cam.cpu().numpy() - cm[name + "_cam"]).max() <= 1e-6
+        assert np.abs(hi.cpu().numpy() - cm[name + "_high_res"]).max() <= 1e-6
+    # ragged sizes, other scale sets, single class
+    rng = np.random.RandomState(3)
+    for (H, W, shapes, label_idx) in ((375, 500, [(24, 32), (12, 16), (36, 47), (47, 63)], [1, 14]),
+                                      (333, 97, [(21, 7), (42, 13)], [19]),
+                                      (512, 512, [(32, 32), (16, 16), (48, 48), (64, 64)], [0, 5, 9, 17])):
+        outs = [np.abs(rng.randn(20, h, w)).astype(np.float32) for h, w in shapes]
+        label = np.zeros(20, np.float32)
+        label[label_idx] = 1
+        keys, cam, hi = ops.cam_merge([torch.from_numpy(o).to(dev) for o in outs], (H, W), torch.from_numpy(label))
+        ok, olo, ohi = O.cam_merge(outs, (H, W), label)
+        assert np.array_equal(keys.cpu().numpy(), ok)
+        assert np.array_equal(cam.cpu().numpy(), olo) and np.array_equal(hi.cpu().numpy(), ohi)
+        tk, tc, th = make_cam.merge_scales_torch([torch.from_numpy(o).to(dev) for o in outs], (H, W),
+                                                 torch.from_numpy(label).to(dev))
+        assert torch.equal(tk, keys) and (tc - cam).abs().max().item() <= 1e-5 and (th - hi).abs().max().item() <= 1e-5
