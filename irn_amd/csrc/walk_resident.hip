@@ -155,15 +155,19 @@ __device__ __forceinline__ void load_weights(float (&wr)[Geom<R>::NS][4], const 
 }
 
 // ---- per sweep and channel: this wave's partial sums for its 4 pixels ----
-template <int R, int QI>
+// HALF 0: the neighbour rows up to and including the one that crosses the half-way point of the
+// part (starts the sums); HALF 1: the rest.  The C = 2 schedule issues a poll between the halves.
+template <int R, int QI, int HALF>
 __device__ __forceinline__ void partial_sums(const float (&wr)[Geom<R>::NS][4], const float *xrow, double (&acc)[4]) {
     using G = Geom<R>;
     constexpr int H = G::H;
-    acc[0] = acc[1] = acc[2] = acc[3] = 0.0;
+    if constexpr (HALF == 0) acc[0] = acc[1] = acc[2] = acc[3] = 0.0;
     static_for<2 * H + 1>([&](auto iy) __attribute__((always_inline)) {
         constexpr int dy = decltype(iy)::value - H;
         constexpr int lo = row_lo<R, QI>(dy), hi = row_hi<R, QI>(dy);
-        if constexpr (lo <= hi) {
+        // (radius 5 keeps everything in half 0: the split pushed that instantiation into scratch)
+        constexpr bool first_half = R == 5 || lo - QI * G::NS < G::NS / 2;
+        if constexpr (lo <= hi && first_half == (HALF == 0)) {
             constexpr int dxlo = kDisc<R>.dx[lo], dxhi = kDisc<R>.dx[hi];
             constexpr int c_lo = floor4(dxlo), c_hi = dxhi + 3;
             constexpr int N4 = (c_hi - c_lo) / 4 + 1;
@@ -400,19 +404,31 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 const float *xrow = xsb + (ly + H) * LW + lx + HP;
                 double acc[4];
                 switch (qi) {
-                    case 0: partial_sums<R, 0>(wr, xrow, acc); break;
-                    case 1: partial_sums<R, 1 % Q>(wr, xrow, acc); break;
-                    case 2: partial_sums<R, 2 % Q>(wr, xrow, acc); break;
-                    case 3: partial_sums<R, 3 % Q>(wr, xrow, acc); break;
-                    case 4: partial_sums<R, 4 % Q>(wr, xrow, acc); break;
-                    case 5: partial_sums<R, 5 % Q>(wr, xrow, acc); break;
-                    case 6: partial_sums<R, 6 % Q>(wr, xrow, acc); break;
-                    default: partial_sums<R, 7 % Q>(wr, xrow, acc); break;
+                    case 0: partial_sums<R, 0, 0>(wr, xrow, acc); break;
+                    case 1: partial_sums<R, 1 % Q, 0>(wr, xrow, acc); break;
+                    case 2: partial_sums<R, 2 % Q, 0>(wr, xrow, acc); break;
+                    case 3: partial_sums<R, 3 % Q, 0>(wr, xrow, acc); break;
+                    case 4: partial_sums<R, 4 % Q, 0>(wr, xrow, acc); break;
+                    case 5: partial_sums<R, 5 % Q, 0>(wr, xrow, acc); break;
+                    case 6: partial_sums<R, 6 % Q, 0>(wr, xrow, acc); break;
+                    default: partial_sums<R, 7 % Q, 0>(wr, xrow, acc); break;
+                }
+                // C = 2: the next step's chain was stored at the end of the previous step; half-way through the
+                // arithmetic (~0.7 us behind those stores) its poll goes out and flies under the rest
+                if (polled && poller && C == 2) issue(state_rsrc(tn), cn * ch_bytes);
+                switch (qi) {
+                    case 0: partial_sums<R, 0, 1>(wr, xrow, acc); break;
+                    case 1: partial_sums<R, 1 % Q, 1>(wr, xrow, acc); break;
+                    case 2: partial_sums<R, 2 % Q, 1>(wr, xrow, acc); break;
+                    case 3: partial_sums<R, 3 % Q, 1>(wr, xrow, acc); break;
+                    case 4: partial_sums<R, 4 % Q, 1>(wr, xrow, acc); break;
+                    case 5: partial_sums<R, 5 % Q, 1>(wr, xrow, acc); break;
+                    case 6: partial_sums<R, 6 % Q, 1>(wr, xrow, acc); break;
+                    default: partial_sums<R, 7 % Q, 1>(wr, xrow, acc); break;
                 }
                 double *pw = part + (k & 1) * (kWaves * 256) + wv * 256 + lane;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) pw[j * 64] = acc[j];
-                if (polled && poller && C == 2) issue(state_rsrc(tn), cn * ch_bytes);
                 __syncthreads();
                 if (pslot) pslot[2] = wall_clock64();
 #pragma unroll

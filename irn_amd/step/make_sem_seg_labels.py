@@ -7,7 +7,7 @@ Writes args.sem_seg_out_dir/<name>.png  uint8 [H,W] (0 = background, class+1 oth
 Per image (step/make_sem_seg_labels.py:28-51): EdgeDisplacement forward (PyTorch-ROCm) -> edge;
 CAM dict from disk; random walk of the CAMs over the edge affinities and the label epilogue run in
 libirn_hip.so.  Unlike the reference's batch-1 loop the walk is issued for `walk_batch` images at a
-time (default 16) so one launch fills the GPU; results per image are unchanged.
+time (default 64) so one launch fills the GPU for several rounds; results per image are unchanged.
 """
 import os
 
@@ -42,7 +42,7 @@ def _work(process_id, model, dataset, args):
     databin = dataset[process_id]
     n_gpus = len(dataset)
     loader = DataLoader(databin, shuffle=False, num_workers=int(args.num_workers) // n_gpus, pin_memory=False)
-    batch = int(getattr(args, "walk_batch", 16))
+    batch = int(getattr(args, "walk_batch", 64))   # 64 VOC-size images = 3-4 rounds of the resident walk
     with torch.no_grad(), torch.cuda.device(process_id):
         model.cuda()
         walker = indexing.RandomWalk(RADIUS)
