@@ -183,18 +183,19 @@ int irn_label4(const uint8_t *mask_dev, int n, int h, int w, int32_t *labels_dev
  * rw_up dev fp32 [n_channels,h,w] (normalised scores), argmax dev int32 [h,w] (0 = background,
  * c+1 = channel c) -> one detection per 4-connected component of every channel's mask, ordered
  * channel ascending then raster order of the component's first pixel (skimage label order).
- *   _count : labels the components and gathers area / max score per detection into `scratch`;
- *            *n_det_out (host) = number of detections.  Synchronises `stream`.
- *   _emit  : after _count on the same scratch: score[d] = area < min_area ? 0 : max(score * mask)
- *            (:96-99), channel[d] (index into the caller's class_id array), mask dev uint8
- *            [n_det,h,w].  Only call with n_det >= 1.
+ *   _count : labels the components (state kept in `scratch`); *n_det_out (host) = number of
+ *            detections.  Synchronises `stream`.
+ *   _emit  : after _count with the same inputs and scratch: score[d] = area < min_area ? 0 :
+ *            max(score * mask) (:96-99), channel[d] (index into the caller's class_id array), mask
+ *            dev uint8 [n_det,h,w].  Only call with n_det >= 1.
  * scratch: irn_detect_scratch_bytes(n_channels, h, w).
  * ------------------------------------------------------------------------------------------- */
 size_t irn_detect_scratch_bytes(int n_channels, int h, int w);
 int irn_detect_instance_count(const float *rw_up_dev, const int32_t *argmax_dev, int n_channels, int h, int w,
                               int *n_det_out, void *scratch_dev, void *stream);
-int irn_detect_instance_emit(int n_channels, int h, int w, int n_det, double min_area, float *score_dev,
-                             int32_t *channel_dev, uint8_t *mask_dev, void *scratch_dev, void *stream);
+int irn_detect_instance_emit(const float *rw_up_dev, const int32_t *argmax_dev, int n_channels, int h, int w, int n_det,
+                             double min_area, float *score_dev, int32_t *channel_dev, uint8_t *mask_dev,
+                             void *scratch_dev, void *stream);
 
 #ifdef __cplusplus
 }

@@ -51,7 +51,7 @@ _SIGS = {
     "irn_label4": (i32, [vp, i32, i32, i32, vp, vp, vp, vp]),
     "irn_detect_scratch_bytes": (sz, [i32, i32, i32]),
     "irn_detect_instance_count": (i32, [vp, vp, i32, i32, i32, C.POINTER(i32), vp, vp]),
-    "irn_detect_instance_emit": (i32, [i32, i32, i32, i32, C.c_double, vp, vp, vp, vp, vp]),
+    "irn_detect_instance_emit": (i32, [vp, vp, i32, i32, i32, i32, C.c_double, vp, vp, vp, vp, vp]),
 }
 
 EXPORTS = tuple(_SIGS)

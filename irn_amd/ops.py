@@ -163,18 +163,41 @@ def detect_instance(rw_up, argmax, class_ids, n_channels, max_fragment_size=0):
     if sc.shape != (n_channels, h, w):
         raise ValueError("rw_up must be [%d,%d,%d], got %s" % (n_channels, h, w, tuple(sc.shape)))
     class_ids = np.asarray(class_ids)
-    scratch = torch.empty(lib.irn_detect_scratch_bytes(n_channels, h, w), dtype=torch.uint8, device=dev)
+    npx = h * w
+    scratch = _cached("det_scratch", dev, lib.irn_detect_scratch_bytes(n_channels, h, w), torch.uint8)
     n = C.c_int()
     with torch.cuda.device(dev):
         check(lib.irn_detect_instance_count(sc.data_ptr(), am.data_ptr(), n_channels, h, w, C.byref(n),
                                             scratch.data_ptr(), _stream()))
-        if n.value == 0:
+        nd = n.value
+        if nd == 0:
             raise ValueError("detect_instance: no foreground pixel in any channel")
-        score = torch.empty(n.value, dtype=torch.float32, device=dev)
-        chan = torch.empty(n.value, dtype=torch.int32, device=dev)
-        mask = torch.empty((n.value, h, w), dtype=torch.uint8, device=dev)
-        check(lib.irn_detect_instance_emit(n_channels, h, w, n.value, float(max_fragment_size), score.data_ptr(),
-                                           chan.data_ptr(), mask.data_ptr(), scratch.data_ptr(), _stream()))
-    return {"score": score.cpu().numpy(),
-            "mask": mask.cpu().numpy().astype(bool),
-            "class": class_ids[chan.cpu().numpy()]}
+        # one packed device buffer [score fp32 | channel int32 | masks uint8] -> one transfer into pinned memory
+        # (a pageable .cpu() of the masks plus fresh allocations cost 3.6 ms per 512^2 image: 10x the rest of the step)
+        head = 8 * nd
+        packed = _cached("det_out", dev, head + nd * npx, torch.uint8)
+        base = packed.data_ptr()
+        check(lib.irn_detect_instance_emit(sc.data_ptr(), am.data_ptr(), n_channels, h, w, nd, float(max_fragment_size),
+                                           base, base + 4 * nd, base + head, scratch.data_ptr(), _stream()))
+        host = _cached("det_host", "pinned", head + nd * npx, torch.uint8)
+        host[:head + nd * npx].copy_(packed[:head + nd * npx], non_blocking=True)
+        torch.cuda.current_stream().synchronize()
+    raw = host.numpy()
+    score = raw[:4 * nd].view(np.float32).copy()
+    chan = raw[4 * nd:head].view(np.int32)
+    mask = raw[head:head + nd * npx].view(np.bool_).reshape(nd, h, w).copy()
+    return {"score": score, "mask": mask, "class": class_ids[chan]}
+
+
+_CACHE = {}
+
+
+def _cached(tag, dev, nbytes, dtype):
+    """Grow-only scratch buffers (device) / pinned staging (dev == "pinned"), one per tag and device."""
+    key = (tag, str(dev))
+    buf = _CACHE.get(key)
+    if buf is None or buf.numel() < nbytes:
+        n = int(nbytes * 1.25) + 256
+        buf = torch.empty(n, dtype=dtype, pin_memory=True) if dev == "pinned" else torch.empty(n, dtype=dtype, device=dev)
+        _CACHE[key] = buf
+    return buf

@@ -29,41 +29,79 @@ cluster_centroids = ops.cluster_centroids
 detect_instance = ops.detect_instance
 
 
+def instance_labels_batch(walker, items, beta, exp_times, bg_thres):
+    """step/make_ins_seg_labels.py:131-150 for a batch of images.  items: dicts with GPU tensors
+    `edge` [1,h,w], `dp` [2,h,w], `cam` [C,h,w], CPU/GPU `keys` [C] and `size` (H, W).  The instance
+    front-end runs per image (cluster_centroids returns K to the host), the random walk and the
+    label epilogue run ONCE for the whole batch (a 128x128 grid is 16 tiles at radius 5 — one image
+    uses 1/16 of the GPU), detection runs per image.  Returns a list of detection dicts (or the
+    ValueError of an image without detections, in its slot)."""
+    cmaps, ks = [], []
+    for it in items:
+        centroids = ops.find_centroids_with_refinement(it["dp"])
+        cmap, k = ops.cluster_centroids(centroids, it["dp"])
+        cmaps.append(cmap)
+        ks.append(k)
+    rws = walker([it["edge"] for it in items], [it["cam"] for it in items], beta=beta, exp_times=exp_times,
+                 inst_maps=cmaps, k_inst=ks)
+    ep = ops.label_epilogue(rws, [it["size"] for it in items], bg_thres, want_labels=False, want_argmax=True,
+                            want_rw_up=True)
+    out = []
+    for i, it in enumerate(items):
+        n_cls = it["cam"].shape[0]
+        class_ids = np.repeat(np.asarray(torch.as_tensor(it["keys"]).cpu()), ks[i])
+        try:
+            out.append(ops.detect_instance(ep["rw_up"][i], ep["argmax"][i], class_ids, n_cls * ks[i],
+                                           max_fragment_size=it["size"][0] * it["size"][1] * 0.01))
+        except ValueError as e:
+            out.append(e)
+    walker.check()                          # the persistent walk reports a stuck tile instead of hanging
+    return out
+
+
 def instance_labels(walker, edge, dp, cams, keys, size, beta, exp_times, bg_thres):
     """One image: returns the detection dict (numpy) — step/make_ins_seg_labels.py:131-150."""
-    centroids = ops.find_centroids_with_refinement(dp)
-    cmap, k = ops.cluster_centroids(centroids, dp)
-    n_cls = cams.shape[0]
-    rw = walker([edge], [cams], beta=beta, exp_times=exp_times, inst_maps=[cmap], k_inst=[k])[0]
-    ep = ops.label_epilogue([rw], [size], bg_thres, want_labels=False, want_argmax=True, want_rw_up=True)
-    class_ids = np.repeat(np.asarray(keys.cpu()), k)
-    walker.check()                          # the persistent walk reports a stuck tile instead of hanging
-    return ops.detect_instance(ep["rw_up"][0], ep["argmax"][0], class_ids, n_cls * k,
-                               max_fragment_size=size[0] * size[1] * 0.01)
+    det = instance_labels_batch(walker, [{"edge": edge, "dp": dp, "cam": cams, "keys": keys, "size": size}],
+                                beta, exp_times, bg_thres)[0]
+    if isinstance(det, Exception):
+        raise det
+    return det
+
+
+def _flush(walker, pend, args):
+    if not pend:
+        return
+    dets = instance_labels_batch(walker, pend, float(args.beta), int(args.exp_times), float(args.ins_seg_bg_thres))
+    for it, det in zip(pend, dets):
+        if isinstance(det, Exception):
+            warnings.warn("%s: %s — no file written" % (it["name"], det))
+            continue
+        np.save(os.path.join(args.ins_seg_out_dir, it["name"] + ".npy"), det)
+    pend.clear()
 
 
 def _work(process_id, model, dataset, args):
     databin = dataset[process_id]
     n_gpus = len(dataset)
     loader = DataLoader(databin, shuffle=False, num_workers=int(args.num_workers) // n_gpus, pin_memory=False)
+    batch = int(getattr(args, "walk_batch", 32))   # images per walk launch (results per image unchanged)
     with torch.no_grad(), torch.cuda.device(process_id):
         model.cuda()
         walker = indexing.RandomWalk(RADIUS)
+        pend = []
         for it, pack in enumerate(loader):
             name = pack["name"][0]
+            if not isinstance(name, str):
+                name = voc12_dataloader.decode_int_filename(name)
             size = (int(pack["size"][0]), int(pack["size"][1]))
             edge, dp = model(pack["img"][0].cuda(non_blocking=True))
             cam_dict = np.load(os.path.join(args.cam_out_dir, name + ".npy"), allow_pickle=True).item()
-            cams = torch.as_tensor(cam_dict["cam"]).cuda()
-            keys = torch.as_tensor(cam_dict["keys"])
-            try:
-                det = instance_labels(walker, edge, dp, cams, keys, size, float(args.beta), int(args.exp_times),
-                                      float(args.ins_seg_bg_thres))
-            except ValueError as e:
-                warnings.warn("%s: %s — no file written" % (name, e))
-                continue
-            np.save(os.path.join(args.ins_seg_out_dir, name + ".npy"), det)
+            pend.append({"name": name, "size": size, "edge": edge, "dp": dp,
+                         "cam": torch.as_tensor(cam_dict["cam"]).cuda(), "keys": torch.as_tensor(cam_dict["keys"])})
+            if len(pend) == batch:
+                _flush(walker, pend, args)
             _common.progress(process_id, n_gpus, it, len(databin))
+        _flush(walker, pend, args)
         walker.close()
 
 

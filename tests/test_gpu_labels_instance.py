@@ -145,3 +145,26 @@ def test_detect_instance_on_device_vs_oracle_random_maps():
     with pytest.raises(ValueError):
         ops.detect_instance(torch.zeros((2, 8, 8), device=_dev()), torch.zeros((8, 8), dtype=torch.int32, device=_dev()),
                             np.arange(2), 2)
+
+
+def test_instance_labels_batch_equals_reference_golden(golden):
+    """The three golden images through ONE batched walk / epilogue (irn_amd.step.make_ins_seg_labels.
+    instance_labels_batch) reproduce the reference's detections exactly as the per-image path does."""
+    from irn_amd.misc import indexing
+    from irn_amd.step import make_ins_seg_labels as mis
+    ins = golden("instance")
+    items = []
+    for name in "abc":
+        H, W = (int(v) for v in ins[name + "_size"])
+        items.append({"edge": torch.from_numpy(ins[name + "_edge"])[None].to(_dev()),
+                      "dp": torch.from_numpy(ins[name + "_dp"]).to(_dev()),
+                      "cam": torch.from_numpy(ins[name + "_cam"]).to(_dev()),
+                      "keys": torch.from_numpy(ins[name + "_keys"]), "size": (H, W)})
+    walker = indexing.RandomWalk(5, _dev())
+    dets = mis.instance_labels_batch(walker, items, 10.0, 8, 0.25)
+    for name, det in zip("abc", dets):
+        assert not isinstance(det, Exception), det
+        assert np.array_equal(det["mask"], _unpack(ins, name + "_det_mask"))
+        assert np.array_equal(det["class"], ins[name + "_det_class"])
+        assert np.abs(det["score"] - ins[name + "_det_score"]).max() <= 1e-4
+    walker.close()
