@@ -1,6 +1,7 @@
 """Shared plumbing of the label-generation steps: one worker process per GPU over strided shards
 (reference step/make_cam.py:67-74), fail-fast, no communication between workers."""
 import importlib
+from concurrent.futures import ThreadPoolExecutor
 
 import torch
 from torch import multiprocessing
@@ -35,3 +36,28 @@ def progress(process_id, n_workers, it, n_items):
     step = max(n_items // 20, 1)
     if process_id == n_workers - 1 and it % step == 0:
         print("%d " % ((5 * it + 1) // step), end="", flush=True)
+
+
+class AsyncWriter:
+    """Output files (4 MB CAM dictionaries, PNG label maps, detection dictionaries) are encoded and
+    written by a small thread pool while the GPU works on the next images; at
+    most `max_pending` writes are in flight, errors surface at the next submit or at close()."""
+
+    def __init__(self, threads=4, max_pending=32):
+        self._pool = ThreadPoolExecutor(max_workers=threads)
+        self._pending = []
+        self._max = max_pending
+
+    def _reap(self, keep):
+        while len(self._pending) > keep:
+            self._pending.pop(0).result()        # re-raises a failed write
+
+    def submit(self, fn, *args, **kw):
+        self._reap(self._max - 1)
+        self._pending.append(self._pool.submit(fn, *args, **kw))
+
+    def close(self):
+        try:
+            self._reap(0)
+        finally:
+            self._pool.shutdown(wait=True)

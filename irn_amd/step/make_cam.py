@@ -56,6 +56,7 @@ def _work(process_id, model, dataset, args):
     databin = dataset[process_id]
     n_gpus = len(dataset)
     loader = DataLoader(databin, shuffle=False, num_workers=int(args.num_workers) // n_gpus, pin_memory=False)
+    writer = _common.AsyncWriter()
     with torch.no_grad(), torch.cuda.device(process_id):
         model.cuda()
         for it, pack in enumerate(loader):
@@ -65,9 +66,10 @@ def _work(process_id, model, dataset, args):
             imgs = pack["img"] if isinstance(pack["img"], (list, tuple)) else [pack["img"]]
             outputs = [model(img[0].cuda(non_blocking=True)) for img in imgs]
             keys, cam, high_res = merge_scales(outputs, size, label.cuda())
-            np.save(os.path.join(args.cam_out_dir, img_name + ".npy"),
-                    {"keys": keys.cpu(), "cam": cam.cpu(), "high_res": high_res.cpu().numpy()})
+            writer.submit(np.save, os.path.join(args.cam_out_dir, img_name + ".npy"),
+                          {"keys": keys.cpu(), "cam": cam.cpu(), "high_res": high_res.cpu().numpy()})
             _common.progress(process_id, n_gpus, it, len(databin))
+    writer.close()
 
 
 def run(args):

@@ -68,7 +68,7 @@ def instance_labels(walker, edge, dp, cams, keys, size, beta, exp_times, bg_thre
     return det
 
 
-def _flush(walker, pend, args):
+def _flush(walker, pend, args, writer):
     if not pend:
         return
     dets = instance_labels_batch(walker, pend, float(args.beta), int(args.exp_times), float(args.ins_seg_bg_thres))
@@ -76,7 +76,7 @@ def _flush(walker, pend, args):
         if isinstance(det, Exception):
             warnings.warn("%s: %s — no file written" % (it["name"], det))
             continue
-        np.save(os.path.join(args.ins_seg_out_dir, it["name"] + ".npy"), det)
+        writer.submit(np.save, os.path.join(args.ins_seg_out_dir, it["name"] + ".npy"), det)
     pend.clear()
 
 
@@ -88,6 +88,7 @@ def _work(process_id, model, dataset, args):
     with torch.no_grad(), torch.cuda.device(process_id):
         model.cuda()
         walker = indexing.RandomWalk(RADIUS)
+        writer = _common.AsyncWriter()
         pend = []
         for it, pack in enumerate(loader):
             name = pack["name"][0]
@@ -99,9 +100,10 @@ def _work(process_id, model, dataset, args):
             pend.append({"name": name, "size": size, "edge": edge, "dp": dp,
                          "cam": torch.as_tensor(cam_dict["cam"]).cuda(), "keys": torch.as_tensor(cam_dict["keys"])})
             if len(pend) == batch:
-                _flush(walker, pend, args)
+                _flush(walker, pend, args, writer)
             _common.progress(process_id, n_gpus, it, len(databin))
-        _flush(walker, pend, args)
+        _flush(walker, pend, args, writer)
+        writer.close()
         walker.close()
 
 

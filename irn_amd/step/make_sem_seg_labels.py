@@ -24,7 +24,11 @@ from . import _common
 RADIUS = 5   # hard-coded at the reference call site (step/make_sem_seg_labels.py:41)
 
 
-def _flush(walker, pend, args):
+def _save_png(path, label):
+    Image.fromarray(label).save(path)
+
+
+def _flush(walker, pend, args, writer):
     if not pend:
         return
     rws = walker([p["edge"] for p in pend], [p["cam"] for p in pend],
@@ -34,7 +38,7 @@ def _flush(walker, pend, args):
     labels = [lab.cpu().numpy() for lab in out["labels"]]
     walker.check()                          # the persistent walk reports a stuck tile instead of hanging
     for p, lab in zip(pend, labels):
-        Image.fromarray(lab).save(os.path.join(args.sem_seg_out_dir, p["name"] + ".png"))
+        writer.submit(_save_png, os.path.join(args.sem_seg_out_dir, p["name"] + ".png"), lab)
     pend.clear()
 
 
@@ -46,6 +50,7 @@ def _work(process_id, model, dataset, args):
     with torch.no_grad(), torch.cuda.device(process_id):
         model.cuda()
         walker = indexing.RandomWalk(RADIUS)
+        writer = _common.AsyncWriter()
         pend = []
         for it, pack in enumerate(loader):
             name = pack["name"][0]
@@ -58,9 +63,10 @@ def _work(process_id, model, dataset, args):
                          "cam": torch.as_tensor(cam_dict["cam"]).cuda(),
                          "keys": torch.as_tensor(cam_dict["keys"]).cuda()})
             if len(pend) == batch:
-                _flush(walker, pend, args)
+                _flush(walker, pend, args, writer)
             _common.progress(process_id, n_gpus, it, len(databin))
-        _flush(walker, pend, args)
+        _flush(walker, pend, args, writer)
+        writer.close()
         walker.close()
 
 

@@ -95,3 +95,17 @@ def test_cam_merge_matches_reference_golden(golden):
         assert np.array_equal(keys.numpy(), cm[name + "_keys"])
         assert np.abs(cam.numpy() - cm[name + "_cam"]).max() <= 1e-6
         assert np.abs(hi.numpy() - cm[name + "_high_res"]).max() <= 1e-6
+
+
+def test_async_writer_writes_everything_and_surfaces_errors(tmp_path):
+    from irn_amd.step import _common
+    w = _common.AsyncWriter(threads=2, max_pending=3)
+    for i in range(10):
+        w.submit(np.save, str(tmp_path / ("f%d.npy" % i)), {"i": i})
+    w.close()
+    assert sorted(p.name for p in tmp_path.iterdir()) == sorted("f%d.npy" % i for i in range(10))
+    assert np.load(str(tmp_path / "f7.npy"), allow_pickle=True).item() == {"i": 7}
+    w = _common.AsyncWriter(threads=1, max_pending=1)
+    w.submit(np.save, str(tmp_path / "no_such_dir" / "x.npy"), 1)
+    with pytest.raises(Exception):
+        w.close()
