@@ -65,6 +65,13 @@ int irn_path_table(int radius, int order, int32_t *dst_dydx, int32_t *path_start
 int irn_edge_to_affinity(const float *edge_dev, int batch, int hp, int wp, int radius,
                          float *aff_dev, void *stream);
 
+/* Its vector-Jacobian product, for the training seam (net/resnet50_irn.py:162-175 under autograd: the
+ * gradient of aff[b,d,s] goes, negated, to the first path cell that attains the maximum).
+ * grad_aff: dev [B, n_dirs, (Hp-rf)*(Wp-2rf)] -> grad_edge: dev [B, Hp, Wp] (overwritten).  The arg-max
+ * is recomputed from `edge`; nothing from the forward call is needed. */
+int irn_edge_to_affinity_backward(const float *edge_dev, const float *grad_aff_dev, int batch, int hp, int wp,
+                                  int radius, float *grad_edge_dev, void *stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Random-walk context  (replaces misc/indexing.py:141-165 `propagate_to_edge` and everything it
  * calls: PathIndex :148, edge_to_affinity :151, affinity_sparse2dense :154, to_transition_matrix

@@ -93,6 +93,72 @@ __global__ __launch_bounds__(256) void affinity_kernel(const AffJob *__restrict_
     }
 }
 
+// Backward of edge_to_affinity for the training seam (reference net/resnet50_irn.py:162-175: index_select
+// + max_pool2d over the path axis; autograd sends the gradient of aff[d,s] to the FIRST path cell that
+// attains the maximum, negated because aff = 1 - max).  The forward's edge tile is rebuilt in LDS and the
+// arg-max is recomputed (nothing is saved by the forward); gradients of a workgroup are gathered in an
+// LDS tile with ds_add_f32 and flushed with one global atomic per touched cell, so overlapping halos of
+// neighbouring workgroups meet in HBM only once per cell instead of once per (pixel, direction).
+__global__ __launch_bounds__(256) void affinity_backward_kernel(const AffJob *__restrict__ jobs,
+                                                                const float *const *__restrict__ grad_aff,
+                                                                float *const *__restrict__ grad_edge,
+                                                                const int *__restrict__ dir_start,
+                                                                const int *__restrict__ cell_dy,
+                                                                const int *__restrict__ cell_dx, int n_dirs, int radius) {
+    extern __shared__ float tile[];
+    const AffJob J = jobs[blockIdx.y];
+    const int tiles_x = (J.sw + AFF_TW - 1) / AFF_TW;
+    const int tiles_y = (J.sh + AFF_TH - 1) / AFF_TH;
+    if ((int)blockIdx.x >= tiles_x * tiles_y) return;
+    const int halo = radius - 1;
+    const int LW = AFF_TW + 2 * halo;
+    const int LH = AFF_TH + halo;
+    float *gtile = tile + LH * LW;
+    const int ty0 = ((int)blockIdx.x / tiles_x) * AFF_TH;
+    const int tx0 = ((int)blockIdx.x % tiles_x) * AFF_TW;
+    for (int i = threadIdx.x; i < LH * LW; i += 256) {
+        const int ly = i / LW, lx = i - ly * LW;
+        const int gy = J.oy + ty0 + ly;
+        const int gx = J.ox + tx0 + lx - halo;
+        float v = 1.0f;
+        if (gy < J.gh && gx >= 0 && gx < J.gw) v = J.edge[(long)gy * J.gw + gx];
+        tile[i] = v;
+        gtile[i] = 0.f;
+    }
+    __syncthreads();
+    const int ly = threadIdx.x / AFF_TW, lx = threadIdx.x % AFF_TW;
+    const int sy = ty0 + ly, sx = tx0 + lx;
+    const bool valid = sy < J.sh && sx < J.sw;
+    const int base = ly * LW + lx + halo;
+    const float *ga = grad_aff[blockIdx.y] + (long)sy * J.sw + sx;
+    if (valid) {
+        for (int d = 0; d < n_dirs; ++d) {
+            const int k0 = dir_start[d], k1 = dir_start[d + 1];
+            float m = -INFINITY;
+            int arg = 0;
+            for (int k = k0; k < k1; ++k) {
+                const int off = cell_dy[k] * LW + cell_dx[k];
+                const float v = tile[base + off];
+                if (v > m) {     // strict: the first maximum keeps the gradient, like max_pool2d
+                    m = v;
+                    arg = off;
+                }
+            }
+            atomicAdd(&gtile[base + arg], -ga[(long)d * J.plane_stride]);
+        }
+    }
+    __syncthreads();
+    float *ge = grad_edge[blockIdx.y];
+    for (int i = threadIdx.x; i < LH * LW; i += 256) {
+        const float g = gtile[i];
+        if (g == 0.f) continue;
+        const int py = i / LW, px = i - py * LW;
+        const int gy = J.oy + ty0 + py;
+        const int gx = J.ox + tx0 + px - halo;
+        if (gy < J.gh && gx >= 0 && gx < J.gw) unsafeAtomicAdd(ge + (long)gy * J.gw + gx, g);
+    }
+}
+
 }  // namespace
 
 int launch_affinity(const AffJob *jobs_dev, int n_jobs, int max_sh, int max_sw, const DeviceTable &tab,
@@ -178,5 +244,46 @@ extern "C" int irn_edge_to_affinity(const float *edge_dev, int batch, int hp, in
     if (rc) return rc;
     rc = launch_affinity(jobs_dev, batch, sh, sw, *tab, false, 0.f, stream);
     if (rc) return rc;
+    return scratch_release(stream);
+}
+
+extern "C" int irn_edge_to_affinity_backward(const float *edge_dev, const float *grad_aff_dev, int batch, int hp, int wp,
+                                             int radius, float *grad_edge_dev, void *stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!edge_dev || !grad_aff_dev || !grad_edge_dev || batch < 1 || radius < 2 || radius > IRN_MAX_RADIUS)
+        return fail(IRN_ERR_ARG, "irn_edge_to_affinity_backward: bad argument");
+    const int rf = radius - 1;
+    const int sh = hp - rf, sw = wp - 2 * rf;
+    if (sh < 1 || sw < 1)
+        return fail(IRN_ERR_ARG, "irn_edge_to_affinity_backward: grid %dx%d too small for radius %d", hp, wp, radius);
+    const DeviceTable *tab = nullptr;
+    int rc = get_device_table(radius, 0, &tab);
+    if (rc) return rc;
+    const long ns = (long)sh * sw;
+    // descriptors + the two pointer arrays in one upload
+    std::vector<char> host(sizeof(AffJob) * batch + 2 * sizeof(void *) * batch);
+    AffJob *jobs = (AffJob *)host.data();
+    const float **gas = (const float **)(host.data() + sizeof(AffJob) * batch);
+    float **ges = (float **)(host.data() + sizeof(AffJob) * batch + sizeof(void *) * batch);
+    for (int b = 0; b < batch; ++b) {
+        AffJob &j = jobs[b];
+        j.edge = edge_dev + (long)b * hp * wp;
+        j.out = nullptr;
+        j.gh = hp; j.gw = wp; j.oy = 0; j.ox = rf; j.sh = sh; j.sw = sw;
+        j.plane_stride = ns;
+        gas[b] = grad_aff_dev + (long)b * tab->n_dirs * ns;
+        ges[b] = grad_edge_dev + (long)b * hp * wp;
+    }
+    char *dev = nullptr;
+    rc = scratch_upload(host.data(), host.size(), (void **)&dev, stream);
+    if (rc) return rc;
+    IRN_HIP_TRY(hipMemsetAsync(grad_edge_dev, 0, sizeof(float) * (size_t)batch * hp * wp, stream));
+    const int tiles = cdiv(sh, AFF_TH) * cdiv(sw, AFF_TW);
+    const size_t lds = 2 * sizeof(float) * (AFF_TH + rf) * (AFF_TW + 2 * rf);
+    hipLaunchKernelGGL(affinity_backward_kernel, dim3(tiles, batch), dim3(256), lds, stream, (const AffJob *)dev,
+                       (const float *const *)(dev + sizeof(AffJob) * batch),
+                       (float *const *)(dev + sizeof(AffJob) * batch + sizeof(void *) * batch), tab->dir_start, tab->cell_dy,
+                       tab->cell_dx, tab->n_dirs, radius);
+    IRN_LAUNCH_CHECK("affinity_backward_kernel");
     return scratch_release(stream);
 }

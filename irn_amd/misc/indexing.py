@@ -110,13 +110,43 @@ class PathIndex:
         return self._indices[2]
 
 
+class _EdgeToAffinity(torch.autograd.Function):
+    """irn_edge_to_affinity with irn_edge_to_affinity_backward as its vector-Jacobian product (the
+    gradient of aff[b,d,s] goes, negated, to the first path cell attaining the maximum — what autograd
+    does through the reference's index_select + max_pool2d, net/resnet50_irn.py:162-175)."""
+
+    @staticmethod
+    def forward(ctx, e, radius, hp, wp):
+        rf = int(np.ceil(radius) - 1)
+        nd, nc = C.c_int(), C.c_int()
+        check(lib.irn_path_count(int(radius), C.byref(nd), C.byref(nc)))
+        out = torch.empty((e.size(0), nd.value, (hp - rf) * (wp - 2 * rf)), device=e.device, dtype=torch.float32)
+        with torch.cuda.device(e.device):
+            check(lib.irn_edge_to_affinity(e.data_ptr(), e.size(0), hp, wp, int(radius), out.data_ptr(), _stream()))
+        ctx.save_for_backward(e)
+        ctx.geom = (int(radius), hp, wp)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        (e,) = ctx.saved_tensors
+        radius, hp, wp = ctx.geom
+        g = grad_out.contiguous().float()
+        grad_edge = torch.empty_like(e)
+        with torch.cuda.device(e.device):
+            check(lib.irn_edge_to_affinity_backward(e.data_ptr(), g.data_ptr(), e.size(0), hp, wp, radius,
+                                                    grad_edge.data_ptr(), _stream()))
+        return grad_edge, None, None, None
+
+
 def edge_to_affinity(edge, paths_indices=None, radius=None, size=None):
-    """aff[b, d, s] = 1 - max over path(d) of edge (reference misc/indexing.py:91-109).
+    """aff[b, d, s] = 1 - max over path(d) of edge (reference misc/indexing.py:91-109 and, under
+    autograd, AffinityDisplacementLoss.to_affinity net/resnet50_irn.py:162-175).
 
     ``edge``: GPU float tensor [B, Hp*Wp] or [B, 1, Hp, Wp] (viewed as [B, -1] like the reference).
     ``paths_indices``: ``PathIndex.path_indices`` (carries radius and grid size) — or pass
     ``radius=`` and ``size=(Hp, Wp)`` directly.  Returns [B, |S|, (Hp-rf)*(Wp-2rf)] in the
-    reference's channel order."""
+    reference's channel order.  Differentiable w.r.t. ``edge``."""
     _need_cuda(edge, "edge")
     if paths_indices is not None and radius is None:
         radius, size = getattr(paths_indices, "radius", None), getattr(paths_indices, "size", None)
@@ -126,13 +156,7 @@ def edge_to_affinity(edge, paths_indices=None, radius=None, size=None):
     e = edge.reshape(edge.size(0), -1).contiguous().float()
     if e.size(1) != hp * wp:
         raise ValueError("edge has %d elements per item, grid is %dx%d" % (e.size(1), hp, wp))
-    rf = int(np.ceil(radius) - 1)
-    nd, nc = C.c_int(), C.c_int()
-    check(lib.irn_path_count(int(radius), C.byref(nd), C.byref(nc)))
-    out = torch.empty((e.size(0), nd.value, (hp - rf) * (wp - 2 * rf)), device=e.device, dtype=torch.float32)
-    with torch.cuda.device(e.device):
-        check(lib.irn_edge_to_affinity(e.data_ptr(), e.size(0), hp, wp, int(radius), out.data_ptr(), _stream()))
-    return out
+    return _EdgeToAffinity.apply(e, radius, hp, wp)
 
 
 def affinity_sparse2dense(affinity_sparse, ind_from, ind_to, n_vertices):

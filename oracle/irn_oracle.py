@@ -96,6 +96,32 @@ def edge_to_affinity(edge_flat, path_indices):
     return np.concatenate(out, axis=0)
 
 
+def edge_to_affinity_backward(edge, grad_aff, radius):
+    """Vector-Jacobian product of AffinityDisplacementLoss.to_affinity (reference net/resnet50_irn.py:
+    162-175) as autograd computes it through index_select + max_pool2d: the gradient of aff[b,d,s]
+    goes, negated (aff = 1 - max), to the FIRST cell of path(d) that attains the maximum.
+    edge [B,Hp,Wp], grad_aff [B,|S|,(Hp-rf)*(Wp-2rf)] in the reference's channel order -> [B,Hp,Wp]."""
+    edge = np.asarray(edge, np.float32)
+    b, hp, wp = edge.shape
+    rf = radius - 1
+    ch, cw = hp - rf, wp - 2 * rf
+    paths, _dst = search_paths_dst(radius)
+    grad = np.zeros(edge.shape, np.float64)
+    d = 0
+    ys, xs = np.mgrid[0:ch, 0:cw]
+    for group in paths:
+        for path in group:
+            vals = np.stack([edge[:, dy:dy + ch, rf + dx:rf + dx + cw] for dy, dx in path], 1)   # [B,L,ch,cw]
+            arg = np.argmax(vals, 1)                                                              # first maximum
+            g = np.asarray(grad_aff, np.float32)[:, d].reshape(b, ch, cw)
+            pdy = np.asarray([p[0] for p in path])[arg]
+            pdx = np.asarray([p[1] for p in path])[arg]
+            for bi in range(b):
+                np.add.at(grad[bi], (ys + pdy[bi], xs + rf + pdx[bi]), -g[bi].astype(np.float64))
+            d += 1
+    return grad.astype(np.float32)
+
+
 def affinity_dense(aff, src, dst, n):
     """Symmetric dense matrix with unit diagonal (misc/indexing.py:112-129)."""
     a = np.zeros((n, n), np.float32)

@@ -97,6 +97,33 @@ def gen_affinity():
     np.savez_compressed(os.path.join(OUT, "affinity.npz"), **out)
 
 
+def gen_affinity_grad():
+    """Training seam: AffinityDisplacementLoss.to_affinity (net/resnet50_irn.py:162-175) under autograd —
+    forward values and the gradient of sum(aff * g) w.r.t. the edge map, batch of 2, radius 5 (the
+    training configuration's index tensors come from PathIndex like step/train_irn.py:12-21)."""
+    from misc import indexing
+    from net import resnet50_irn
+    out = {}
+    for r, (hp, wp) in ((5, (20, 27)), (3, (12, 15))):
+        pi = indexing.PathIndex(radius=r, default_size=(hp, wp))
+        loss = resnet50_irn.AffinityDisplacementLoss.__new__(resnet50_irn.AffinityDisplacementLoss)
+        torch.nn.Module.__init__(loss)
+        loss.path_index = pi
+        loss.n_path_lengths = len(pi.path_indices)
+        for i, pind in enumerate(pi.path_indices):
+            loss.register_buffer(resnet50_irn.AffinityDisplacementLoss.path_indices_prefix + str(i), torch.from_numpy(pind))
+        edge = torch.stack([torch.from_numpy(synth.edge_field(hp, wp, seed=300 + r + b)) for b in range(2)])[:, None]
+        edge.requires_grad_(True)
+        aff = loss.to_affinity(edge)
+        g = torch.from_numpy(np.random.RandomState(7 + r).randn(*aff.shape).astype(np.float32))
+        (aff * g).sum().backward()
+        out["r%d_edge" % r] = edge.detach()[:, 0].numpy()
+        out["r%d_aff" % r] = aff.detach().numpy()
+        out["r%d_gout" % r] = g.numpy()
+        out["r%d_gedge" % r] = edge.grad[:, 0].numpy()
+    np.savez_compressed(os.path.join(OUT, "affinity_grad.npz"), **out)
+
+
 WALK_CASES = [
     # name, h, w, C, radius, beta, exp_times, seed
     ("r5_b10_e8", 32, 32, 3, 5, 10, 8, 1),
@@ -290,7 +317,7 @@ def gen_nets():
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", nargs="*", default=None,
-                    help="subset of: path affinity walk semseg instance cam_merge nets; or walk case names")
+                    help="subset of: path affinity affinity_grad walk semseg instance cam_merge nets; or walk case names")
     a = ap.parse_args()
     _install_reference()
     torch.set_num_threads(os.cpu_count())
@@ -303,6 +330,8 @@ def main():
         gen_path_tables()
     if want("affinity"):
         gen_affinity()
+    if want("affinity_grad"):
+        gen_affinity_grad()
     walk_names = {c[0] for c in WALK_CASES}
     if want("walk") or (sel and sel & walk_names):
         gen_walk(only=(sel & walk_names) if sel and not want("walk") else None)

@@ -205,3 +205,33 @@ def test_full_size_128_vs_fp64_oracle():
     st = O.propagate_to_edge_stencil(cam, edge, 10, 10, 8)
     assert np.abs(rw - st).max() <= TOL_F64
     assert np.array_equal(np.argmax(rw[:, 0], 0), np.argmax(st[:, 0], 0))
+
+
+@pytest.mark.parametrize("r", [3, 5])
+def test_edge_to_affinity_is_differentiable_like_the_reference(golden, r):
+    """Training seam (net/resnet50_irn.py:162-175): forward values exact, and the gradient that flows
+    back through irn_edge_to_affinity_backward equals the one autograd produced through the reference's
+    index_select + max_pool2d (fixture generated by running the reference) and the oracle's restatement."""
+    from irn_amd.misc import indexing
+    ag = golden("affinity_grad")
+    edge_np, gout = ag["r%d_edge" % r], ag["r%d_gout" % r]
+    b, hp, wp = edge_np.shape
+    edge = torch.from_numpy(edge_np).to(_dev()).requires_grad_(True)
+    aff = indexing.edge_to_affinity(edge[:, None], radius=r, size=(hp, wp))
+    assert np.array_equal(aff.detach().cpu().numpy(), ag["r%d_aff" % r])
+    (aff * torch.from_numpy(gout).to(_dev())).sum().backward()
+    ge = edge.grad.cpu().numpy()
+    ref = ag["r%d_gedge" % r]
+    assert np.abs(ge - ref).max() <= 1e-5 * np.abs(ref).max()
+    assert np.abs(ge - O.edge_to_affinity_backward(edge_np, gout, r)).max() <= 1e-5 * np.abs(ref).max()
+    # a larger ragged batch against the oracle, radius 10 included
+    for rr, (hh, ww) in ((10, (40, 61)), (5, (33, 70))):
+        from irn_amd import synth
+        e_np = np.stack([synth.edge_field(hh, ww, seed=900 + i) for i in range(3)])
+        nd = {5: 34, 10: 152}[rr]
+        g_np = np.random.RandomState(rr).randn(3, nd, (hh - rr + 1) * (ww - 2 * (rr - 1))).astype(np.float32)
+        e = torch.from_numpy(e_np).to(_dev()).requires_grad_(True)
+        a = indexing.edge_to_affinity(e[:, None], radius=rr, size=(hh, ww))
+        (a * torch.from_numpy(g_np).to(_dev())).sum().backward()
+        want = O.edge_to_affinity_backward(e_np, g_np, rr)
+        assert np.abs(e.grad.cpu().numpy() - want).max() <= 2e-5 * np.abs(want).max()

@@ -141,3 +141,12 @@ def test_cam_merge(golden, name):
     # on `cam` is 1e-4 (north star), this is 100x tighter
     assert np.abs(lo - cm[name + "_cam"]).max() <= 1e-6
     assert np.abs(hi - cm[name + "_high_res"]).max() <= 1e-6
+
+
+@pytest.mark.parametrize("r", [3, 5])
+def test_affinity_backward_restatement_vs_reference_autograd(golden, r):
+    """oracle.edge_to_affinity_backward against the gradient autograd produced through the reference's
+    AffinityDisplacementLoss.to_affinity (tests/golden/make_golden.py gen_affinity_grad)."""
+    ag = golden("affinity_grad")
+    ge = O.edge_to_affinity_backward(ag["r%d_edge" % r], ag["r%d_gout" % r], r)
+    assert np.abs(ge - ag["r%d_gedge" % r]).max() <= 1e-5 * np.abs(ag["r%d_gedge" % r]).max()
