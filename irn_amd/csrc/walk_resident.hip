@@ -155,44 +155,90 @@ __device__ __forceinline__ void load_weights(float (&wr)[Geom<R>::NS][4], const 
 }
 
 // ---- per sweep and channel: this wave's partial sums for its 4 pixels ----
-// HALF 0: the neighbour rows up to and including the one that crosses the half-way point of the
-// part (starts the sums); HALF 1: the rest.  The C = 2 schedule issues a poll between the halves.
+// Neighbour rows of wave part QI that belong to HALF (0: the rows up to and including the one that
+// crosses the half-way point of the part, 1: the rest; radius 5 keeps everything in half 0 — the split
+// pushed that instantiation into scratch).  The C = 2 schedule issues a poll between the halves.
+template <int R, int QI, int HALF>
+struct RowList {
+    int n = 0;
+    int dy[2 * R] = {};
+    constexpr RowList() {
+        constexpr int NS = Geom<R>::NS;
+        for (int y = -(R - 1); y <= R - 1; ++y) {
+            const int lo = row_lo<R, QI>(y), hi = row_hi<R, QI>(y);
+            if (lo > hi) continue;
+            const bool first_half = R == 5 || lo - QI * NS < NS / 2;
+            if (first_half == (HALF == 0)) dy[n++] = y;
+        }
+    }
+};
+template <int R, int QI, int HALF>
+inline constexpr RowList<R, QI, HALF> kRowList{};
+
+template <int R, int QI, int DY>
+struct RowInfo {
+    static constexpr int lo = row_lo<R, QI>(DY), hi = row_hi<R, QI>(DY);
+    static constexpr int c_lo = floor4(kDisc<R>.dx[lo]), c_hi = kDisc<R>.dx[hi] + 3;
+    static constexpr int N4 = (c_hi - c_lo) / 4 + 1;          // aligned 16-byte reads of the state window
+};
+
+constexpr int kMaxWin = 7;   // (2 * 9 + 4 + 3) / 4 + ...: a full radius-10 row needs 7 float4
+
+template <int R, int QI, int DY>
+__device__ __forceinline__ void load_window(f4a (&w)[kMaxWin], const float *xrow) {
+    using RW = RowInfo<R, QI, DY>;
+    static_assert(RW::N4 <= kMaxWin, "window");
+    const float *row = xrow + DY * Geom<R>::LW + RW::c_lo;
+#pragma unroll
+    for (int k = 0; k < RW::N4; ++k) w[k] = *reinterpret_cast<const f4a *>(row + 4 * k);
+}
+
+// one fp32 chain per pixel over the neighbours of the row (<= 19 terms), folded into fp64.  (More chains
+// for ILP and packed FMAs were both measured: slower / no gain.)
+template <int R, int QI, int DY>
+__device__ __forceinline__ void fma_window(const float (&wr)[Geom<R>::NS][4], const f4a (&w)[kMaxWin], double (&acc)[4]) {
+    using RW = RowInfo<R, QI, DY>;
+    float pf[4] = {0.f, 0.f, 0.f, 0.f};
+    static_for<RW::hi - RW::lo + 1>([&](auto is) __attribute__((always_inline)) {
+        constexpr int s = RW::lo + decltype(is)::value;
+        constexpr int dx = kDisc<R>.dx[s];
+        constexpr int k = s - QI * Geom<R>::NS;
+        static_for<4>([&](auto ij) __attribute__((always_inline)) {
+            constexpr int j = decltype(ij)::value;
+            constexpr int e = dx + j - RW::c_lo;
+            pf[j] = fmaf(wr[k][j], w[e / 4][e % 4], pf[j]);
+        });
+    });
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[j] += (double)pf[j];
+}
+
+// The window of row r+1 is read BEFORE the FMAs of row r (two windows live).  Isolated in
+// tools/arith_probe.hip the phase is LDS-bound: the window reads alone take 0.44 us per step, reads
+// then FMAs row after row 0.78 us (no overlap at all: every wave of the CU is in the same phase), this
+// order 0.62 us; reading every window of the part first 0.70 us.
 template <int R, int QI, int HALF>
 __device__ __forceinline__ void partial_sums(const float (&wr)[Geom<R>::NS][4], const float *xrow, double (&acc)[4]) {
-    using G = Geom<R>;
-    constexpr int H = G::H;
+    constexpr int NR = kRowList<R, QI, HALF>.n;
     if constexpr (HALF == 0) acc[0] = acc[1] = acc[2] = acc[3] = 0.0;
-    static_for<2 * H + 1>([&](auto iy) __attribute__((always_inline)) {
-        constexpr int dy = decltype(iy)::value - H;
-        constexpr int lo = row_lo<R, QI>(dy), hi = row_hi<R, QI>(dy);
-        // (radius 5 keeps everything in half 0: the split pushed that instantiation into scratch)
-        constexpr bool first_half = R == 5 || lo - QI * G::NS < G::NS / 2;
-        if constexpr (lo <= hi && first_half == (HALF == 0)) {
-            constexpr int dxlo = kDisc<R>.dx[lo], dxhi = kDisc<R>.dx[hi];
-            constexpr int c_lo = floor4(dxlo), c_hi = dxhi + 3;
-            constexpr int N4 = (c_hi - c_lo) / 4 + 1;
-            float win[4 * N4];
-            const float *row = xrow + dy * G::LW + c_lo;
-#pragma unroll
-            for (int k = 0; k < N4; ++k) {
-                const f4a v = *reinterpret_cast<const f4a *>(row + 4 * k);
-                win[4 * k] = v.x; win[4 * k + 1] = v.y; win[4 * k + 2] = v.z; win[4 * k + 3] = v.w;
-            }
-            // One fp32 chain per pixel and row segment (<= 19 terms).  The sweep is VALU-throughput
-            // bound here (152 v_fmac per wave, two waves per SIMD), so extra chains for ILP only add
-            // instructions (measured: slower).
-            float pf[4] = {0.f, 0.f, 0.f, 0.f};
-            static_for<hi - lo + 1>([&](auto is) __attribute__((always_inline)) {
-                constexpr int s = lo + decltype(is)::value;
-                constexpr int dx = kDisc<R>.dx[s];
-                constexpr int k = s - QI * G::NS;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) pf[j] = fmaf(wr[k][j], win[dx + j - c_lo], pf[j]);
-            });
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc[j] += (double)pf[j];
-        }
-    });
+    if constexpr (NR > 0 && R == 5) {
+        // radius 5: row after row (the double-buffered order spills in that instantiation)
+        static_for<NR>([&](auto ir) __attribute__((always_inline)) {
+            f4a w1[kMaxWin];
+            load_window<R, QI, kRowList<R, QI, HALF>.dy[decltype(ir)::value]>(w1, xrow);
+            fma_window<R, QI, kRowList<R, QI, HALF>.dy[decltype(ir)::value]>(wr, w1, acc);
+        });
+    } else if constexpr (NR > 0) {
+        f4a w[2][kMaxWin];
+        load_window<R, QI, kRowList<R, QI, HALF>.dy[0]>(w[0], xrow);
+        static_for<NR>([&](auto ir) __attribute__((always_inline)) {
+            constexpr int r = decltype(ir)::value;
+            if constexpr (r + 1 < NR) load_window<R, QI, kRowList<R, QI, HALF>.dy[r + 1 < NR ? r + 1 : r]>(w[(r + 1) & 1], xrow);
+            __builtin_amdgcn_sched_barrier(0);
+            fma_window<R, QI, kRowList<R, QI, HALF>.dy[r]>(wr, w[r & 1], acc);
+            __builtin_amdgcn_sched_barrier(0);
+        });
+    }
 }
 
 // Granule = {fp32 value, tag} in one naturally aligned 8-byte word, moved by ONE agent-scope access:
