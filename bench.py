@@ -12,10 +12,13 @@ argmax -> uint8 label map [512,512].  One "step" = that whole path for `--batch`
 with edge/CAM tensors already resident in HBM.  Images shard over ranks with no collective on the
 data path (weak scaling: every rank processes its own `--batch` images per step).
 
-One JSON line on rank 0: metric/value (images/s, whole job), roofline of the sweep kernels
-(algorithmic bytes per sweep launch / measured HIP-event time per sweep vs 8 TB/s HBM peak) and a
-CPU baseline (oracle/walk_oracle.c, the fp64 C port of the same algorithm, timed on the host cores
-at N=1).
+One JSON line on rank 0: metric/value (images/s, whole job); `roofline` of the dominant kernel —
+the weights-stationary resident walk by default (one launch = all sweeps of the batch), the
+streaming sweep with --variant 1 (one launch = one sweep): algorithmic bytes per launch (SURVEY.md
+§8d: weights streamed once per sweep) / HIP-event time of the launch on the launch stream vs the
+8 TB/s HBM peak, plus the PMC-measured fabric traffic (profiles/traffic_walk.json) — and
+`cpu_baseline` (oracle/walk_oracle.c, the fp64 C port of the same algorithm, timed on the host
+cores at N=1 on 8 images).  Other legs: --workload walk_r5 | ins | coco | cam | e2e.
 """
 import argparse
 import json

@@ -541,9 +541,6 @@ extern "C" int irn_walk_set_option(irn_walk_ctx *ctx, const char *name, int valu
     } else if (!strcmp(name, "poll_delay")) {
         if (value < 0 || value > 1000) return fail(IRN_ERR_ARG, "poll_delay must be in [0,1000]");
         ctx->res_poll_delay = value;
-    } else if (!strcmp(name, "poll_stagger")) {
-        if (value < 0 || value > 1000) return fail(IRN_ERR_ARG, "poll_stagger must be in [0,1000]");
-        ctx->res_poll_stagger = value;
     } else if (!strcmp(name, "profile")) {
         if (value && !ctx->res_prof_dev) {
             IRN_HIP_TRY(hipMalloc((void **)&ctx->res_prof_dev, 2 * 256 * 4 * sizeof(long long)));

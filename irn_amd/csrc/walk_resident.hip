@@ -15,9 +15,12 @@
 //     neighbours x 4 px = 152 weight registers per lane; radius 5: Q = 2 x 34, four slabs per
 //     workgroup).  Each wave's part of the disc is a different, fully expanded instruction stream
 //     (wave-uniform switch), so every weight has a fixed register;
-//   * per sweep a wave forms, per neighbour row, an fp32 FMA chain (<= 19 terms) over a register
-//     window of the LDS-staged state and folds it into fp64; the Q partial sums of a pixel meet in
-//     LDS, get the centre term and 1/deg in fp64 (same numerics contract as walk.hip).
+//   * a step = (sweep t, channel c), c fastest.  Waves 4-7 poll and stage x_t[c] of the tile + halo into
+//     LDS (double-buffered); every wave forms, per neighbour row, an fp32 FMA chain (<= 19 terms) over
+//     a register window of the staged state and folds it into fp64; the Q partial sums of a pixel meet
+//     in LDS; waves 0-3 add the centre term, multiply by 1/deg in fp64 and store x_{t+1}[c] (same
+//     numerics contract as walk.hip).  Channels are independent chains: with C >= 2 the poll of the
+//     next step flies during the arithmetic of this one.
 //
 // Exchange between workgroups (tiles of one image; no kernel boundary between sweeps)
 //   state buffers hold one 8-byte granule {tag = sweep + 1, fp32 value} per pixel and channel, written
@@ -28,8 +31,9 @@
 //   after every reader of its x_t has finished reading.  Polls are bounded (wall clock): a
 //   workgroup that cannot make progress reports through `err` and the launch fails loudly.
 //
-// Scheduling: grid = one workgroup per CU.  The host packs images into rounds of <= #CU tiles
-// (tile = 8x32 px at radius 10, 16x64 at radius 5); workgroup b runs job[round][b] for every round.
+// Scheduling: grid = one workgroup per CU.  The host packs images into rounds of <= #CU tiles in
+// descending cost order (tile = 8x32 px at radius 10, 16x64 at radius 5); workgroup b runs
+// job[round][b] for every round.
 // Tiles of an image sit on consecutive slots of one XCD (slot -> block id b = idx*8 + xcd; observed
 // placement, speed only).  No grid-wide barrier exists, so rounds pipeline.
 #include <algorithm>
@@ -40,7 +44,6 @@ namespace irn {
 namespace {
 
 typedef unsigned long long u64;
-typedef u64 IRN_GLOBAL *gu64_t;
 typedef const double IRN_GLOBAL *gcd_t;
 typedef float IRN_GLOBAL *gf_t;
 typedef float f4a __attribute__((ext_vector_type(4)));
@@ -121,10 +124,6 @@ constexpr int row_hi(int dy) {
     return -1;
 }
 constexpr int floor4(int v) { return v >= 0 ? v / 4 * 4 : -((-v + 3) / 4 * 4); }
-
-struct Job {
-    int img, ty0, tx0, pad;
-};
 
 // ---- per-job: weights of this lane's 4 pixels for the wave's part of the disc -> registers ----
 template <int R, int QI>
@@ -281,7 +280,7 @@ __global__ __launch_bounds__(256) void x0_granule_kernel(const WalkImg *__restri
 template <int R>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void resident_kernel(
     const WalkImg *__restrict__ imgs, const int4 *__restrict__ jobs, int n_rounds, int t_first, int t_count,
-    int t_total, unsigned *err, long long timeout_ticks, long long *prof, int poll_delay, int poll_stagger) {
+    int t_total, unsigned *err, long long timeout_ticks, long long *prof, int poll_delay) {
     using G = Geom<R>;
     constexpr int H = G::H, HP = G::HP, LH = G::LH, LW = G::LW, LWU = G::LWU, RG = G::RG, Q = G::Q, NK = G::NK;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -299,7 +298,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     if (tid == 0) *abort_flag = 0;
 
     float wr[G::NS][4];
-    // poll_delay / poll_stagger: units of s_sleep(1) = 64 clocks.  Fixed on purpose: steering the delay
+    // poll_delay: units of s_sleep(1) = 64 clocks.  Fixed on purpose: steering the delay
     // from hits and misses was tried twice and lost both times — a miss usually means a neighbour
     // was late, not that this workgroup polled early, so every tile backs off together (symmetric
     // steering: 3.6 us per sweep, late-only steering: 3.5 us and drifting, fixed: 2.7-3.0 us).
@@ -614,7 +613,7 @@ static int launch_resident(irn_walk_ctx *ctx, int t_first, int t_count, int t_to
     const long long timeout_ticks = 200000000LL;   // 2 s of the 100 MHz wall clock
     hipLaunchKernelGGL((resident_kernel<R>), dim3(ctx->res_nwg), dim3(512), G::LDS_BYTES, stream, ctx->imgs_dev,
                        ctx->res_jobs_dev, ctx->res_rounds, t_first, t_count, t_total, ctx->res_err_dev, timeout_ticks,
-                       ctx->res_prof_dev, ctx->res_poll_delay, ctx->res_poll_stagger);
+                       ctx->res_prof_dev, ctx->res_poll_delay);
     IRN_LAUNCH_CHECK("resident_kernel");
     return IRN_OK;
 }
