@@ -119,3 +119,30 @@ def test_cam_merge_kernel_vs_oracle_and_reference_golden(golden):
         tk, tc, th = make_cam.merge_scales_torch([torch.from_numpy(o).to(dev) for o in outs], (H, W),
                                                  torch.from_numpy(label).to(dev))
         assert torch.equal(tk, keys) and (tc - cam).abs().max().item() <= 1e-5 and (th - hi).abs().max().item() <= 1e-5
+
+
+def test_bench_contract_one_json_line():
+    """python bench.py (small batch) prints ONE JSON line with the driver's fields, the `roofline` object of
+    the dominant kernel and the `cpu_baseline` object."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "2", "--warmup", "1", "--batch", "8",
+                          "--cpu-images", "1"], capture_output=True, text=True, timeout=600, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    r = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in r, key
+    assert r["unit"] == "images/s" and r["n_gpus"] == 1 and r["steps"] == 2 and r["scaling"] == "weak"
+    assert r["higher_is_better"] is True and r["vs_baseline"] is None and r["data"] == "synthetic" and r["dtype"] == "f32"
+    assert "workload" in r["config"] and "model" not in r["config"]
+    rf = r["roofline"]
+    assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9 and rf["achieved"] > 0 and "traffic" in rf
+    assert abs(r["value"] - 2 * 8 / (r["ms_per_step"] * 2e-3)) / r["value"] < 1e-6
+    cb = r["cpu_baseline"]
+    assert cb["kind"] in ("port", "reference") and cb["cores"] >= 1 and cb["value"] > 0 and cb["unit"] == "images/s" and cb["sample"]
