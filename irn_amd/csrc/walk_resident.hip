@@ -156,7 +156,8 @@ __device__ __forceinline__ void load_weights(float (&wr)[Geom<R>::NS][4], const 
 // ---- per sweep and channel: this wave's partial sums for its 4 pixels ----
 // Neighbour rows of wave part QI that belong to HALF (0: the rows up to and including the one that
 // crosses the half-way point of the part, 1: the rest; radius 5 keeps everything in half 0 — the split
-// pushed that instantiation into scratch).  The C = 2 schedule issues a poll between the halves.
+// pushed that instantiation into scratch; HALF 2 = all rows in one piece).  The C = 2 schedule issues a
+// poll between the halves; the other schedules run the whole part as one pipeline.
 template <int R, int QI, int HALF>
 struct RowList {
     int n = 0;
@@ -167,7 +168,7 @@ struct RowList {
             const int lo = row_lo<R, QI>(y), hi = row_hi<R, QI>(y);
             if (lo > hi) continue;
             const bool first_half = R == 5 || lo - QI * NS < NS / 2;
-            if (first_half == (HALF == 0)) dy[n++] = y;
+            if (HALF == 2 || first_half == (HALF == 0)) dy[n++] = y;
         }
     }
 };
@@ -219,7 +220,7 @@ __device__ __forceinline__ void fma_window(const float (&wr)[Geom<R>::NS][4], co
 template <int R, int QI, int HALF>
 __device__ __forceinline__ void partial_sums(const float (&wr)[Geom<R>::NS][4], const float *xrow, double (&acc)[4]) {
     constexpr int NR = kRowList<R, QI, HALF>.n;
-    if constexpr (HALF == 0) acc[0] = acc[1] = acc[2] = acc[3] = 0.0;
+    if constexpr (HALF != 1) acc[0] = acc[1] = acc[2] = acc[3] = 0.0;
     if constexpr (NR > 0 && R == 5) {
         // radius 5: row after row (the double-buffered order spills in that instantiation)
         static_for<NR>([&](auto ir) __attribute__((always_inline)) {
@@ -448,28 +449,42 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             {
                 const float *xrow = xsb + (ly + H) * LW + lx + HP;
                 double acc[4];
-                switch (qi) {
-                    case 0: partial_sums<R, 0, 0>(wr, xrow, acc); break;
-                    case 1: partial_sums<R, 1 % Q, 0>(wr, xrow, acc); break;
-                    case 2: partial_sums<R, 2 % Q, 0>(wr, xrow, acc); break;
-                    case 3: partial_sums<R, 3 % Q, 0>(wr, xrow, acc); break;
-                    case 4: partial_sums<R, 4 % Q, 0>(wr, xrow, acc); break;
-                    case 5: partial_sums<R, 5 % Q, 0>(wr, xrow, acc); break;
-                    case 6: partial_sums<R, 6 % Q, 0>(wr, xrow, acc); break;
-                    default: partial_sums<R, 7 % Q, 0>(wr, xrow, acc); break;
-                }
-                // C = 2: the next step's chain was stored at the end of the previous step; half-way through the
-                // arithmetic (~0.7 us behind those stores) its poll goes out and flies under the rest
-                if (polled && poller && C == 2) issue(state_rsrc(tn), cn * ch_bytes);
-                switch (qi) {
-                    case 0: partial_sums<R, 0, 1>(wr, xrow, acc); break;
-                    case 1: partial_sums<R, 1 % Q, 1>(wr, xrow, acc); break;
-                    case 2: partial_sums<R, 2 % Q, 1>(wr, xrow, acc); break;
-                    case 3: partial_sums<R, 3 % Q, 1>(wr, xrow, acc); break;
-                    case 4: partial_sums<R, 4 % Q, 1>(wr, xrow, acc); break;
-                    case 5: partial_sums<R, 5 % Q, 1>(wr, xrow, acc); break;
-                    case 6: partial_sums<R, 6 % Q, 1>(wr, xrow, acc); break;
-                    default: partial_sums<R, 7 % Q, 1>(wr, xrow, acc); break;
+                if (R == 10 && C == 2) {
+                    switch (qi) {
+                        case 0: partial_sums<R, 0, 0>(wr, xrow, acc); break;
+                        case 1: partial_sums<R, 1 % Q, 0>(wr, xrow, acc); break;
+                        case 2: partial_sums<R, 2 % Q, 0>(wr, xrow, acc); break;
+                        case 3: partial_sums<R, 3 % Q, 0>(wr, xrow, acc); break;
+                        case 4: partial_sums<R, 4 % Q, 0>(wr, xrow, acc); break;
+                        case 5: partial_sums<R, 5 % Q, 0>(wr, xrow, acc); break;
+                        case 6: partial_sums<R, 6 % Q, 0>(wr, xrow, acc); break;
+                        default: partial_sums<R, 7 % Q, 0>(wr, xrow, acc); break;
+                    }
+                    // C = 2: the next step's chain was stored at the end of the previous step; half-way through
+                    // the arithmetic (~0.7 us behind those stores) its poll goes out and flies under the rest
+                    if (polled && poller) issue(state_rsrc(tn), cn * ch_bytes);
+                    switch (qi) {
+                        case 0: partial_sums<R, 0, 1>(wr, xrow, acc); break;
+                        case 1: partial_sums<R, 1 % Q, 1>(wr, xrow, acc); break;
+                        case 2: partial_sums<R, 2 % Q, 1>(wr, xrow, acc); break;
+                        case 3: partial_sums<R, 3 % Q, 1>(wr, xrow, acc); break;
+                        case 4: partial_sums<R, 4 % Q, 1>(wr, xrow, acc); break;
+                        case 5: partial_sums<R, 5 % Q, 1>(wr, xrow, acc); break;
+                        case 6: partial_sums<R, 6 % Q, 1>(wr, xrow, acc); break;
+                        default: partial_sums<R, 7 % Q, 1>(wr, xrow, acc); break;
+                    }
+                } else {
+                    switch (qi) {
+                        case 0: partial_sums<R, 0, 2>(wr, xrow, acc); break;
+                        case 1: partial_sums<R, 1 % Q, 2>(wr, xrow, acc); break;
+                        case 2: partial_sums<R, 2 % Q, 2>(wr, xrow, acc); break;
+                        case 3: partial_sums<R, 3 % Q, 2>(wr, xrow, acc); break;
+                        case 4: partial_sums<R, 4 % Q, 2>(wr, xrow, acc); break;
+                        case 5: partial_sums<R, 5 % Q, 2>(wr, xrow, acc); break;
+                        case 6: partial_sums<R, 6 % Q, 2>(wr, xrow, acc); break;
+                        default: partial_sums<R, 7 % Q, 2>(wr, xrow, acc); break;
+                    }
+                    if (polled && poller && C == 2) issue(state_rsrc(tn), cn * ch_bytes);   // radius 5
                 }
                 double *pw = part + (k & 1) * (kWaves * 256) + wv * 256 + lane;
 #pragma unroll
