@@ -278,7 +278,9 @@ __global__ __launch_bounds__(256) void x0_granule_kernel(const WalkImg *__restri
     }
 }
 
-template <int R>
+// PROF: per-step time stamps for tools/resident_profile.py (its own instantiation: the stamp pointer would
+// cost the production kernel two live VGPRs per lane, and it sits exactly at the 256-register limit)
+template <int R, bool PROF>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void resident_kernel(
     const WalkImg *__restrict__ imgs, const int4 *__restrict__ jobs, int n_rounds, int t_first, int t_count,
     int t_total, unsigned *err, long long timeout_ticks, long long *prof, int poll_delay) {
@@ -390,9 +392,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             const unsigned want = (unsigned)(t + 1);
             float *xsb = xs + (k & 1) * (LH * LW);
             long long *pslot = nullptr;   // diagnostic time stamps of round 0 for two workgroups
-            if (prof && round == 0 && tid == 0 && (blockIdx.x == 0 || blockIdx.x == gridDim.x / 2) && k < 256)
+            if (PROF && prof && round == 0 && tid == 0 && (blockIdx.x == 0 || blockIdx.x == gridDim.x / 2) && k < 256)
                 pslot = prof + ((blockIdx.x == 0 ? 0 : 256) + k) * 4;
-            if (pslot) pslot[0] = wall_clock64();
+            if (PROF && pslot) pslot[0] = wall_clock64();
 
             // ---- [A] poll + stage x_t[c] of the tile and its halo (polling waves) ----
             // All tiles of an image run in lock step, so nothing is ready right after our own stores:
@@ -432,7 +434,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             }
             __syncthreads();
             if (*abort_flag) return;
-            if (pslot) pslot[1] = wall_clock64();
+            if (PROF && pslot) pslot[1] = wall_clock64();
 
             // ---- [B] prefetch: the next step's poll is issued as soon as its input can be there ----
             // chain cn was stored C-1 steps ago: long ago for C >= 3 (issue before the arithmetic), at the
@@ -490,7 +492,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #pragma unroll
                 for (int j = 0; j < 4; ++j) pw[j * 64] = acc[j];
                 __syncthreads();
-                if (pslot) pslot[2] = wall_clock64();
+                if (PROF && pslot) pslot[2] = wall_clock64();
 #pragma unroll
                 for (int i = tid; i < (poller ? 0 : G::SLABS * 256); i += 256) {
                     const int s2 = i >> 8, j = (i >> 6) & 3, l2 = i & 63;
@@ -512,7 +514,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             // C = 1: the next poll is timed from our own stores, so every wave has to start its delay
             // behind them (the waves that do not combine would otherwise poll ~0.2 us early)
             if (C == 1) __syncthreads();
-            if (pslot) pslot[3] = wall_clock64();
+            if (PROF && pslot) pslot[3] = wall_clock64();
             t = tn;
             c = cn;
         }
@@ -616,17 +618,17 @@ int resident_configure(irn_walk_ctx *ctx) {
     return IRN_OK;
 }
 
-template <int R>
+template <int R, bool PROF>
 static int launch_resident(irn_walk_ctx *ctx, int t_first, int t_count, int t_total, hipStream_t stream) {
     using G = Geom<R>;
     static bool attr_set = false;
     if (!attr_set) {
-        IRN_HIP_TRY(hipFuncSetAttribute((const void *)resident_kernel<R>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        IRN_HIP_TRY(hipFuncSetAttribute((const void *)resident_kernel<R, PROF>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                         G::LDS_BYTES));
         attr_set = true;
     }
     const long long timeout_ticks = 200000000LL;   // 2 s of the 100 MHz wall clock
-    hipLaunchKernelGGL((resident_kernel<R>), dim3(ctx->res_nwg), dim3(512), G::LDS_BYTES, stream, ctx->imgs_dev,
+    hipLaunchKernelGGL((resident_kernel<R, PROF>), dim3(ctx->res_nwg), dim3(512), G::LDS_BYTES, stream, ctx->imgs_dev,
                        ctx->res_jobs_dev, ctx->res_rounds, t_first, t_count, t_total, ctx->res_err_dev, timeout_ticks,
                        ctx->res_prof_dev, ctx->res_poll_delay);
     IRN_LAUNCH_CHECK("resident_kernel");
@@ -642,8 +644,13 @@ int resident_run(irn_walk_ctx *ctx, int n_sweeps, hipStream_t stream) {
     const int step = ctx->res_sweeps_per_launch > 0 ? ctx->res_sweeps_per_launch : n_sweeps;
     for (int t = 0; t < n_sweeps; t += step) {
         const int cnt = std::min(step, n_sweeps - t);
-        const int rc = ctx->radius == 10 ? launch_resident<10>(ctx, t, cnt, n_sweeps, stream)
-                                         : launch_resident<5>(ctx, t, cnt, n_sweeps, stream);
+        int rc;
+        if (ctx->res_prof_dev)
+            rc = ctx->radius == 10 ? launch_resident<10, true>(ctx, t, cnt, n_sweeps, stream)
+                                   : launch_resident<5, true>(ctx, t, cnt, n_sweeps, stream);
+        else
+            rc = ctx->radius == 10 ? launch_resident<10, false>(ctx, t, cnt, n_sweeps, stream)
+                                   : launch_resident<5, false>(ctx, t, cnt, n_sweeps, stream);
         if (rc) return rc;
     }
     IRN_HIP_TRY(hipMemcpyAsync(ctx->res_err_host, ctx->res_err_dev, 4 * sizeof(unsigned), hipMemcpyDeviceToHost, stream));
