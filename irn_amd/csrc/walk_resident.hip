@@ -92,7 +92,8 @@ struct Geom {
     // (56 floats, the tight fit, was 2-3-way conflicted: 0.95 us of a 3.1 us sweep).
     static constexpr int LH = TH + 2 * H, LW = 96;
     static_assert(LW >= TW + 2 * HP && LW % 64 == 32, "LDS row stride");
-    static constexpr int NK = (LH * (TW + 2 * H) + 255) / 256;   // staged pixels per polling lane (waves 4-7)
+    static_assert((TW + 2 * H) % 2 == 0, "staged rows are polled in pixel pairs");
+    static constexpr int NK = (LH * ((TW + 2 * H) / 2) + 255) / 256;   // staged pixel PAIRS per polling lane (waves 4-7)
     static constexpr int LWU = TW + 2 * H;               // columns actually staged
     static constexpr int RG = LH * LWU;                  // staged pixels per channel
     static constexpr int D = kDisc<R>.n;
@@ -247,6 +248,7 @@ __device__ __forceinline__ void partial_sums(const float (&wr)[Geom<R>::NS][4], 
 // SGPRs and needs one 32-bit VGPR per item (64-bit flat addresses cost 2 and pushed the kernel
 // into scratch).
 typedef unsigned u2v __attribute__((ext_vector_type(2)));
+typedef unsigned u4v __attribute__((ext_vector_type(4)));
 constexpr int kSc1 = 16;
 __device__ __forceinline__ u2v ld_granule(__amdgpu_buffer_rsrc_t rsrc, int voff, int soff) {
     return __builtin_bit_cast(u2v, __builtin_amdgcn_raw_buffer_load_b64(rsrc, voff, soff, kSc1));
@@ -260,7 +262,6 @@ __device__ __forceinline__ void st_granule(__amdgpu_buffer_rsrc_t rsrc, int voff
 
 // two adjacent pixels' granules in ONE 16-byte write-through store (8-byte sc1 stores are one fabric write
 // each and cost ~2.7x per byte: MI355X guide, stores table); each 8-byte half is still written whole
-typedef unsigned u4v __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void st_granule2(__amdgpu_buffer_rsrc_t rsrc, int voff, int soff, unsigned tag, float v0, float v1) {
     u4v g;
     g.x = __float_as_uint(v0);
@@ -352,18 +353,33 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         // with vmcnt(0), i.e. for the write-through acknowledge of the stores as well (that put the
         // whole store latency, ~0.5 us, into every step); a polling wave never stores.
         const bool poller = wv >= 4;
-        // staged pixels of a polling lane (the same for every channel and sweep of the job): byte
-        // offset of the granule inside one channel (high bits) | LDS index (low 12 bits); positions
-        // outside the image are zeroed once here and never polled
+        // Staged pixel PAIRS of a polling lane (the same for every channel and sweep of the job): two adjacent
+        // granules come with ONE 16-byte load (half as many poll requests as one load per granule; each
+        // 8-byte half is read whole).  Per pair: granule index of its first pixel inside one channel (high
+        // bits) | LDS index (low 12 bits); vmask has one bit per HALF.  Positions outside the image are
+        // zeroed once here and never examined (their half of the load reads a neighbouring granule or, out
+        // of range, 0 from the bounds-checked buffer).
         unsigned btab[NK];
         unsigned vmask = 0;
 #pragma unroll
         for (int k = 0; k < NK; ++k) {
             const int i = (tid - 256) + k * 256;
-            const int ry = i / LWU, rx = i - ry * LWU;
-            const int yy = ty0 - H + ry, xx = tx0 - H + rx;
-            btab[k] = ((unsigned)(yy * w + xx) << 15) | (unsigned)(ry * LW + rx + (HP - H));
-            if (poller && i < RG && yy >= 0 && yy < h && xx >= 0 && xx < w) vmask |= 1u << k;
+            const int ry = i / (LWU / 2);
+            int rx = (i - ry * (LWU / 2)) * 2;
+            const int yy = ty0 - H + ry;
+            int xx = tx0 - H + rx;
+            bool second = true;
+            if (xx == -1) {          // pair straddling the left image edge: load (0, 1) instead and use its first half only
+                xx = 0;
+                rx += 1;
+                second = false;
+            }
+            const bool row_ok = poller && i < RG / 2 && yy >= 0 && yy < h;
+            const bool ok0 = row_ok && xx >= 0 && xx < w, ok1 = row_ok && second && xx >= 0 && xx + 1 < w;
+            // pairs without a valid half read granule 0 (in range, never examined)
+            btab[k] = ((ok0 ? (unsigned)(yy * w + xx) : 0u) << 15) | (unsigned)(ry * LW + rx + (HP - H));
+            if (ok0) vmask |= 1u << (2 * k);
+            if (ok1) vmask |= 2u << (2 * k);
         }
         for (int i = tid; i < 2 * LH * LW; i += 512) xs[i] = 0.f;
         __syncthreads();
@@ -384,15 +400,16 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             for (int d = 0; d < units; ++d) __builtin_amdgcn_s_sleep(1);
         };
         auto state_rsrc = [&](int tt) {
-            return __builtin_amdgcn_make_buffer_rsrc((void *)((tt & 1) ? I.xb : I.xa), 0, state_bytes, 0x00020000);
+            // + 16: the 16-byte poll of the last granule reaches one granule past the state (the workspace keeps
+            // >= 64 bytes of slack behind every state buffer)
+            return __builtin_amdgcn_make_buffer_rsrc((void *)((tt & 1) ? I.xb : I.xa), 0, state_bytes + 16, 0x00020000);
         };
-        // One poll slot of NK granules per polling lane.  Loads are unconditional (straight-line code):
-        // a lane's slots that fall outside the image or beyond the region read some other in-range
-        // granule or, out of range, 0 from the bounds-checked buffer — they are never examined.
-        u2v va[NK];
+        // One poll slot of NK granule pairs per polling lane.  Loads are unconditional (straight-line code).
+        u4v va[NK];
         auto issue = [&](__amdgpu_buffer_rsrc_t rs, int soff) __attribute__((always_inline)) {
 #pragma unroll
-            for (int kk = 0; kk < NK; ++kk) va[kk] = ld_granule(rs, (int)((btab[kk] >> 15) << 3), soff);
+            for (int kk = 0; kk < NK; ++kk)
+                va[kk] = __builtin_bit_cast(u4v, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)((btab[kk] >> 15) << 3), soff, kSc1));
         };
         int t = t_first, c = 0;
         bool fresh = true;             // first step of the job: its input has been there since before the launch
@@ -423,11 +440,16 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 long long t_start = 0;
                 for (;;) {
 #pragma unroll
-                    for (int kk = 0; kk < NK; ++kk)
-                        if (((pend >> kk) & 1u) && va[kk].y == want) {
+                    for (int kk = 0; kk < NK; ++kk) {
+                        if (((pend >> (2 * kk)) & 1u) && va[kk].y == want) {
                             xsb[btab[kk] & 0xfff] = __uint_as_float(va[kk].x);
-                            pend &= ~(1u << kk);
+                            pend &= ~(1u << (2 * kk));
                         }
+                        if (((pend >> (2 * kk)) & 2u) && va[kk].w == want) {
+                            xsb[(btab[kk] & 0xfff) + 1] = __uint_as_float(va[kk].z);
+                            pend &= ~(2u << (2 * kk));
+                        }
+                    }
                     if (!__builtin_amdgcn_ballot_w64(pend != 0)) break;
                     issue(src, c * ch_bytes);
                     const long long now = wall_clock64();
