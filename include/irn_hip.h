@@ -161,6 +161,32 @@ int irn_cam_merge(int n_scales, const float *const *src_dev, const int32_t *hs, 
                   void *scratch_dev, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Multi-scale input pipeline  (replaces the per-scale loop of VOC12ClassificationDatasetMSF.__getitem__,
+ * voc12/dataloader.py:191-201: pil_rescale misc/imutils.py:8-22 -> TorchvisionNormalize
+ * voc12/dataloader.py:65-78 -> HWC_to_CHW -> stack([img, flip(img, -1)])).
+ *
+ * The resampling is Pillow's 8-bit bicubic (Image.resize(size, Image.BICUBIC): separable, 22-bit fixed-point
+ * weights, int32 accumulation, 8-bit intermediate) and is bit-exact.
+ *
+ *   irn_bicubic_plan        host only: the fixed-point tap table of one axis (lo[out], count[out],
+ *                           weights[out * ksize]); call with null arrays to query ksize.
+ *   irn_bicubic_resize_u8   dev u8 [h, w, channels] -> dev u8 [hs, ws, channels]  (= misc/imutils.py pil_resize
+ *                           order 3); channels 1, 3 or 4; scratch: irn_bicubic_scratch_bytes.
+ *   irn_msf_pack            dev u8 [h, w, 3] -> for each scale s a dev fp32 [2, 3, hs[s], ws[s]]: resized,
+ *                           normalised through lut (dev fp32 [3 * 256], lut[c * 256 + v] = the fp32 value of
+ *                           (v / 255. - mean[c]) / std[c] computed in double), channel-major, image followed by
+ *                           its horizontal flip.  hs/ws equal to h/w skip the resize like the reference's
+ *                           `s == 1` branch.  scratch: max over scales of irn_bicubic_scratch_bytes(.., 3).
+ * ------------------------------------------------------------------------------------------- */
+int irn_bicubic_plan(int in_size, int out_size, int32_t *ksize, int32_t *lo, int32_t *count, int32_t *weights,
+                     size_t weights_capacity);
+size_t irn_bicubic_scratch_bytes(int h, int w, int hs, int ws, int channels);
+int irn_bicubic_resize_u8(const uint8_t *img_dev, int h, int w, int channels, int hs, int ws, uint8_t *out_dev,
+                          void *scratch_dev, void *stream);
+int irn_msf_pack(const uint8_t *img_dev, int h, int w, int n_scales, const int32_t *hs, const int32_t *ws,
+                 const float *lut_dev, float *const *out_dev, void *scratch_dev, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Instance front-end
  *   irn_find_centroids   replaces step/make_ins_seg_labels.py:18-56
  *       dp dev [2,h,w] -> centroids dev int32 [2,h,w]; float32 state, float64 increment in the

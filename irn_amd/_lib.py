@@ -45,6 +45,10 @@ _SIGS = {
     "irn_walk_export_weights": (i32, [vp, i32, vp, vp, vp, vp]),
     "irn_label_epilogue": (i32, [i32, ppv, pi32, pi32, pi32, pi32, pi32, f32, ppv, ppv, ppv, ppv, vp, vp]),
     "irn_cam_merge": (i32, [i32, ppv, pi32, pi32, i32, vp, i32, i32, i32, vp, vp, vp, vp]),
+    "irn_bicubic_plan": (i32, [i32, i32, pi32, pi32, pi32, pi32, sz]),
+    "irn_bicubic_scratch_bytes": (sz, [i32, i32, i32, i32, i32]),
+    "irn_bicubic_resize_u8": (i32, [vp, i32, i32, i32, i32, i32, vp, vp, vp]),
+    "irn_msf_pack": (i32, [vp, i32, i32, i32, pi32, pi32, vp, ppv, vp, vp]),
     "irn_find_centroids": (i32, [vp, i32, i32, i32, vp, vp]),
     "irn_cluster_scratch_bytes": (sz, [i32, i32]),
     "irn_cluster_centroids": (i32, [vp, vp, i32, i32, f32, vp, C.POINTER(i32), vp, vp]),

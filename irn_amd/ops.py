@@ -6,6 +6,8 @@ Reference functions mirrored (names kept where the reference has one):
     label4(mask)                = skimage.measure.label(mask, connectivity=1, background=0)  (:66,:92)
     label_epilogue(...)         = step/make_sem_seg_labels.py:43-49, step/make_ins_seg_labels.py:137-145
     detect_instance(...)        = step/make_ins_seg_labels.py:82-105
+    bicubic_resize(img, size)   = misc/imutils.py:8-17 pil_resize(img, size, order=3)
+    msf_pack(img, scales)       = voc12/dataloader.py:191-201 (rescale, normalise, CHW, flip pair)
 GPU tensors in, GPU tensors out; no CPU fallback.
 """
 import ctypes as C
@@ -93,6 +95,76 @@ def cam_merge(outputs, size, label):
                                 i32_array([o.shape[2] for o in outs]), n_cls, keys.data_ptr(), k, H, W, cam.data_ptr(),
                                 hi.data_ptr(), scratch.data_ptr(), _stream()))
     return keys, cam, hi
+
+
+_LUTS = {}
+
+
+def rescale_size(h, w, scale):
+    """misc/imutils.py:19-22: target size of pil_rescale (np.round: half to even)."""
+    return int(np.round(h * scale)), int(np.round(w * scale))
+
+
+def bicubic_plan(in_size, out_size):
+    """Host-only: Pillow's fixed-point bicubic tap table of one axis -> (lo [out], count [out], weights [out, ksize])."""
+    ks = C.c_int32()
+    check(lib.irn_bicubic_plan(int(in_size), int(out_size), C.byref(ks), None, None, None, 0))
+    lo = np.empty(out_size, np.int32)
+    cnt = np.empty(out_size, np.int32)
+    k = np.empty((out_size, ks.value), np.int32)
+    as_p = lambda a: a.ctypes.data_as(C.POINTER(C.c_int32))
+    check(lib.irn_bicubic_plan(int(in_size), int(out_size), C.byref(ks), as_p(lo), as_p(cnt), as_p(k), k.size))
+    return lo, cnt, k
+
+
+def bicubic_resize(img, size):
+    """GPU uint8 [H,W,C] (C in 1,3,4) or [H,W] -> GPU uint8 resized to size=(h,w); bit-identical to
+    np.asarray(Image.fromarray(img).resize(size[::-1], Image.BICUBIC)) (misc/imutils.py:8-17)."""
+    _need_cuda(img, "img")
+    if img.dtype != torch.uint8:
+        raise ValueError("bicubic_resize: uint8 image expected (Pillow's 8-bit path)")
+    squeeze = img.dim() == 2
+    src = (img[..., None] if squeeze else img).contiguous()
+    h, w, ch = src.shape
+    hs, ws = int(size[0]), int(size[1])
+    if (hs, ws) == (h, w):
+        return img
+    out = torch.empty((hs, ws, ch), dtype=torch.uint8, device=src.device)
+    scratch = torch.empty(max(lib.irn_bicubic_scratch_bytes(h, w, hs, ws, ch), 1), dtype=torch.uint8, device=src.device)
+    with torch.cuda.device(src.device):
+        check(lib.irn_bicubic_resize_u8(src.data_ptr(), h, w, ch, hs, ws, out.data_ptr(), scratch.data_ptr(), _stream()))
+    return out[..., 0] if squeeze else out
+
+
+def normalize_lut(mean=(0.485, 0.456, 0.406), std=(0.229, 0.224, 0.225)):
+    """fp32 [3,256]: TorchvisionNormalize (voc12/dataloader.py:65-78) of every byte value, computed in float64
+    and stored as float32 exactly like the reference's `proc_img[..., c] = (imgarr[..., c] / 255. - mean) / std`."""
+    v = np.arange(256, dtype=np.uint8)
+    return np.stack([((v / 255. - mean[c]) / std[c]).astype(np.float32) for c in range(3)])
+
+
+def msf_pack(img, scales, mean=(0.485, 0.456, 0.406), std=(0.229, 0.224, 0.225)):
+    """GPU uint8 [H,W,3] -> list over scales of GPU fp32 [2,3,Hs,Ws]: the `img` entry of a
+    VOC12ClassificationDatasetMSF item (voc12/dataloader.py:191-201), bit-identical to the PIL/numpy path."""
+    _need_cuda(img, "img")
+    if img.dtype != torch.uint8 or img.dim() != 3 or img.shape[2] != 3:
+        raise ValueError("msf_pack: uint8 [H,W,3] image expected")
+    src = img.contiguous()
+    dev = src.device
+    h, w = int(src.shape[0]), int(src.shape[1])
+    sizes = [(h, w) if s == 1 else rescale_size(h, w, s) for s in scales]
+    key = ("msf_lut", tuple(mean), tuple(std), str(dev))
+    lut = _LUTS.get(key)
+    if lut is None:
+        lut = _LUTS[key] = torch.from_numpy(normalize_lut(mean, std)).to(dev).contiguous()
+    outs = [torch.empty((2, 3, hs, ws), dtype=torch.float32, device=dev) for hs, ws in sizes]
+    nbytes = max([lib.irn_bicubic_scratch_bytes(h, w, hs, ws, 3) for hs, ws in sizes] + [1])
+    scratch = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        check(lib.irn_msf_pack(src.data_ptr(), h, w, len(sizes), i32_array([s[0] for s in sizes]),
+                               i32_array([s[1] for s in sizes]), lut.data_ptr(), ptr_array([o.data_ptr() for o in outs]),
+                               scratch.data_ptr(), _stream()))
+    return outs
 
 
 def find_centroids_with_refinement(displacement, iterations=300):

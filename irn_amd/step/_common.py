@@ -30,6 +30,23 @@ def spawn_workers(work, model, shards, args):
         multiprocessing.spawn(work, nprocs=n, args=(model, shards, args), join=True)
 
 
+def device_preprocess(args):
+    """Steps build the multi-scale inputs on the GPU unless args.device_preprocess is set to False."""
+    return bool(getattr(args, "device_preprocess", True))
+
+
+def device_images(pack, scales, normal=None):
+    """Loader item -> list over scales of GPU fp32 [2,3,Hs,Ws] (image + horizontal flip).  Raw uint8 items
+    (dataset raw=True) go through irn_msf_pack; items already in the reference's format are copied as is."""
+    img = pack["img"]
+    if torch.is_tensor(img) and img.dtype == torch.uint8:
+        from .. import ops
+        kw = {} if normal is None else {"mean": normal.mean, "std": normal.std}
+        return ops.msf_pack(img[0].cuda(non_blocking=True), scales, **kw)
+    imgs = img if isinstance(img, (list, tuple)) else [img]
+    return [i[0].cuda(non_blocking=True) for i in imgs]
+
+
 def progress(process_id, n_workers, it, n_items):
     """The reference prints 5 % ticks from the last rank and divides by len//20 (ZeroDivision for
     shards under 20 images, step/make_cam.py:58); guarded here."""

@@ -5,6 +5,8 @@ Reads  args.cam_network, args.cam_weights_name(+'.pth'), args.train_list, args.v
 Writes args.cam_out_dir/<name>.npy = {"keys": LongTensor[K], "cam": FloatTensor[K,h,w] (cpu),
        "high_res": float32 ndarray [K,H,W]}   (same pickle schema as step/make_cam.py:55-56)
 
+The per-scale inputs are built on the GPU from the decoded uint8 image (irn_msf_pack: Pillow-exact bicubic,
+normalise, flip pair; args.device_preprocess=False keeps the reference's PIL loop in the loader workers).
 The ResNet-50 forward passes run on PyTorch-ROCm (MIOpen); the merge (step/make_cam.py:38-52) is
 one HIP kernel pair (irn_cam_merge).  One process per GPU over strided shards, no communication.
 """
@@ -63,8 +65,8 @@ def _work(process_id, model, dataset, args):
             img_name = pack["name"][0]
             label = pack["label"][0]
             size = (int(pack["size"][0]), int(pack["size"][1]))
-            imgs = pack["img"] if isinstance(pack["img"], (list, tuple)) else [pack["img"]]
-            outputs = [model(img[0].cuda(non_blocking=True)) for img in imgs]
+            scales = tuple(float(s) for s in args.cam_scales)
+            outputs = [model(img) for img in _common.device_images(pack, scales)]
             keys, cam, high_res = merge_scales(outputs, size, label.cuda())
             writer.submit(np.save, os.path.join(args.cam_out_dir, img_name + ".npy"),
                           {"keys": keys.cpu(), "cam": cam.cpu(), "high_res": high_res.cpu().numpy()})
@@ -79,7 +81,7 @@ def run(args):
     n_gpus = _common.n_gpus_or_raise()
     scales = tuple(float(s) for s in args.cam_scales)
     dataset = voc12_dataloader.VOC12ClassificationDatasetMSF(args.train_list, voc12_root=args.voc12_root,
-                                                             scales=scales)
+                                                             scales=scales, raw=_common.device_preprocess(args))
     dataset = torchutils.split_dataset(dataset, n_gpus)
     os.makedirs(args.cam_out_dir, exist_ok=True)
     print("[ ", end="")

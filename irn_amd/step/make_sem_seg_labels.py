@@ -57,7 +57,7 @@ def _work(process_id, model, dataset, args):
             if not isinstance(name, str):
                 name = voc12_dataloader.decode_int_filename(name)
             size = (int(pack["size"][0]), int(pack["size"][1]))
-            edge, _dp = model(pack["img"][0].cuda(non_blocking=True))
+            edge, _dp = model(_common.device_images(pack, (1.0,))[0])
             cam_dict = np.load(os.path.join(args.cam_out_dir, name + ".npy"), allow_pickle=True).item()
             pend.append({"name": name, "size": size, "edge": edge,
                          "cam": torch.as_tensor(cam_dict["cam"]).cuda(),
@@ -76,7 +76,7 @@ def run(args):
     model.eval()
     n_gpus = _common.n_gpus_or_raise()
     dataset = voc12_dataloader.VOC12ClassificationDatasetMSF(args.infer_list, voc12_root=args.voc12_root,
-                                                             scales=(1.0,))
+                                                             scales=(1.0,), raw=_common.device_preprocess(args))
     dataset = torchutils.split_dataset(dataset, n_gpus)
     os.makedirs(args.sem_seg_out_dir, exist_ok=True)
     print("[", end="")

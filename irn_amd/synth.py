@@ -87,3 +87,21 @@ def voc_num_classes(seed):
 def voc_keys(k, seed):
     """Sorted 0-based class ids, the ``keys`` entry of a CAM dict (step/make_cam.py:46)."""
     return np.sort(_rng(seed + 32452843).choice(20, k, replace=False)).astype(np.int64)
+
+
+def photo(h, w, seed=0):
+    """uint8 [h,w,3] photo-like image: smooth colour fields, hard-edged saturated rectangles (the bicubic
+    overshoot there exercises the 0/255 clipping) and sensor-like noise."""
+    rng = _rng(seed)
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float64)
+    img = np.zeros((h, w, 3))
+    for c in range(3):
+        fy, fx, ph = rng.uniform(0.5, 3.0), rng.uniform(0.5, 3.0), rng.uniform(0, 6.28)
+        img[..., c] = 128 + 90 * np.sin(fy * yy / h * 6.28 + ph) * np.cos(fx * xx / w * 6.28)
+    for _ in range(4):
+        y0, x0 = int(rng.randint(0, max(h - 2, 1))), int(rng.randint(0, max(w - 2, 1)))
+        y1, x1 = y0 + int(rng.randint(1, max(h // 3, 2))), x0 + int(rng.randint(1, max(w // 3, 2)))
+        img[y0:y1, x0:x1] = rng.choice([0.0, 255.0], 3)
+    img += rng.normal(0, 6, img.shape)
+    return np.clip(np.rint(img), 0, 255).astype(np.uint8)
+

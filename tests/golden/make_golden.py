@@ -314,10 +314,48 @@ def gen_nets():
         r50.model_zoo.load_url = real_load
 
 
+def gen_msf():
+    """Multi-scale dataset item: the reference's own VOC12ClassificationDatasetMSF.__getitem__
+    (voc12/dataloader.py:185-205) on synthetic photos (imageio.imread stubbed to hand them over), i.e.
+    misc/imutils.pil_rescale -> installed Pillow's Image.resize(BICUBIC) -> TorchvisionNormalize -> CHW ->
+    flip pair; plus raw Pillow resizes (via the reference's pil_resize) of ragged sizes."""
+    import PIL
+    from misc import imutils
+    import voc12.dataloader as vd
+    out = {"pillow_version": np.asarray(PIL.__version__)}
+    scales = (1.0, 0.5, 1.5, 2.0)
+    out["scales"] = np.asarray(scales)
+    cases = {"a": (45, 60), "b": (53, 37)}
+    for name, (h, w) in cases.items():
+        img = synth.photo(h, w, seed=500 + h)
+        sys.modules["imageio"].imread = lambda path, _img=img: _img
+        ds = vd.VOC12ClassificationDatasetMSF.__new__(vd.VOC12ClassificationDatasetMSF)
+        ds.img_name_list = np.asarray([2007000032])
+        ds.label_list = np.zeros((1, 20), np.float32)
+        ds.voc12_root = "/nonexistent"
+        ds.img_normal = vd.TorchvisionNormalize()
+        ds.scales = scales
+        item = ds[0]
+        out["%s_img" % name] = img
+        for i, arr in enumerate(item["img"]):
+            out["%s_item%d" % (name, i)] = np.ascontiguousarray(arr)
+        assert item["size"] == (h, w)
+    rng = np.random.default_rng(7)
+    sizes = [((31, 47), (97, 13)), ((64, 64), (17, 64)), ((9, 200), (9, 77)), ((120, 90), (1, 1)), ((5, 3), (40, 41))]
+    for i, ((h, w), tgt) in enumerate(sizes):
+        img = synth.photo(h, w, seed=600 + i) if i % 2 == 0 else rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        out["resize%d_img" % i] = img
+        out["resize%d_out" % i] = np.asarray(imutils.pil_resize(img, tgt, 3))
+    gray = synth.photo(40, 50, seed=650)[..., 0].copy()
+    out["gray_img"] = gray
+    out["gray_out"] = np.asarray(imutils.pil_resize(gray, (61, 33), 3))
+    np.savez_compressed(os.path.join(OUT, "msf.npz"), **out)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", nargs="*", default=None,
-                    help="subset of: path affinity affinity_grad walk semseg instance cam_merge nets; or walk case names")
+                    help="subset of: path affinity affinity_grad walk semseg instance cam_merge nets msf; or walk case names")
     a = ap.parse_args()
     _install_reference()
     torch.set_num_threads(os.cpu_count())
@@ -343,6 +381,8 @@ def main():
         gen_cam_merge()
     if want("nets"):
         gen_nets()
+    if want("msf"):
+        gen_msf()
 
 
 if __name__ == "__main__":

@@ -65,6 +65,16 @@ def test_steps_end_to_end(tmp_path):
         # the reference's readers: keys + 1 padded (make_sem_seg_labels.py:37), cam.cuda() (:39)
         assert np.pad(d["keys"] + 1, (1, 0), mode="constant")[0] == 0
 
+    # default = inputs built on the GPU (irn_msf_pack); the reference's PIL loop in the loader gives the same files
+    ref_args = argparse.Namespace(**{**vars(args), "cam_out_dir": str(tmp_path / "cam_pil"), "device_preprocess": False})
+    os.makedirs(ref_args.cam_out_dir)
+    make_cam.run(ref_args)
+    for n in names:
+        a = np.load(os.path.join(args.cam_out_dir, n + ".npy"), allow_pickle=True).item()
+        b = np.load(os.path.join(ref_args.cam_out_dir, n + ".npy"), allow_pickle=True).item()
+        assert torch.equal(a["keys"], b["keys"])
+        assert (a["cam"] - b["cam"]).abs().max().item() <= 1e-5 and np.abs(a["high_res"] - b["high_res"]).max() <= 1e-5
+
     make_sem_seg_labels.run(args)
     for n in names:
         png = np.asarray(Image.open(os.path.join(args.sem_seg_out_dir, n + ".png")))

@@ -109,3 +109,31 @@ def test_async_writer_writes_everything_and_surfaces_errors(tmp_path):
     w.submit(np.save, str(tmp_path / "no_such_dir" / "x.npy"), 1)
     with pytest.raises(Exception):
         w.close()
+
+
+def test_bicubic_plan_host_table_equals_oracle():
+    """irn_bicubic_plan is host-only (no GPU): the fixed-point tap tables the kernels consume are Pillow's."""
+    from irn_amd import ops
+    from oracle import msf_oracle as M
+    for n_in, n_out in [(500, 250), (375, 188), (375, 562), (500, 1000), (7, 3), (333, 334), (281, 1), (3, 40)]:
+        lo, cnt, k = ops.bicubic_plan(n_in, n_out)
+        a, b, c = M.bicubic_coeffs(n_in, n_out)
+        assert np.array_equal(lo, a) and np.array_equal(cnt, b) and np.array_equal(k, c), (n_in, n_out)
+    lo, cnt, k = ops.bicubic_plan(64, 64)                    # identity plan = "pass skipped"
+    assert np.array_equal(lo, np.arange(64)) and (cnt == 1).all() and (k == 1 << 22).all()
+
+
+def test_normalize_lut_equals_reference_normalisation():
+    from irn_amd import ops
+    from irn_amd.voc12.dataloader import TorchvisionNormalize
+    img = np.random.RandomState(1).randint(0, 256, (9, 11, 3)).astype(np.uint8)
+    lut = ops.normalize_lut()
+    assert np.array_equal(TorchvisionNormalize()(img), np.stack([lut[c][img[..., c]] for c in range(3)], -1))
+
+
+def test_msf_pack_refuses_cpu_tensors():
+    from irn_amd import ops
+    with pytest.raises(ValueError, match="GPU tensor"):
+        ops.msf_pack(torch.zeros((4, 4, 3), dtype=torch.uint8), (1.0,))
+    with pytest.raises(ValueError, match="GPU tensor"):
+        ops.bicubic_resize(torch.zeros((4, 4, 3), dtype=torch.uint8), (2, 2))

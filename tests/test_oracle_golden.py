@@ -150,3 +150,49 @@ def test_affinity_backward_restatement_vs_reference_autograd(golden, r):
     ag = golden("affinity_grad")
     ge = O.edge_to_affinity_backward(ag["r%d_edge" % r], ag["r%d_gout" % r], r)
     assert np.abs(ge - ag["r%d_gedge" % r]).max() <= 1e-5 * np.abs(ag["r%d_gedge" % r]).max()
+
+
+# ------------------------------------------------------------------------------------------------
+# Multi-scale input pipeline (oracle/msf_oracle.py): Pillow's 8-bit bicubic + the reference's item
+# construction, pinned on outputs of the reference's own dataset class over the installed Pillow.
+# ------------------------------------------------------------------------------------------------
+def test_msf_item_restatement_vs_reference_dataset(golden):
+    from oracle import msf_oracle as M
+    d = golden("msf")
+    for name in "ab":
+        items = M.msf_item(d[name + "_img"], d["scales"])
+        assert len(items) == 4
+        for i, it in enumerate(items):
+            g = d["%s_item%d" % (name, i)]
+            assert it.dtype == np.float32 and it.shape == g.shape
+            assert np.array_equal(it, g), (name, i)
+
+
+def test_pil_bicubic_restatement_vs_pillow_golden(golden):
+    from oracle import msf_oracle as M
+    d = golden("msf")
+    for i in range(5):
+        want = d["resize%d_out" % i]
+        assert np.array_equal(M.pil_bicubic_resize(d["resize%d_img" % i], want.shape[:2]), want), i
+    assert np.array_equal(M.pil_bicubic_resize(d["gray_img"][..., None], (61, 33))[..., 0], d["gray_out"])
+
+
+def test_pil_bicubic_restatement_vs_live_pillow():
+    """Random sizes and scale factors against the installed Pillow (skipped where Pillow is absent)."""
+    Image = pytest.importorskip("PIL.Image")
+    from oracle import msf_oracle as M
+    rng = np.random.default_rng(3)
+    for t in range(24):
+        h, w = (int(v) for v in rng.integers(3, 90, 2))
+        s = float(rng.choice([0.5, 1.5, 2.0, 0.37, 1.01, 0.99, 3.3, 0.1]))
+        hs, ws = (max(v, 1) for v in M.rescale_size(h, w, s))
+        img = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        want = np.asarray(Image.fromarray(img).resize((ws, hs), Image.BICUBIC))
+        assert np.array_equal(M.pil_bicubic_resize(img, (hs, ws)), want), (h, w, s)
+
+
+def test_rescale_size_rounds_half_to_even():
+    from oracle import msf_oracle as M
+    assert M.rescale_size(375, 500, 0.5) == (188, 250)      # 187.5 -> 188
+    assert M.rescale_size(375, 500, 1.5) == (562, 750)      # 562.5 -> 562
+    assert M.rescale_size(281, 500, 0.5) == (140, 250)      # 140.5 -> 140
