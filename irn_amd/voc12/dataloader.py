@@ -81,7 +81,7 @@ class VOC12ClassificationDatasetMSF(Dataset):
         name_str = decode_int_filename(self.img_name_list[idx])
         img = np.asarray(Image.open(get_img_path(name_str, self.voc12_root)).convert("RGB"))
         if self.raw:
-            return {"name": name_str, "img": torch.from_numpy(np.ascontiguousarray(img)),
+            return {"name": name_str, "img": torch.from_numpy(np.array(img)),
                     "size": (img.shape[0], img.shape[1]), "label": torch.from_numpy(self.label_list[idx])}
         ms = []
         for s in self.scales:

@@ -73,7 +73,9 @@ def test_steps_end_to_end(tmp_path):
         a = np.load(os.path.join(args.cam_out_dir, n + ".npy"), allow_pickle=True).item()
         b = np.load(os.path.join(ref_args.cam_out_dir, n + ".npy"), allow_pickle=True).item()
         assert torch.equal(a["keys"], b["keys"])
-        assert (a["cam"] - b["cam"]).abs().max().item() <= 1e-5 and np.abs(a["high_res"] - b["high_res"]).max() <= 1e-5
+        # the inputs are bit-identical (tests/test_gpu_msf.py); the backbone is not run-to-run deterministic at the
+        # last bits (MIOpen picks solvers by timing), so the files are compared at the parity bar of SURVEY.md §8(d)
+        assert (a["cam"] - b["cam"]).abs().max().item() <= 1e-4 and np.abs(a["high_res"] - b["high_res"]).max() <= 1e-4
 
     make_sem_seg_labels.run(args)
     for n in names:
