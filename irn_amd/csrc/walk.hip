@@ -814,11 +814,14 @@ extern "C" int irn_walk_run(irn_walk_ctx *ctx, const float *const *edge_dev, con
     int rc = launch_affinity(ctx->jobs_dev, n, ctx->max_h, ctx->max_w, tab, true, beta, stream);
     if (rc) return rc;
     const int pix_blocks = cdiv(ctx->max_n, 256);
-    hipLaunchKernelGGL(degree_kernel, dim3(pix_blocks, n), dim3(256), 0, stream, ctx->imgs_dev, tab.dir_dy,
-                       tab.dir_dx, tab.n_dirs);
-    IRN_LAUNCH_CHECK("degree_kernel");
     const bool resident = ctx->variant == 2 && ctx->res_ok && n_sweeps > 0;
+    // the resident kernel sums the degree from the weights it holds in registers; the inv_deg array is then
+    // only filled on demand (irn_walk_export_weights)
+    ctx->deg_stale = resident;
     if (!resident) {
+        hipLaunchKernelGGL(degree_kernel, dim3(pix_blocks, n), dim3(256), 0, stream, ctx->imgs_dev, tab.dir_dy,
+                           tab.dir_dx, tab.n_dirs);
+        IRN_LAUNCH_CHECK("degree_kernel");
         hipLaunchKernelGGL(x0_kernel, dim3(pix_blocks, n), dim3(256), 0, stream, ctx->imgs_dev, n_sweeps == 0 ? 1 : 0);
         IRN_LAUNCH_CHECK("x0_kernel");
     }
@@ -913,6 +916,12 @@ extern "C" int irn_walk_export_weights(irn_walk_ctx *ctx, int image, float *w_de
         const float *src = (const float *)(ws + ctx->off_wts[image]) + ctx->front_pad[image];
         IRN_HIP_TRY(hipMemcpy2DAsync(w_dev, sizeof(float) * npx, src, sizeof(float) * ctx->plane_stride[image],
                                      sizeof(float) * npx, ctx->tab->n_dirs, hipMemcpyDeviceToDevice, stream));
+    }
+    if (inv_deg_dev && ctx->deg_stale) {
+        hipLaunchKernelGGL(degree_kernel, dim3(cdiv(ctx->max_n, 256), ctx->n), dim3(256), 0, stream, ctx->imgs_dev,
+                           ctx->tab->dir_dy, ctx->tab->dir_dx, ctx->tab->n_dirs);
+        IRN_LAUNCH_CHECK("degree_kernel");
+        ctx->deg_stale = false;
     }
     if (inv_deg_dev)
         IRN_HIP_TRY(hipMemcpyAsync(inv_deg_dev, ws + ctx->off_deg[image], sizeof(double) * npx,

@@ -154,6 +154,35 @@ __device__ __forceinline__ void load_weights(float (&wr)[Geom<R>::NS][4], const 
     });
 }
 
+// deg(p) - 1 = sum of the 2|S| directed weights of p (column sum of misc/indexing.py:135): this wave's part of it,
+// from the registers load_weights just filled, in fp64.  A backward weight whose source pixel lies outside
+// the image is whatever the linear address wrapped to (the sweeps multiply it by a zero state); it is left out here.
+template <int R, int QI>
+__device__ __forceinline__ void degree_partial(const float (&wr)[Geom<R>::NS][4], const WalkImg &I, int gy, int gx,
+                                               double (&ds)[4]) {
+    using G = Geom<R>;
+    ds[0] = ds[1] = ds[2] = ds[3] = 0.0;
+    // validity of a backward source as 0/1 FACTORS in VGPRs, one per column offset (dx + j) and per row: kept as
+    // per-neighbour lane masks the conditions needed ~150 SGPR pairs at once and spilled
+    float fx[2 * R + 2];
+#pragma unroll
+    for (int e = 0; e < 2 * R + 2; ++e) fx[e] = (unsigned)(gx + e - (R - 1)) < (unsigned)I.w ? 1.f : 0.f;
+    static_for<G::NS>([&](auto is) __attribute__((always_inline)) {
+        constexpr int s = QI * G::NS + decltype(is)::value;
+        constexpr int dy = kDisc<R>.dy[s], dx = kDisc<R>.dx[s];
+        constexpr bool fwd = dy > 0 || (dy == 0 && dx > 0);
+        if constexpr (fwd) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) ds[j] += (double)wr[decltype(is)::value][j];
+        } else {
+            const float fy = gy + dy >= 0 ? 1.f : 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) ds[j] += (double)(wr[decltype(is)::value][j] * (fx[dx + j + R - 1] * fy));
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    });
+}
+
 // ---- per sweep and channel: this wave's partial sums for its 4 pixels ----
 // Neighbour rows of wave part QI that belong to HALF (0: the rows up to and including the one that
 // crosses the half-way point of the part, 1: the rest; radius 5 keeps everything in half 0 — the split
@@ -329,24 +358,39 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         const unsigned n = (unsigned)(h * w);
         const int gy = ty0 + ly, gx = tx0 + lx;
 
+        double dsum[4];
+#define IRN_LOAD_PART(QI)                          \
+    load_weights<R, (QI) % Q>(wr, I, gy, gx);      \
+    degree_partial<R, (QI) % Q>(wr, I, gy, gx, dsum)
         switch (qi) {
-            case 0: load_weights<R, 0>(wr, I, gy, gx); break;
-            case 1: load_weights<R, 1 % Q>(wr, I, gy, gx); break;
-            case 2: load_weights<R, 2 % Q>(wr, I, gy, gx); break;
-            case 3: load_weights<R, 3 % Q>(wr, I, gy, gx); break;
-            case 4: load_weights<R, 4 % Q>(wr, I, gy, gx); break;
-            case 5: load_weights<R, 5 % Q>(wr, I, gy, gx); break;
-            case 6: load_weights<R, 6 % Q>(wr, I, gy, gx); break;
-            default: load_weights<R, 7 % Q>(wr, I, gy, gx); break;
+            case 0: IRN_LOAD_PART(0); break;
+            case 1: IRN_LOAD_PART(1); break;
+            case 2: IRN_LOAD_PART(2); break;
+            case 3: IRN_LOAD_PART(3); break;
+            case 4: IRN_LOAD_PART(4); break;
+            case 5: IRN_LOAD_PART(5); break;
+            case 6: IRN_LOAD_PART(6); break;
+            default: IRN_LOAD_PART(7); break;
         }
-        // 1/deg of the tile
-        __syncthreads();   // previous job's readers of invd / xs are done
+#undef IRN_LOAD_PART
+        // 1/deg of the tile: the waves' parts meet in LDS (the combine's partial-sum buffer), fp64 throughout
+        __syncthreads();   // previous job's readers of part / invd / xs are done
+        {
+            double *pw = part + wv * 256 + lane * 4;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) pw[j] = dsum[j];
+        }
+        __syncthreads();
 #pragma unroll
         for (int i = tid; i < G::SLABS * 256; i += 512) {     // [slab][row][column] like the combine's thread order
             const int s2 = i >> 8, prow = (i >> 5) & 7, x = i & 31;
             const int yy = ty0 + (s2 / G::C::SL_X) * kSlabH + prow;
             const int xx = tx0 + (s2 % G::C::SL_X) * kSlabW + x;
-            invd[i] = (yy < h && xx < w) ? ((gcd_t)I.inv_deg)[yy * w + xx] : 0.0;
+            const double *pr = part + (s2 * Q) * 256 + (prow * 8 + (x >> 2)) * 4 + (x & 3);
+            double deg = 1.0;
+#pragma unroll
+            for (int q = 0; q < Q; ++q) deg += pr[q * 256];
+            invd[i] = (yy < h && xx < w) ? 1.0 / deg : 0.0;
         }
         // Wave roles: waves 4-7 poll and stage the state, waves 0-3 combine and store it.  A wave
         // that issued divergent stores after its prefetched poll loads can only wait for those loads
