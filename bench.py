@@ -50,6 +50,8 @@ def parse():
     ap.add_argument("--streams", type=int, default=1, help="channel-chunk classes on separate streams (merged=0)")
     ap.add_argument("--merged", type=int, default=0, help="all channel-chunk widths in one launch per sweep")
     ap.add_argument("--probe", type=int, default=0, help="diagnostic: time the weight-streaming skeleton instead")
+    ap.add_argument("--walk-option", action="append", default=[], metavar="NAME=VALUE",
+                    help="extra irn_walk_set_option settings (tuning experiments), e.g. poll_delay=8")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-images", type=int, default=8)
     ap.add_argument("--json-out", default=None)
@@ -247,6 +249,9 @@ def main():
     walker.set_option("streams", a.streams)
     walker.set_option("merged", a.merged)
     walker.set_option("probe", a.probe)
+    for kv in a.walk_option:
+        name, value = kv.split("=")
+        walker.set_option(name, int(value))
     walker.enable_timing(True)
     outs = [torch.empty((s[2], 1, h, w), device=device) for s in shapes]
 

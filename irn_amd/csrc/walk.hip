@@ -538,6 +538,10 @@ extern "C" int irn_walk_set_option(irn_walk_ctx *ctx, const char *name, int valu
     } else if (!strcmp(name, "sweeps_per_launch")) {
         if (value < 0) return fail(IRN_ERR_ARG, "sweeps_per_launch must be >= 0");
         ctx->res_sweeps_per_launch = value;
+    } else if (!strcmp(name, "plain_store")) {
+        if (value && ctx->radius != 5)
+            return fail(IRN_ERR_ARG, "plain_store needs radius 5 (all tiles of an image inside one XCD)");
+        ctx->res_plain_store = value != 0;
     } else if (!strcmp(name, "poll_delay")) {
         if (value < 0 || value > 1000) return fail(IRN_ERR_ARG, "poll_delay must be in [0,1000]");
         ctx->res_poll_delay = value;
