@@ -72,6 +72,16 @@ int irn_edge_to_affinity(const float *edge_dev, int batch, int hp, int wp, int r
 int irn_edge_to_affinity_backward(const float *edge_dev, const float *grad_aff_dev, int batch, int hp, int wp,
                                   int radius, float *grad_edge_dev, void *stream);
 
+/* Pair displacement of the training seam (AffinityDisplacementLoss.to_pair_displacement,
+ * net/resnet50_irn.py:177-193).  disp: dev fp32 [batch, channels, hp, wp]; out: dev fp32
+ * [batch, channels, |S|, (hp-rf)*(wp-2rf)], out[b,c,d,y,x] = disp[b,c,y,rf+x] - disp[b,c,y+dy_d,rf+x+dx_d]
+ * with d in the reference's channel order (search_dst).  The backward writes the full gradient
+ * [batch, channels, hp, wp] (no accumulation, no atomics). */
+int irn_pair_displacement(const float *disp_dev, int batch, int channels, int hp, int wp, int radius, float *out_dev,
+                          void *stream);
+int irn_pair_displacement_backward(const float *grad_out_dev, int batch, int channels, int hp, int wp, int radius,
+                                   float *grad_disp_dev, void *stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Random-walk context  (replaces misc/indexing.py:141-165 `propagate_to_edge` and everything it
  * calls: PathIndex :148, edge_to_affinity :151, affinity_sparse2dense :154, to_transition_matrix

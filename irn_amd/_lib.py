@@ -33,6 +33,8 @@ _SIGS = {
     "irn_path_table": (i32, [i32, i32, pi32, pi32, pi32]),
     "irn_edge_to_affinity": (i32, [vp, i32, i32, i32, i32, vp, vp]),
     "irn_edge_to_affinity_backward": (i32, [vp, vp, i32, i32, i32, i32, vp, vp]),
+    "irn_pair_displacement": (i32, [vp, i32, i32, i32, i32, i32, vp, vp]),
+    "irn_pair_displacement_backward": (i32, [vp, i32, i32, i32, i32, i32, vp, vp]),
     "irn_walk_create": (i32, [i32, C.POINTER(vp)]),
     "irn_walk_destroy": (i32, [vp]),
     "irn_walk_configure": (i32, [vp, i32, pi32, pi32, pi32, C.POINTER(sz)]),

@@ -287,3 +287,79 @@ extern "C" int irn_edge_to_affinity_backward(const float *edge_dev, const float 
     IRN_LAUNCH_CHECK("affinity_backward_kernel");
     return scratch_release(stream);
 }
+
+namespace {
+// ---------------------------------------------------------------------------------------------
+// Pair displacement of the training seam (AffinityDisplacementLoss.to_pair_displacement,
+// net/resnet50_irn.py:177-193): out[b,c,d,y,x] = disp[b,c,y,rf+x] - disp[b,c,y+dy_d,rf+x+dx_d] over the
+// cropped grid — |S| shifted slices, a stack and a subtraction in the reference; one pass here, exact.
+// Backward as a gather (no atomics): the gradient of a cell is the sum over d of what it received as a
+// source minus what it received as the destination of the cell at (-dy_d, -dx_d).
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void pair_disp_kernel(const float *__restrict__ disp, float *__restrict__ out, int hp,
+                                                        int wp, int rf, int n_dirs, const int *__restrict__ dir_dy,
+                                                        const int *__restrict__ dir_dx) {
+    const int ch = hp - rf, cw = wp - 2 * rf;
+    const int s = blockIdx.x * 256 + threadIdx.x;
+    if (s >= ch * cw) return;
+    const int y = s / cw, x = s - y * cw;
+    const float *plane = disp + (size_t)blockIdx.y * hp * wp;
+    float *o = out + (size_t)blockIdx.y * n_dirs * ch * cw + s;
+    const float src = plane[y * wp + rf + x];
+    for (int d = 0; d < n_dirs; ++d)
+        o[(size_t)d * ch * cw] = src - plane[(y + dir_dy[d]) * wp + rf + x + dir_dx[d]];
+}
+
+__global__ __launch_bounds__(256) void pair_disp_backward_kernel(const float *__restrict__ gout, float *__restrict__ gdisp,
+                                                                 int hp, int wp, int rf, int n_dirs,
+                                                                 const int *__restrict__ dir_dy, const int *__restrict__ dir_dx) {
+    const int ch = hp - rf, cw = wp - 2 * rf;
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= hp * wp) return;
+    const int Y = p / wp, X = p - Y * wp;
+    const float *g = gout + (size_t)blockIdx.y * n_dirs * ch * cw;
+    const int xs = X - rf;
+    float acc = 0.f;
+    if (Y < ch && xs >= 0 && xs < cw)
+        for (int d = 0; d < n_dirs; ++d) acc += g[(size_t)d * ch * cw + Y * cw + xs];
+    for (int d = 0; d < n_dirs; ++d) {
+        const int yy = Y - dir_dy[d], xx = xs - dir_dx[d];
+        if (yy >= 0 && yy < ch && xx >= 0 && xx < cw) acc -= g[(size_t)d * ch * cw + yy * cw + xx];
+    }
+    gdisp[(size_t)blockIdx.y * hp * wp + p] = acc;
+}
+
+int pair_disp_args(const char *who, const void *a, const void *b, int batch, int channels, int hp, int wp, int radius,
+                   const DeviceTable **tab) {
+    if (!a || !b || batch < 1 || channels < 1 || radius < 2 || radius > IRN_MAX_RADIUS)
+        return fail(IRN_ERR_ARG, "%s: bad argument", who);
+    if (hp - (radius - 1) < 1 || wp - 2 * (radius - 1) < 1)
+        return fail(IRN_ERR_ARG, "%s: grid %dx%d too small for radius %d", who, hp, wp, radius);
+    if ((long)batch * channels > 65535) return fail(IRN_ERR_ARG, "%s: batch * channels must be <= 65535", who);
+    return get_device_table(radius, 0, tab);
+}
+}  // namespace
+
+extern "C" int irn_pair_displacement(const float *disp_dev, int batch, int channels, int hp, int wp, int radius,
+                                     float *out_dev, void *stream) {
+    const DeviceTable *tab = nullptr;
+    if (int rc = pair_disp_args("irn_pair_displacement", disp_dev, out_dev, batch, channels, hp, wp, radius, &tab)) return rc;
+    const int rf = radius - 1;
+    hipLaunchKernelGGL(pair_disp_kernel, dim3(cdiv((hp - rf) * (wp - 2 * rf), 256), batch * channels), dim3(256), 0,
+                       (hipStream_t)stream, disp_dev, out_dev, hp, wp, rf, tab->n_dirs, tab->dir_dy, tab->dir_dx);
+    IRN_LAUNCH_CHECK("pair_disp_kernel");
+    return IRN_OK;
+}
+
+extern "C" int irn_pair_displacement_backward(const float *grad_out_dev, int batch, int channels, int hp, int wp,
+                                              int radius, float *grad_disp_dev, void *stream) {
+    const DeviceTable *tab = nullptr;
+    if (int rc = pair_disp_args("irn_pair_displacement_backward", grad_out_dev, grad_disp_dev, batch, channels, hp, wp,
+                                radius, &tab))
+        return rc;
+    hipLaunchKernelGGL(pair_disp_backward_kernel, dim3(cdiv(hp * wp, 256), batch * channels), dim3(256), 0,
+                       (hipStream_t)stream, grad_out_dev, grad_disp_dev, hp, wp, radius - 1, tab->n_dirs, tab->dir_dy,
+                       tab->dir_dx);
+    IRN_LAUNCH_CHECK("pair_disp_backward_kernel");
+    return IRN_OK;
+}

@@ -159,6 +159,41 @@ def edge_to_affinity(edge, paths_indices=None, radius=None, size=None):
     return _EdgeToAffinity.apply(e, radius, hp, wp)
 
 
+class _PairDisplacement(torch.autograd.Function):
+    """irn_pair_displacement / irn_pair_displacement_backward."""
+
+    @staticmethod
+    def forward(ctx, disp, radius):
+        b, c, hp, wp = disp.shape
+        rf = int(np.ceil(radius) - 1)
+        nd, nc = C.c_int(), C.c_int()
+        check(lib.irn_path_count(int(radius), C.byref(nd), C.byref(nc)))
+        out = torch.empty((b, c, nd.value, (hp - rf) * (wp - 2 * rf)), device=disp.device, dtype=torch.float32)
+        with torch.cuda.device(disp.device):
+            check(lib.irn_pair_displacement(disp.data_ptr(), b, c, hp, wp, int(radius), out.data_ptr(), _stream()))
+        ctx.geom = (int(radius), b, c, hp, wp)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        radius, b, c, hp, wp = ctx.geom
+        g = grad_out.contiguous().float()
+        grad = torch.empty((b, c, hp, wp), device=g.device, dtype=torch.float32)
+        with torch.cuda.device(g.device):
+            check(lib.irn_pair_displacement_backward(g.data_ptr(), b, c, hp, wp, radius, grad.data_ptr(), _stream()))
+        return grad, None
+
+
+def pair_displacement(disp, radius):
+    """pair_disp[b,c,d,s] = disp at the source cell minus disp at the cell (dy_d, dx_d) away, over the cropped grid
+    (AffinityDisplacementLoss.to_pair_displacement, net/resnet50_irn.py:177-193).  ``disp``: GPU float
+    [B, C, Hp, Wp]; returns [B, C, |S|, (Hp-rf)*(Wp-2rf)] in the reference's channel order.  Differentiable."""
+    _need_cuda(disp, "disp")
+    if disp.dim() != 4:
+        raise ValueError("pair_displacement: [B, C, Hp, Wp] expected")
+    return _PairDisplacement.apply(disp.contiguous().float(), radius)
+
+
 def affinity_sparse2dense(affinity_sparse, ind_from, ind_to, n_vertices):
     """Dense symmetric affinity with unit diagonal (reference misc/indexing.py:112-129).
     Kept for API completeness only — the walk never densifies; built on-device with index_put

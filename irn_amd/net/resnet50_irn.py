@@ -2,9 +2,9 @@
 PyTorch-ROCm.  API mirror of reference net/resnet50_irn.py:7-133 (``Net``) and :216-234
 (``EdgeDisplacement``); attribute names reproduce the reference's state-dict keys.
 
-The training wrapper ``AffinityDisplacementLoss`` (net/resnet50_irn.py:144-213) is out of scope
- — its path-max gather is the same operator as
-``irn_amd.misc.indexing.edge_to_affinity``.
+``AffinityDisplacementLoss`` (net/resnet50_irn.py:144-213) is mirrored as the training SEAM only (SURVEY.md §8f
+rank 4): its two gather operators run as differentiable HIP ops (``irn_amd.misc.indexing.edge_to_affinity``,
+``pair_displacement``); the training loop, optimiser and datasets around it are out of scope.
 """
 import torch
 import torch.nn as nn
@@ -72,11 +72,11 @@ class Net(nn.Module):
                                         self.fc_dp5, self.fc_dp6, self.fc_dp7])
 
     def forward(self, x):
-        f1 = self.stage1(x)
-        f2 = self.stage2(f1)
-        f3 = self.stage3(f2)
-        f4 = self.stage4(f3)
-        f5 = self.stage5(f4)
+        f1 = self.stage1(x).detach()        # the trunk is frozen (net/resnet50_irn.py:111-115)
+        f2 = self.stage2(f1).detach()
+        f3 = self.stage3(f2).detach()
+        f4 = self.stage4(f3).detach()
+        f5 = self.stage5(f4).detach()
 
         e2 = self.fc_edge2(f2)
         eh, ew = e2.shape[2:]
@@ -91,6 +91,14 @@ class Net(nn.Module):
         up3 = self.fc_dp6(mid)[..., :d2.shape[2], :d2.shape[3]]
         dp = self.fc_dp7(torch.cat([self.fc_dp1(f1), d2, up3], dim=1))
         return edge, dp
+
+    def trainable_parameters(self):
+        return tuple(self.edge_layers.parameters()), tuple(self.dp_layers.parameters())
+
+    def train(self, mode=True):
+        super().train(mode)
+        self.backbone.eval()                # net/resnet50_irn.py:139-141
+        return self
 
 
 class EdgeDisplacement(Net):
@@ -111,3 +119,36 @@ class EdgeDisplacement(Net):
         e = e[..., :h, :w]
         d = d[..., :h, :w]
         return torch.sigmoid(e[0] / 2 + e[1].flip(-1) / 2), d[0]
+
+
+class AffinityDisplacementLoss(Net):
+    """Training-time losses of IRNet (net/resnet50_irn.py:144-213): same constructor (a ``PathIndex``), same four
+    outputs of ``forward(x, True)``.  ``to_affinity`` and ``to_pair_displacement`` are the HIP operators (forward and
+    backward) instead of |S| index_select / slice / stack launches; GPU tensors only."""
+
+    def __init__(self, path_index):
+        super().__init__()
+        self.path_index = path_index
+        dst = torch.as_tensor(path_index.search_dst, dtype=torch.float32)            # [|S|, 2] (dy, dx)
+        self.register_buffer("disp_target", dst.t().unsqueeze(0).unsqueeze(-1))       # [1, 2, |S|, 1]
+
+    def to_affinity(self, edge):
+        from ..misc import indexing
+        return indexing.edge_to_affinity(edge, radius=self.path_index.radius, size=self.path_index.default_size)
+
+    def to_pair_displacement(self, disp):
+        from ..misc import indexing
+        return indexing.pair_displacement(disp, self.path_index.radius)
+
+    def to_displacement_loss(self, pair_disp):
+        return torch.abs(pair_disp - self.disp_target)
+
+    def forward(self, x, return_loss=True):
+        edge_out, dp_out = super().forward(x)
+        if return_loss is False:
+            return edge_out, dp_out
+        aff = self.to_affinity(torch.sigmoid(edge_out))
+        pos_aff_loss = (-1) * torch.log(aff + 1e-5)
+        neg_aff_loss = (-1) * torch.log(1. + 1e-5 - aff)
+        pair_disp = self.to_pair_displacement(dp_out)
+        return pos_aff_loss, neg_aff_loss, self.to_displacement_loss(pair_disp), torch.abs(pair_disp)

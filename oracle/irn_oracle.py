@@ -122,6 +122,37 @@ def edge_to_affinity_backward(edge, grad_aff, radius):
     return grad.astype(np.float32)
 
 
+def pair_displacement(disp, radius):
+    """AffinityDisplacementLoss.to_pair_displacement (reference net/resnet50_irn.py:177-193):
+    disp [B,C,Hp,Wp] -> [B,C,|S|,(Hp-rf)*(Wp-2rf)], source cell minus the cell (dy,dx) away, directions
+    in the reference's channel order."""
+    disp = np.asarray(disp, np.float32)
+    b, c, hp, wp = disp.shape
+    rf = radius - 1
+    ch, cw = hp - rf, wp - 2 * rf
+    _paths, dst = search_paths_dst(radius)
+    src = disp[:, :, :ch, rf:rf + cw]
+    out = np.stack([src - disp[:, :, dy:dy + ch, rf + dx:rf + dx + cw] for dy, dx in dst], 2)
+    return out.reshape(b, c, len(dst), ch * cw)
+
+
+def pair_displacement_backward(grad_out, radius, size):
+    """Vector-Jacobian product of the above (what autograd does through the slices, the stack and the
+    subtraction): +g to the source cell, -g to the destination cell; fp64 accumulation.  size = (Hp, Wp)."""
+    g = np.asarray(grad_out, np.float64)
+    b, c, nd, _ = g.shape
+    hp, wp = size
+    rf = radius - 1
+    ch, cw = hp - rf, wp - 2 * rf
+    g = g.reshape(b, c, nd, ch, cw)
+    _paths, dst = search_paths_dst(radius)
+    grad = np.zeros((b, c, hp, wp), np.float64)
+    for d, (dy, dx) in enumerate(dst):
+        grad[:, :, :ch, rf:rf + cw] += g[:, :, d]
+        grad[:, :, dy:dy + ch, rf + dx:rf + dx + cw] -= g[:, :, d]
+    return grad.astype(np.float32)
+
+
 def affinity_dense(aff, src, dst, n):
     """Symmetric dense matrix with unit diagonal (misc/indexing.py:112-129)."""
     a = np.zeros((n, n), np.float32)

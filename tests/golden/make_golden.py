@@ -124,6 +124,28 @@ def gen_affinity_grad():
     np.savez_compressed(os.path.join(OUT, "affinity_grad.npz"), **out)
 
 
+def gen_pair_disp():
+    """Training seam: AffinityDisplacementLoss.to_pair_displacement (net/resnet50_irn.py:177-193) under autograd:
+    forward values and the gradient of sum(pair_disp * g) w.r.t. the displacement field."""
+    from misc import indexing
+    from net import resnet50_irn
+    out = {}
+    for r, (hp, wp) in ((5, (20, 27)), (3, (12, 15)), (10, (16, 29))):
+        pi = indexing.PathIndex(radius=r, default_size=(hp, wp))
+        loss = resnet50_irn.AffinityDisplacementLoss.__new__(resnet50_irn.AffinityDisplacementLoss)
+        torch.nn.Module.__init__(loss)
+        loss.path_index = pi
+        disp = torch.stack([torch.from_numpy(synth.displacement_field(hp, wp, seed=400 + r + b)) for b in range(2)])
+        disp.requires_grad_(True)
+        pd = loss.to_pair_displacement(disp)
+        g = torch.from_numpy(np.random.RandomState(11 + r).randn(*pd.shape).astype(np.float32))
+        (pd * g).sum().backward()
+        out["r%d_disp" % r] = disp.detach().numpy()
+        out["r%d_pair" % r] = pd.detach().numpy()
+        out["r%d_gdisp" % r] = disp.grad.numpy()     # g is regenerated from its seed by the tests (RandomState(11 + r))
+    np.savez_compressed(os.path.join(OUT, "pair_disp.npz"), **out)
+
+
 WALK_CASES = [
     # name, h, w, C, radius, beta, exp_times, seed
     ("r5_b10_e8", 32, 32, 3, 5, 10, 8, 1),
@@ -355,7 +377,7 @@ def gen_msf():
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", nargs="*", default=None,
-                    help="subset of: path affinity affinity_grad walk semseg instance cam_merge nets msf; or walk case names")
+                    help="subset of: path affinity affinity_grad walk semseg instance cam_merge nets msf pair_disp; or walk case names")
     a = ap.parse_args()
     _install_reference()
     torch.set_num_threads(os.cpu_count())
@@ -383,6 +405,8 @@ def main():
         gen_nets()
     if want("msf"):
         gen_msf()
+    if want("pair_disp"):
+        gen_pair_disp()
 
 
 if __name__ == "__main__":

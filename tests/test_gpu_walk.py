@@ -235,3 +235,52 @@ def test_edge_to_affinity_is_differentiable_like_the_reference(golden, r):
         (a * torch.from_numpy(g_np).to(_dev())).sum().backward()
         want = O.edge_to_affinity_backward(e_np, g_np, rr)
         assert np.abs(e.grad.cpu().numpy() - want).max() <= 2e-5 * np.abs(want).max()
+
+
+@pytest.mark.parametrize("r", [3, 5, 10])
+def test_pair_displacement_forward_backward_vs_reference_autograd(golden, r):
+    """irn_pair_displacement / _backward (training seam, net/resnet50_irn.py:177-193) against the reference run
+    under autograd: forward bit-exact (a subtraction), gradient within fp32 summation-order noise."""
+    from irn_amd.misc import indexing
+    from oracle import irn_oracle as O
+    pd = golden("pair_disp")
+    disp = torch.from_numpy(pd["r%d_disp" % r]).cuda().requires_grad_(True)
+    out = indexing.pair_displacement(disp, r)
+    want = pd["r%d_pair" % r]
+    assert np.array_equal(out.detach().cpu().numpy(), want)
+    g = np.random.RandomState(11 + r).randn(*want.shape).astype(np.float32)
+    (out * torch.from_numpy(g).cuda()).sum().backward()
+    ref = pd["r%d_gdisp" % r]
+    assert np.abs(disp.grad.cpu().numpy() - ref).max() <= 2e-6 * np.abs(ref).max()
+    # larger, training-shaped input against the oracle: batch 4 x 2 channels, 48x64 grid
+    big = np.random.RandomState(r).randn(4, 2, 48, 64).astype(np.float32)
+    t = torch.from_numpy(big).cuda().requires_grad_(True)
+    o = indexing.pair_displacement(t, r)
+    assert np.array_equal(o.detach().cpu().numpy(), O.pair_displacement(big, r))
+    gg = np.random.RandomState(r + 1).randn(*o.shape).astype(np.float32)
+    (o * torch.from_numpy(gg).cuda()).sum().backward()
+    gref = O.pair_displacement_backward(gg, r, (48, 64))
+    assert np.abs(t.grad.cpu().numpy() - gref).max() <= 2e-6 * np.abs(gref).max()
+
+
+def test_affinity_displacement_loss_module_matches_operator_tier():
+    """AffinityDisplacementLoss mirror: the four loss tensors of forward(x, True) have the reference's shapes and are
+    the operator-tier results applied to the network outputs; gradients reach both heads (the trunk is frozen)."""
+    from irn_amd.misc import indexing
+    from irn_amd.net import resnet50_irn, weights
+    pi = indexing.PathIndex(radius=5, default_size=(16, 16))
+    net = resnet50_irn.AffinityDisplacementLoss(pi)
+    net.load_state_dict(weights.random_irn_state(3), strict=False)
+    net = net.cuda().train()
+    x = torch.randn(2, 3, 64, 64, device="cuda")
+    pos, neg, fg, bg = net(x, True)
+    n_dirs, ns = 34, (16 - 4) * (16 - 8)
+    assert pos.shape == neg.shape == (2, n_dirs, ns) and fg.shape == bg.shape == (2, 2, n_dirs, ns)
+    edge, dp = net(x, False)
+    aff = indexing.edge_to_affinity(torch.sigmoid(edge), radius=5, size=(16, 16))
+    assert torch.allclose(pos, -torch.log(aff + 1e-5), atol=1e-5)
+    assert torch.allclose(bg, indexing.pair_displacement(dp, 5).abs(), atol=1e-5)
+    (pos.mean() + neg.mean() + fg.mean() + bg.mean()).backward()
+    assert net.fc_edge6.weight.grad is not None and float(net.fc_edge6.weight.grad.abs().sum()) > 0
+    assert net.fc_dp1[0].weight.grad is not None and float(net.fc_dp1[0].weight.grad.abs().sum()) > 0
+    assert net.resnet50.conv1.weight.grad is None and not net.stage1.training

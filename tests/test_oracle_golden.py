@@ -196,3 +196,15 @@ def test_rescale_size_rounds_half_to_even():
     assert M.rescale_size(375, 500, 0.5) == (188, 250)      # 187.5 -> 188
     assert M.rescale_size(375, 500, 1.5) == (562, 750)      # 562.5 -> 562
     assert M.rescale_size(281, 500, 0.5) == (140, 250)      # 140.5 -> 140
+
+
+@pytest.mark.parametrize("r", [3, 5, 10])
+def test_pair_displacement_restatement_vs_reference_autograd(golden, r):
+    """oracle.pair_displacement (+ backward) against AffinityDisplacementLoss.to_pair_displacement run under
+    autograd (tests/golden/make_golden.py gen_pair_disp): the forward is a subtraction and exact."""
+    pd = golden("pair_disp")
+    disp, want = pd["r%d_disp" % r], pd["r%d_pair" % r]
+    assert np.array_equal(O.pair_displacement(disp, r), want)
+    g = np.random.RandomState(11 + r).randn(*want.shape).astype(np.float32)
+    gd = O.pair_displacement_backward(g, r, disp.shape[2:])
+    assert np.abs(gd - pd["r%d_gdisp" % r]).max() <= 1e-6 * np.abs(pd["r%d_gdisp" % r]).max()
