@@ -502,6 +502,9 @@ extern "C" int irn_walk_create(int radius, irn_walk_ctx **ctx_out) {
     // radius 5 / 10: weights-stationary persistent walk (falls back to the streaming sweeps per batch
     // when an image does not fit one round); other radii: generic table-driven sweep
     c->variant = (radius == 5 || radius == 10) ? 2 : 0;
+    // radius 5: an image is 16 tiles and normally sits inside one XCD; tiles verify that per image inside the
+    // kernel and then exchange through the XCD's L2 (plain stores) instead of the fabric
+    c->res_plain_store = radius == 5;
     *ctx_out = c;
     return IRN_OK;
 }
@@ -542,6 +545,9 @@ extern "C" int irn_walk_set_option(irn_walk_ctx *ctx, const char *name, int valu
         if (value && ctx->radius != 5)
             return fail(IRN_ERR_ARG, "plain_store needs radius 5 (all tiles of an image inside one XCD)");
         ctx->res_plain_store = value != 0;
+    } else if (!strcmp(name, "poll_delay_plain")) {
+        if (value < 0 || value > 1000) return fail(IRN_ERR_ARG, "poll_delay_plain must be in [0,1000]");
+        ctx->res_poll_delay_plain = value;
     } else if (!strcmp(name, "poll_delay")) {
         if (value < 0 || value > 1000) return fail(IRN_ERR_ARG, "poll_delay must be in [0,1000]");
         ctx->res_poll_delay = value;

@@ -104,7 +104,10 @@ struct irn_walk_ctx {
     unsigned *res_err_host = nullptr;      // pinned mirror
     long long *res_prof_dev = nullptr;     // [2][256][4] time stamps (option "profile")
     int res_poll_delay = 10;   // s_sleep(1) units (64 clocks): first poll this long after our own stores
-    bool res_plain_store = false;   // experiment: state stores without sc1 (see resident_kernel)
+    bool res_plain_store = false;          // radius 5: plain state stores for images whose tiles share an XCD (voted in-kernel)
+    int res_poll_delay_plain = 2;          // poll delay of such jobs
+    unsigned long long *res_votes_dev = nullptr;   // [n] per-image XCD vote words
+    int res_votes_cap = 0;
     bool deg_stale = false;    // last run was resident: the inv_deg array of the workspace was not written
     bool res_ok = false;                   // the configured batch fits the resident kernel
     int res_sweeps_per_launch = 0;         // 0 = all sweeps in one launch; k = relaunch every k sweeps (test hook)

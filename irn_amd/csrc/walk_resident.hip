@@ -327,7 +327,7 @@ __global__ __launch_bounds__(256) void x0_granule_kernel(const WalkImg *__restri
 template <int R, bool PROF>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void resident_kernel(
     const WalkImg *__restrict__ imgs, const int4 *__restrict__ jobs, int n_rounds, int t_first, int t_count,
-    int t_total, unsigned *err, long long timeout_ticks, long long *prof, int poll_delay) {
+    int t_total, unsigned *err, long long timeout_ticks, long long *prof, int poll_delay, unsigned long long *votes) {
     using G = Geom<R>;
     constexpr int H = G::H, HP = G::HP, LH = G::LH, LW = G::LW, LWU = G::LWU, RG = G::RG, Q = G::Q, NK = G::NK;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -343,12 +343,14 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const int ly = (slab / G::C::SL_X) * kSlabH + (lane >> 3);
     const int lx = (slab % G::C::SL_X) * kSlabW + (lane & 7) * 4;
     if (tid == 0) *abort_flag = 0;
-    // bit 16 of the delay argument (option "plain_store", radius 5 only, off by default): state stores without sc1.
-    // They keep the line in this XCD's L2, which then serves a same-XCD neighbour's sc1 poll without the trip
-    // through the fabric (C = 1 sweep 2.61 -> 2.23 us).  A reader on ANOTHER XCD never sees such a store in time
-    // (radius 10, 64 tiles = 2 XCDs per image: every launch ran into the bounded wait), so this is only sound
-    // while all 16 tiles of an image share an XCD, which rests on the observed, not promised, block -> XCD map.
-    const bool plain_st = R == 5 && (poll_delay & 0x10000) != 0;
+    // Option "plain_store" (radius 5 only; `votes` non-null): state stores without sc1 when every tile of the image
+    // has been SEEN to run on this XCD.  Such a store keeps the line in the XCD's L2, which then serves a same-XCD
+    // neighbour's sc1 poll without the trip through the fabric (C = 1 sweep 2.61 -> 2.23 us).  A reader on another XCD
+    // never sees it in time (radius 10, 64 tiles = 2 XCDs per image: every launch ran into the bounded wait), and HIP
+    // promises nothing about block -> XCD placement, so each job votes: every tile adds 1 to the byte of its XCC id
+    // in the image's 64-bit word and waits until all tiles have voted; one byte holding them all = same XCD.
+    int *plain_flag = abort_flag + 1;
+    const int delay_plain = (poll_delay >> 16) & 0xffff;
     poll_delay &= 0xffff;
 
     float wr[G::NS][4];
@@ -366,6 +368,32 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         const int h = I.h, w = I.w;
         const unsigned n = (unsigned)(h * w);
         const int gy = ty0 + ly, gx = tx0 + lx;
+        if constexpr (R == 5) {
+            if (votes && tid == 0) {
+                const unsigned xcc = (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 20) & 7u;   // HW_REG_XCC_ID
+                unsigned long long *v = votes + je.x;
+                __hip_atomic_fetch_add(v, 1ull << (8 * xcc), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const long long t0 = wall_clock64();
+                int same = 0;
+                for (;;) {
+                    const unsigned long long word = __hip_atomic_load(v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    unsigned total = 0;
+                    bool single = false;
+                    for (int f = 0; f < 8; ++f) {
+                        const unsigned cnt = (unsigned)(word >> (8 * f)) & 0xffu;
+                        total += cnt;
+                        single |= cnt == (unsigned)je.w;
+                    }
+                    if (total >= (unsigned)je.w) {
+                        same = single ? 1 : 0;
+                        break;
+                    }
+                    if (wall_clock64() - t0 > timeout_ticks) break;      // sc1 stores are always safe
+                    __builtin_amdgcn_s_sleep(16);
+                }
+                *plain_flag = same;
+            }
+        }
 
         double dsum[4];
 #define IRN_LOAD_PART(QI)                          \
@@ -390,6 +418,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             for (int j = 0; j < 4; ++j) pw[j] = dsum[j];
         }
         __syncthreads();
+        const bool plain_st = R == 5 && votes && *plain_flag != 0;
+        const int job_delay = plain_st ? delay_plain : poll_delay;
 #pragma unroll
         for (int i = tid; i < G::SLABS * 256; i += 512) {     // [slab][row][column] like the combine's thread order
             const int s2 = i >> 8, prow = (i >> 5) & 7, x = i & 31;
@@ -487,7 +517,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             if (poller) {
                 unsigned pend = vmask;
                 if (!polled) {
-                    if (!fresh) nap(poll_delay);
+                    if (!fresh) nap(job_delay);
                     issue(src, c * ch_bytes);
                 }
                 long long t_start = 0;
@@ -672,6 +702,9 @@ void resident_destroy(irn_walk_ctx *ctx) {
     if (ctx->res_err_dev) (void)hipFree(ctx->res_err_dev);
     if (ctx->res_err_host) (void)hipHostFree(ctx->res_err_host);
     if (ctx->res_prof_dev) (void)hipFree(ctx->res_prof_dev);
+    if (ctx->res_votes_dev) (void)hipFree(ctx->res_votes_dev);
+    ctx->res_votes_dev = nullptr;
+    ctx->res_votes_cap = 0;
     ctx->res_prof_dev = nullptr;
     ctx->res_jobs_dev = nullptr;
     ctx->res_err_dev = nullptr;
@@ -729,7 +762,7 @@ int resident_configure(irn_walk_ctx *ctx) {
                 const int per = (n_wg + 7) / 8;
                 int b = (slot % per) * 8 + slot / per;
                 if (n_wg % 8 != 0 || b >= n_wg) b = slot;
-                rounds[r][b] = make_int4(i, ty, tx, 0);
+                rounds[r][b] = make_int4(i, ty, tx, tiles[i]);
             }
     }
     const int total = (int)rounds.size() * n_wg;
@@ -743,6 +776,12 @@ int resident_configure(irn_walk_ctx *ctx) {
     flat.reserve(total);
     for (auto &r : rounds) flat.insert(flat.end(), r.begin(), r.end());
     IRN_HIP_TRY(hipMemcpy(ctx->res_jobs_dev, flat.data(), sizeof(int4) * total, hipMemcpyHostToDevice));
+    if (ctx->res_votes_cap < n) {
+        if (ctx->res_votes_dev) (void)hipFree(ctx->res_votes_dev);
+        ctx->res_votes_dev = nullptr;
+        IRN_HIP_TRY(hipMalloc((void **)&ctx->res_votes_dev, sizeof(unsigned long long) * n));
+        ctx->res_votes_cap = n;
+    }
     if (!ctx->res_err_dev) {
         IRN_HIP_TRY(hipMalloc((void **)&ctx->res_err_dev, 4 * sizeof(unsigned)));
         IRN_HIP_TRY(hipHostMalloc((void **)&ctx->res_err_host, 4 * sizeof(unsigned), hipHostMallocDefault));
@@ -762,9 +801,14 @@ static int launch_resident(irn_walk_ctx *ctx, int t_first, int t_count, int t_to
         attr_set = true;
     }
     const long long timeout_ticks = 200000000LL;   // 2 s of the 100 MHz wall clock
+    unsigned long long *votes = nullptr;
+    if (R == 5 && ctx->res_plain_store) {           // one vote word per image, cleared before every launch
+        votes = ctx->res_votes_dev;
+        IRN_HIP_TRY(hipMemsetAsync(votes, 0, sizeof(unsigned long long) * ctx->n, stream));
+    }
     hipLaunchKernelGGL((resident_kernel<R, PROF>), dim3(ctx->res_nwg), dim3(512), G::LDS_BYTES, stream, ctx->imgs_dev,
                        ctx->res_jobs_dev, ctx->res_rounds, t_first, t_count, t_total, ctx->res_err_dev, timeout_ticks,
-                       ctx->res_prof_dev, ctx->res_poll_delay | (ctx->res_plain_store ? 0x10000 : 0));
+                       ctx->res_prof_dev, ctx->res_poll_delay | (ctx->res_poll_delay_plain << 16), votes);
     IRN_LAUNCH_CHECK("resident_kernel");
     return IRN_OK;
 }

@@ -184,3 +184,26 @@ def test_falls_back_when_an_image_does_not_fit_a_round():
         assert (a - b).abs().max().item() <= 2e-6
         wk.close()
         gen.close()
+
+
+def test_radius5_plain_store_vote_is_bitwise_equal_and_radius10_refuses():
+    """Option plain_store (radius 5): tiles vote their XCC id per image and store the state without sc1 only when
+    the whole image was seen on one XCD; the arithmetic is the same, so results equal the default bit for bit —
+    36 images of 1..5 channels (3 rounds), launched whole and in 5-sweep chunks (votes are cleared per launch)."""
+    from irn_amd._lib import IrnHipError
+    shapes = [(128, 128, 1 + (i * 3) % 5) for i in range(34)] + [(94, 125, 2), (60, 200, 1)]
+    edges, cams = _inputs(shapes, 1300)
+    ref_w = _walker(5)
+    ref = [o.clone() for o in ref_w(edges, cams, beta=10, n_sweeps=40)]
+    ref_w.check()
+    for extra in ({}, {"sweeps_per_launch": 5}, {"poll_delay_plain": 0}):
+        wk = _walker(5, plain_store=1, **extra)
+        for rep in range(2):
+            out = wk(edges, cams, beta=10, n_sweeps=40)
+            wk.check()
+            for i in range(len(shapes)):
+                assert torch.equal(out[i], ref[i]), (extra, rep, i)
+        wk.close()
+    ref_w.close()
+    with pytest.raises(IrnHipError, match="radius 5"):
+        _walker(10, plain_store=1)
