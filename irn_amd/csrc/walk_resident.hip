@@ -640,35 +640,49 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     }
                 }
                 } else {
-                    // radius 5 (1024 pixels per tile, 4 per combining thread): two iterations of a pixel PAIR per
-                    // thread beat four of a single pixel (0.41 vs 0.75 us) — the iterations run one after the other
+                    // radius 5 (1024 pixels per tile, 4 per combining thread): a pixel PAIR per thread and iteration
+                    // (0.41 vs 0.75 us for four single pixels); the sums of all iterations are formed before the
+                    // first store so that their LDS reads overlap
+                    constexpr int NIT = G::SLABS * 128 / 256;
+                    if (!poller) {
+                        float r0v[NIT], r1v[NIT];
 #pragma unroll
-                    for (int i = tid; i < (poller ? 0 : G::SLABS * 128); i += 256) {
-                        const int s2 = i >> 7, prow = (i >> 4) & 7, x = (i & 15) * 2;
-                        const int py = (s2 / G::C::SL_X) * kSlabH + prow;
-                        const int px = (s2 % G::C::SL_X) * kSlabW + x;
-                        const double *pr = part + (k & 1) * (kWaves * 256) + (s2 * Q) * 256 + (prow * 8 + (x >> 2)) * 4 + (x & 3);
-                        const float *xc = xsb + (py + H) * LW + px + HP;
-                        double sum0 = (double)xc[0], sum1 = (double)xc[1];
+                        for (int it = 0; it < NIT; ++it) {
+                            const int i = tid + it * 256;
+                            const int s2 = i >> 7, prow = (i >> 4) & 7, x = (i & 15) * 2;
+                            const int py = (s2 / G::C::SL_X) * kSlabH + prow;
+                            const int px = (s2 % G::C::SL_X) * kSlabW + x;
+                            const double *pr = part + (k & 1) * (kWaves * 256) + (s2 * Q) * 256 + (prow * 8 + (x >> 2)) * 4 + (x & 3);
+                            const float *xc = xsb + (py + H) * LW + px + HP;
+                            double sum0 = (double)xc[0], sum1 = (double)xc[1];
 #pragma unroll
-                        for (int q = 0; q < Q; ++q) {
-                            sum0 += pr[q * 256];
-                            sum1 += pr[q * 256 + 1];
+                            for (int q = 0; q < Q; ++q) {
+                                sum0 += pr[q * 256];
+                                sum1 += pr[q * 256 + 1];
+                            }
+                            const int ii = s2 * 256 + prow * 32 + x;
+                            r0v[it] = (float)(sum0 * invd[ii]);
+                            r1v[it] = (float)(sum1 * invd[ii + 1]);
                         }
-                        const int ii = s2 * 256 + prow * 32 + x;
-                        const float r0 = (float)(sum0 * invd[ii]), r1 = (float)(sum1 * invd[ii + 1]);
-                        const int yy = ty0 + py, xx = tx0 + px;
-                        if (yy < h && xx < w) {
-                            const unsigned o = (unsigned)(yy * w + xx);
-                            if (last) {
-                                ((gf_t)I.out)[(unsigned)c * n + o] = r0;
-                                if (xx + 1 < w) ((gf_t)I.out)[(unsigned)c * n + o + 1] = r1;
-                            } else if (xx + 1 < w) {
-                                if (plain_st) st_granule2<0>(dst, (int)o * 8, c * ch_bytes, want + 1, r0, r1);
-                                else st_granule2(dst, (int)o * 8, c * ch_bytes, want + 1, r0, r1);
-                            } else {
-                                if (plain_st) st_granule<0>(dst, (int)o * 8, c * ch_bytes, want + 1, r0);
-                                else st_granule(dst, (int)o * 8, c * ch_bytes, want + 1, r0);
+#pragma unroll
+                        for (int it = 0; it < NIT; ++it) {
+                            const int i = tid + it * 256;
+                            const int s2 = i >> 7, prow = (i >> 4) & 7, x = (i & 15) * 2;
+                            const int yy = ty0 + (s2 / G::C::SL_X) * kSlabH + prow;
+                            const int xx = tx0 + (s2 % G::C::SL_X) * kSlabW + x;
+                            const float r0 = r0v[it], r1 = r1v[it];
+                            if (yy < h && xx < w) {
+                                const unsigned o = (unsigned)(yy * w + xx);
+                                if (last) {
+                                    ((gf_t)I.out)[(unsigned)c * n + o] = r0;
+                                    if (xx + 1 < w) ((gf_t)I.out)[(unsigned)c * n + o + 1] = r1;
+                                } else if (xx + 1 < w) {
+                                    if (plain_st) st_granule2<0>(dst, (int)o * 8, c * ch_bytes, want + 1, r0, r1);
+                                    else st_granule2(dst, (int)o * 8, c * ch_bytes, want + 1, r0, r1);
+                                } else {
+                                    if (plain_st) st_granule<0>(dst, (int)o * 8, c * ch_bytes, want + 1, r0);
+                                    else st_granule(dst, (int)o * 8, c * ch_bytes, want + 1, r0);
+                                }
                             }
                         }
                     }
