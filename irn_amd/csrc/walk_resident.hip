@@ -104,8 +104,8 @@ struct Geom {
     static_assert(SLABS * Q == kWaves, "8 waves per workgroup");
     // LDS carve (bytes)
     static constexpr int XS_BYTES = 2 * LH * LW * 4;               // [2][LH][LW] fp32, double-buffered per step
-    static constexpr int PART_BYTES = 2 * kWaves * 4 * 64 * 8;      // [2][wave][j][lane] fp64
-    static constexpr int INVD_BYTES = SLABS * 4 * 64 * 8;           // [slab][j][lane] fp64
+    static constexpr int PART_BYTES = 2 * kWaves * 4 * 64 * 8;      // [2][wave][lane][j] fp64
+    static constexpr int INVD_BYTES = SLABS * 4 * 64 * 8;           // [slab][row][column] fp64
     static constexpr int LDS_BYTES = XS_BYTES + PART_BYTES + INVD_BYTES + 16;
 };
 
@@ -156,7 +156,8 @@ __device__ __forceinline__ void load_weights(float (&wr)[Geom<R>::NS][4], const 
 
 // deg(p) - 1 = sum of the 2|S| directed weights of p (column sum of misc/indexing.py:135): this wave's part of it,
 // from the registers load_weights just filled, in fp64.  A backward weight whose source pixel lies outside
-// the image is whatever the linear address wrapped to (the sweeps multiply it by a zero state); it is left out here.
+// the image reads a stored zero by construction of the planes (walk.hip, layout); it is masked out here all
+// the same, like degree_kernel does, so that the degree never depends on that property.
 template <int R, int QI>
 __device__ __forceinline__ void degree_partial(const float (&wr)[Geom<R>::NS][4], const WalkImg &I, int gy, int gx,
                                                double (&ds)[4]) {

@@ -5,7 +5,7 @@ import copy, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ.setdefault("MIOPEN_FIND_MODE", "2")
 import torch, torch.nn as nn, torch.nn.functional as F
-from irn_amd.net import resnet50_cam, weights, resnet50 as r50
+from irn_amd.net import resnet50_cam, weights
 dev = torch.device("cuda", 0)
 base = resnet50_cam.CAM(); base.load_state_dict(weights.random_cam_state(1)); base = base.to(dev).eval()
 
