@@ -33,6 +33,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s peak (6.3 TB/s achievable)
+FP32_VECTOR_PEAK_TFLOPS = 157.3   # same guide: fp32 vector (non-matrix) FMA peak, 256 CUs x 128 lanes x 2 flop x 2.4 GHz
 N_DIRS = {5: 34, 10: 152}
 
 
@@ -294,6 +295,9 @@ def main():
         sweeps_per_launch = n_sweeps if a.variant == 2 else 1
         bytes_per_launch = per_sweep_bytes * sweeps_per_launch
         avg_launch_ms = avg_sweep_ms * sweeps_per_launch
+        # the other ceiling: F = 2 * (2|S| + 1) flops per pixel, channel and sweep on the fp32 vector FMAs
+        flops_per_launch = sweeps_per_launch * sum(2.0 * (2 * n_dirs + 1) * s[0] * s[1] * s[2] for s in shapes)
+        fma_tflops = flops_per_launch / (avg_launch_ms * 1e-3) / 1e12
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic_%s.json" % a.workload)
         if os.path.exists(tpath):
@@ -334,6 +338,8 @@ def main():
                                   "traffic (see `traffic`) is far below that figure and `frac` may exceed 1: it is faster than "
                                   "any kernel that re-reads the weights from HBM every sweep can be; it is bound by the "
                                   "tile-to-tile exchange latency and fp32 VALU issue, not by HBM") if a.variant == 2 else None,
+                         "fp32_fma": {"achieved": fma_tflops, "peak": FP32_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                      "frac": fma_tflops / FP32_VECTOR_PEAK_TFLOPS},
                          "sweep_share_of_step": sweep_ms / (1e3 * elapsed)},
             "label_checksum": checksum,
         }

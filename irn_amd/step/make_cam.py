@@ -59,13 +59,13 @@ def _work(process_id, model, dataset, args):
     n_gpus = len(dataset)
     loader = DataLoader(databin, shuffle=False, num_workers=int(args.num_workers) // n_gpus, pin_memory=False)
     writer = _common.AsyncWriter()
+    scales = tuple(float(s) for s in args.cam_scales)
     with torch.no_grad(), torch.cuda.device(process_id):
         model.cuda()
         for it, pack in enumerate(loader):
             img_name = pack["name"][0]
             label = pack["label"][0]
             size = (int(pack["size"][0]), int(pack["size"][1]))
-            scales = tuple(float(s) for s in args.cam_scales)
             outputs = [model(img) for img in _common.device_images(pack, scales)]
             keys, cam, high_res = merge_scales(outputs, size, label.cuda())
             writer.submit(np.save, os.path.join(args.cam_out_dir, img_name + ".npy"),
