@@ -137,3 +137,29 @@ def test_msf_pack_refuses_cpu_tensors():
         ops.msf_pack(torch.zeros((4, 4, 3), dtype=torch.uint8), (1.0,))
     with pytest.raises(ValueError, match="GPU tensor"):
         ops.bicubic_resize(torch.zeros((4, 4, 3), dtype=torch.uint8), (2, 2))
+
+
+def test_dataset_raw_mode_hands_over_the_decoded_image(tmp_path):
+    """raw=True: the item carries the decoded uint8 image (the steps build the scales on the GPU); name, size and
+    label are those of the reference-format item."""
+    from PIL import Image
+    from irn_amd import synth
+    from irn_amd.voc12 import dataloader
+    root = tmp_path / "voc"
+    (root / "JPEGImages").mkdir(parents=True)
+    img = synth.photo(37, 52, seed=3)
+    Image.fromarray(img).save(root / "JPEGImages" / "2008_000001.jpg", quality=95)
+    (tmp_path / "train.txt").write_text("2008_000001\n")
+    lab = np.zeros(20, np.float32)
+    lab[[2, 7]] = 1
+    kw = dict(voc12_root=str(root), scales=(1.0, 0.5), cls_labels={2008000001: lab})
+    raw = dataloader.VOC12ClassificationDatasetMSF(str(tmp_path / "train.txt"), raw=True, **kw)[0]
+    ref = dataloader.VOC12ClassificationDatasetMSF(str(tmp_path / "train.txt"), **kw)[0]
+    decoded = np.asarray(Image.open(root / "JPEGImages" / "2008_000001.jpg").convert("RGB"))
+    assert raw["img"].dtype == torch.uint8 and np.array_equal(raw["img"].numpy(), decoded)
+    assert raw["name"] == ref["name"] and raw["size"] == ref["size"] == (37, 52)
+    assert torch.equal(raw["label"], ref["label"])
+    # the host loop over the same decoded image is what the oracle restates
+    from oracle import msf_oracle as M
+    for a, b in zip(ref["img"], M.msf_item(decoded, (1.0, 0.5))):
+        assert np.array_equal(a, b)
