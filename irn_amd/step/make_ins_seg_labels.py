@@ -84,7 +84,7 @@ def _work(process_id, model, dataset, args):
     databin = dataset[process_id]
     n_gpus = len(dataset)
     loader = DataLoader(databin, shuffle=False, num_workers=int(args.num_workers) // n_gpus, pin_memory=False)
-    batch = int(getattr(args, "walk_batch", 32))   # images per walk launch (results per image unchanged)
+    batch = int(getattr(args, "walk_batch", 0) or 32)   # images per walk launch (results per image unchanged)
     with torch.no_grad(), torch.cuda.device(process_id):
         model.cuda()
         walker = indexing.RandomWalk(RADIUS)

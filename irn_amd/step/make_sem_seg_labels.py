@@ -46,7 +46,7 @@ def _work(process_id, model, dataset, args):
     databin = dataset[process_id]
     n_gpus = len(dataset)
     loader = DataLoader(databin, shuffle=False, num_workers=int(args.num_workers) // n_gpus, pin_memory=False)
-    batch = int(getattr(args, "walk_batch", 64))   # 64 VOC-size images = 3-4 rounds of the resident walk
+    batch = int(getattr(args, "walk_batch", 0) or 64)   # 64 VOC-size images = 3-4 rounds of the resident walk
     with torch.no_grad(), torch.cuda.device(process_id):
         model.cuda()
         walker = indexing.RandomWalk(RADIUS)

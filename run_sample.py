@@ -38,7 +38,8 @@ def build_parser():
     p.add_argument("--exp_times", default=8, type=int)
     p.add_argument("--ins_seg_bg_thres", default=0.25, type=float)
     p.add_argument("--sem_seg_bg_thres", default=0.25, type=float)
-    p.add_argument("--walk_batch", default=16, type=int, help="images per random-walk launch (not in the reference)")
+    p.add_argument("--walk_batch", default=0, type=int,
+                   help="images per random-walk launch (not in the reference); 0 = the step's default (64 sem-seg, 32 ins-seg)")
     p.add_argument("--log_name", default="sample_train_eval", type=str)
     p.add_argument("--cam_weights_name", default="sess/res50_cam.pth", type=str)
     p.add_argument("--irn_weights_name", default="sess/res50_irn.pth", type=str)
