@@ -80,3 +80,28 @@ def test_device_entry_points_fail_loudly_without_gpu():
     from irn_amd.misc import indexing
     with pytest.raises(ValueError):
         indexing.propagate_to_edge(torch.zeros(1, 4, 4), torch.zeros(1, 4, 4))  # CPU tensors are refused
+
+
+def test_argument_validation_of_the_newer_entry_points():
+    """Null pointers, non-positive sizes and unsupported channel counts are refused with IRN_ERR_ARG before any
+    device work (no GPU needed); the message names the entry point."""
+    L = _lib.lib
+    assert L.irn_msf_pack(None, 4, 4, 1, None, None, None, None, None, None) == 1
+    assert b"irn_msf_pack" in L.irn_last_error()
+    assert L.irn_bicubic_resize_u8(None, 4, 4, 3, 2, 2, None, None, None) == 1
+    one = C.c_void_p(64)                                                       # never dereferenced on these paths
+    assert L.irn_bicubic_resize_u8(one, 4, 4, 2, 2, 2, one, one, None) == 1   # 2 channels
+    assert b"channels" in L.irn_last_error()
+    assert L.irn_bicubic_resize_u8(one, 0, 4, 3, 2, 2, one, one, None) == 1   # empty image
+    assert L.irn_bicubic_resize_u8(one, 4, 4, 3, 2, 3, one, None, None) == 1  # width changes: scratch required
+    assert L.irn_bicubic_scratch_bytes(375, 500, 188, 250, 3) == 375 * 250 * 3
+    assert L.irn_bicubic_scratch_bytes(375, 500, 188, 500, 3) == 0            # vertical pass only
+    ks = C.c_int32()
+    assert L.irn_bicubic_plan(0, 4, C.byref(ks), None, None, None, 0) == 1
+    assert L.irn_bicubic_plan(8, 4, C.byref(ks), None, None, None, 0) == 0 and ks.value == 9   # support 4 -> 2*4+1
+    lo = (C.c_int32 * 4)()
+    assert L.irn_bicubic_plan(8, 4, C.byref(ks), lo, lo, lo, 3) == 1          # weights array too small
+    assert L.irn_pair_displacement(None, 1, 2, 20, 27, 5, None, None) == 1
+    assert L.irn_pair_displacement(one, 1, 2, 4, 27, 5, one, None) == 1       # grid smaller than the radius
+    assert b"too small" in L.irn_last_error()
+    assert L.irn_pair_displacement_backward(one, 40000, 2, 20, 27, 5, one, None) == 1    # batch * channels > 65535

@@ -208,3 +208,29 @@ def test_pair_displacement_restatement_vs_reference_autograd(golden, r):
     g = np.random.RandomState(11 + r).randn(*want.shape).astype(np.float32)
     gd = O.pair_displacement_backward(g, r, disp.shape[2:])
     assert np.abs(gd - pd["r%d_gdisp" % r]).max() <= 1e-6 * np.abs(pd["r%d_gdisp" % r]).max()
+
+
+def test_pair_displacement_backward_is_the_adjoint():
+    """<J x, g> == <x, J^T g> for random x, g: the backward restatement is the transpose of the (linear) forward."""
+    rng = np.random.RandomState(5)
+    for r, (hp, wp) in ((3, (9, 11)), (5, (13, 21))):
+        x = rng.randn(2, 2, hp, wp).astype(np.float32)
+        y = O.pair_displacement(x, r)
+        g = rng.randn(*y.shape).astype(np.float32)
+        lhs = float((y.astype(np.float64) * g).sum())
+        rhs = float((x.astype(np.float64) * O.pair_displacement_backward(g, r, (hp, wp))).sum())
+        assert abs(lhs - rhs) <= 1e-5 * max(1.0, abs(lhs))
+
+
+def test_msf_oracle_identity_and_flip_properties():
+    from irn_amd import synth
+    from oracle import msf_oracle as M
+    img = synth.photo(33, 47, seed=9)
+    assert M.pil_bicubic_resize(img, (33, 47)) is img                      # both passes skipped (misc/imutils.py:9-10)
+    items = M.msf_item(img, (1.0, 1.5))
+    for it in items:
+        assert np.array_equal(it[1], it[0][..., ::-1])
+    # resizing commutes with a horizontal mirror only up to rounding of the centre taps; it does commute with channel
+    # permutation exactly (bands are independent)
+    perm = img[..., ::-1]
+    assert np.array_equal(M.pil_bicubic_resize(perm, (50, 70)), M.pil_bicubic_resize(img, (50, 70))[..., ::-1])
