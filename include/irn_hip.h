@@ -112,15 +112,27 @@ int irn_walk_run(irn_walk_ctx *ctx, const float *const *edge_dev, const float *c
                  float *const *out_dev, float beta, int n_sweeps,
                  void *workspace_dev, size_t workspace_bytes, void *stream);
 
-/* Tuning knobs (performance only, never results): name/value pairs, e.g. "variant" = 0 generic
- * table-driven sweep, 1 = register-blocked sweep for radius 5/10 (default).  Unknown names fail. */
+/* Tuning knobs (performance only, never results): name/value pairs, e.g. "variant" = 0 generic table-driven sweep
+ * (any radius; the default for radii other than 5 and 10), 1 = register-blocked streaming sweep (radius 5/10),
+ * 2 = weights-stationary persistent walk (radius 5/10; the DEFAULT there, with a per-batch fall-back to variant 1
+ * when an image does not fit one round of workgroups or the grid cannot be co-resident); "cooperative" = 1 (default)
+ * launches the persistent kernel with hipLaunchCooperativeKernel.  Unknown names fail. */
 int irn_walk_set_option(irn_walk_ctx *ctx, const char *name, int value);
 
-/* The weights-stationary persistent kernel ("variant" = 2) polls neighbouring tiles with a bounded
- * wait; if a launch ever gave up, the first irn_walk_check after the stream has been synchronised
- * returns IRN_ERR_STATE (and the outputs of that run are invalid).  Always IRN_OK for the streaming
- * variants. */
+/* The weights-stationary persistent kernel ("variant" = 2) runs one workgroup per compute unit and its tiles wait for
+ * each other inside the launch, with a bounded wait: when the grid does not become co-resident in time (another
+ * process, stream or partition holds compute units) a launch gives up instead of hanging.
+ *   irn_walk_sync   waits for the last irn_walk_run; if that launch gave up, runs the batch again on the streaming
+ *                   sweeps (same operator, kernel boundaries instead of in-launch hand-offs) and waits for it, so the
+ *                   outputs are valid whenever it returns IRN_OK.  *fell_back (may be NULL) = 1 when that happened.
+ *                   This is the call to make before consuming the outputs of a run.
+ *   irn_walk_check  no waiting, no repair: IRN_ERR_STATE if a launch completed so far gave up and irn_walk_sync has
+ *                   not handled it (the outputs of that run are invalid) — what a benchmark wants, where a silent
+ *                   fall-back would misreport.  Always IRN_OK for the streaming variants.
+ *   irn_walk_fallback_runs   how many batches irn_walk_sync has re-run so far (monitoring). */
+int irn_walk_sync(irn_walk_ctx *ctx, int *fell_back);
 int irn_walk_check(irn_walk_ctx *ctx);
+int irn_walk_fallback_runs(irn_walk_ctx *ctx);
 
 /* Diagnostic (option "profile" = 1, resident walk only): per-sweep time stamps of two workgroups of
  * the first round — host_out is int64 [2][256][4] = {sweep start, state staged, first partial sums
@@ -213,6 +225,17 @@ size_t irn_cluster_scratch_bytes(int h, int w);
 int irn_cluster_centroids(const int32_t *centroids_dev, const float *dp_dev, int h, int w, float thres,
                           int32_t *cluster_map_dev, int *k_out, void *scratch_dev, void *stream);
 
+/* Batched forms (the loop over images of step/make_ins_seg_labels.py:119-133): HOST arrays of device pointers and
+ * sizes, one launch sequence for the whole batch, and NOTHING synchronises — the instance counts stay on the device
+ * (k_dev: dev int32 [n_images]) and the caller fetches all of them with one transfer before it configures the walk
+ * (c[i] = n_classes[i] * K[i]).  scratch: irn_cluster_batch_scratch_bytes. */
+int irn_find_centroids_batch(int n_images, const float *const *dp_dev, const int32_t *h, const int32_t *w,
+                             int iterations, int32_t *const *centroids_dev, void *stream);
+size_t irn_cluster_batch_scratch_bytes(int n_images, const int32_t *h, const int32_t *w);
+int irn_cluster_centroids_batch(int n_images, const int32_t *const *centroids_dev, const float *const *dp_dev,
+                                const int32_t *h, const int32_t *w, float thres, int32_t *const *cluster_map_dev,
+                                int32_t *k_dev, void *scratch_dev, void *stream);
+
 /* 4-connected component labelling of a byte mask [n,h,w] (non-zero = foreground), ids 1.. per
  * image in raster order of first pixel, 0 = background — the skimage.measure.label(connectivity=1,
  * background=0) call of step/make_ins_seg_labels.py:66,92.  n_labels_dev: int32 [n] component
@@ -239,6 +262,21 @@ int irn_detect_instance_count(const float *rw_up_dev, const int32_t *argmax_dev,
 int irn_detect_instance_emit(const float *rw_up_dev, const int32_t *argmax_dev, int n_channels, int h, int w, int n_det,
                              double min_area, float *score_dev, int32_t *channel_dev, uint8_t *mask_dev,
                              void *scratch_dev, void *stream);
+
+
+/* Batched forms: one labelling pass sequence for all images of a batch.  _batch_count writes the detection counts
+ * to n_det_dev (dev int32 [n_images]) and does NOT synchronise; the caller reads them with one transfer, sizes the
+ * outputs and calls _batch_emit with the same inputs and scratch plus the counts (host) — images with n_det[i] == 0
+ * are skipped (their output pointers may be NULL); every mask block must be 16-byte aligned.  min_area: host [n_images].
+ * scratch: irn_detect_batch_scratch_bytes. */
+size_t irn_detect_batch_scratch_bytes(int n_images, const int32_t *n_channels, const int32_t *h, const int32_t *w);
+int irn_detect_instance_batch_count(int n_images, const float *const *rw_up_dev, const int32_t *const *argmax_dev,
+                                    const int32_t *n_channels, const int32_t *h, const int32_t *w, int32_t *n_det_dev,
+                                    void *scratch_dev, void *stream);
+int irn_detect_instance_batch_emit(int n_images, const float *const *rw_up_dev, const int32_t *const *argmax_dev,
+                                   const int32_t *n_channels, const int32_t *h, const int32_t *w, const int32_t *n_det,
+                                   const double *min_area, float *const *score_dev, int32_t *const *channel_dev,
+                                   uint8_t *const *mask_dev, void *scratch_dev, void *stream);
 
 #ifdef __cplusplus
 }

@@ -40,7 +40,9 @@ _SIGS = {
     "irn_walk_configure": (i32, [vp, i32, pi32, pi32, pi32, C.POINTER(sz)]),
     "irn_walk_run": (i32, [vp, ppv, ppv, ppv, pi32, ppv, f32, i32, vp, sz, vp]),
     "irn_walk_set_option": (i32, [vp, C.c_char_p, i32]),
+    "irn_walk_sync": (i32, [vp, C.POINTER(i32)]),
     "irn_walk_check": (i32, [vp]),
+    "irn_walk_fallback_runs": (i32, [vp]),
     "irn_walk_read_profile": (i32, [vp, vp]),
     "irn_walk_enable_timing": (i32, [vp, i32]),
     "irn_walk_last_sweep_ms": (i32, [vp, C.POINTER(f32), C.POINTER(i32)]),
@@ -54,11 +56,17 @@ _SIGS = {
     "irn_find_centroids": (i32, [vp, i32, i32, i32, vp, vp]),
     "irn_cluster_scratch_bytes": (sz, [i32, i32]),
     "irn_cluster_centroids": (i32, [vp, vp, i32, i32, f32, vp, C.POINTER(i32), vp, vp]),
+    "irn_find_centroids_batch": (i32, [i32, ppv, pi32, pi32, i32, ppv, vp]),
+    "irn_cluster_batch_scratch_bytes": (sz, [i32, pi32, pi32]),
+    "irn_cluster_centroids_batch": (i32, [i32, ppv, ppv, pi32, pi32, f32, ppv, vp, vp, vp]),
     "irn_ccl_scratch_bytes": (sz, [i32, i32, i32]),
     "irn_label4": (i32, [vp, i32, i32, i32, vp, vp, vp, vp]),
     "irn_detect_scratch_bytes": (sz, [i32, i32, i32]),
     "irn_detect_instance_count": (i32, [vp, vp, i32, i32, i32, C.POINTER(i32), vp, vp]),
     "irn_detect_instance_emit": (i32, [vp, vp, i32, i32, i32, i32, C.c_double, vp, vp, vp, vp, vp]),
+    "irn_detect_batch_scratch_bytes": (sz, [i32, pi32, pi32, pi32]),
+    "irn_detect_instance_batch_count": (i32, [i32, ppv, ppv, pi32, pi32, pi32, vp, vp, vp]),
+    "irn_detect_instance_batch_emit": (i32, [i32, ppv, ppv, pi32, pi32, pi32, pi32, C.POINTER(C.c_double), ppv, ppv, ppv, vp, vp]),
 }
 
 EXPORTS = tuple(_SIGS)

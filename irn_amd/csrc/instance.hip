@@ -27,8 +27,19 @@ __device__ __forceinline__ double bilinear_inc(const float *__restrict__ f, int 
     return __dadd_rn(__dadd_rn(__dadd_rn(t0, t1), t2), t3);
 }
 
-__global__ __launch_bounds__(256) void centroid_kernel(const float *__restrict__ dp, int h, int w, int iters,
-                                                       int32_t *__restrict__ out) {
+struct CenJob {
+    const float *dp;     // [2,h,w]
+    int32_t *out;        // [2,h,w]
+    int h, w;
+};
+
+// grid.y = image of the batch (every pixel's trajectory is independent; a batch fills the chip where one 128x128
+// image is 64 workgroups of latency-bound gathers)
+__global__ __launch_bounds__(256) void centroid_kernel(const CenJob *__restrict__ jobs, int iters) {
+    const CenJob J = jobs[blockIdx.y];
+    const float *__restrict__ dp = J.dp;
+    int32_t *__restrict__ out = J.out;
+    const int h = J.h, w = J.w;
     const int p = blockIdx.x * 256 + threadIdx.x;
     const int n = h * w;
     if (p >= n) return;
@@ -148,33 +159,99 @@ __global__ __launch_bounds__(256) void ccl_relabel_kernel(const int *__restrict_
 }
 
 // ---------------------------------------------------------------------------------------------
-// cluster_centroids
+// cluster_centroids, batched (grid.y or grid.x = image): K of every image stays on the device, the caller reads
+// all of them with ONE transfer per batch (step/make_ins_seg_labels.py:58-75 returns K to the host per image).
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void weak_mask_kernel(const float *__restrict__ dp, int n, float thres,
-                                                        uint8_t *__restrict__ mask) {
+struct ClusterJob {
+    const int32_t *centroids;   // [2,h,w]
+    const float *dp;            // [2,h,w]
+    int32_t *cluster_map;       // [h,w] out
+    int *parent, *rank;         // [npx] union-find forest of the weak-displacement mask / rank of its roots
+    int32_t *picked;            // [npx]
+    int *present;               // [npx + 2]
+    int32_t *k_out;             // -> k_dev[i]
+    int h, w;
+};
+
+// weak = |dp| < thres, np.sqrt(dp[1]**2 + dp[0]**2) in float32 with every operation rounded
+// (step/make_ins_seg_labels.py:61); forest initialised on the mask; `present` cleared
+__global__ __launch_bounds__(256) void cluster_init_kernel(const ClusterJob *__restrict__ jobs, float thres) {
+    const ClusterJob J = jobs[blockIdx.y];
+    const int n = J.h * J.w;
     const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p < 2) J.present[n + p] = 0;
     if (p >= n) return;
-    // np.sqrt(dp[1]**2 + dp[0]**2) in float32, each op rounded (step/make_ins_seg_labels.py:61)
-    const float a = dp[n + p], b = dp[p];
+    const float a = J.dp[n + p], b = J.dp[p];
     const float s = __fsqrt_rn(__fadd_rn(__fmul_rn(a, a), __fmul_rn(b, b)));
-    mask[p] = s < thres ? 1 : 0;
+    J.parent[p] = s < thres ? p : -1;
+    J.present[p] = 0;
+}
+
+__global__ __launch_bounds__(256) void cluster_merge_kernel(const ClusterJob *__restrict__ jobs) {
+    const ClusterJob J = jobs[blockIdx.y];
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= J.h * J.w) return;
+    int *parent = J.parent;
+    if (parent[p] < 0) return;
+    const int y = p / J.w, x = p - y * J.w;
+    if (x > 0 && parent[p - 1] >= 0) uf_union(parent, p, p - 1);
+    if (y > 0 && parent[p - J.w] >= 0) uf_union(parent, p, p - J.w);
+}
+
+__global__ __launch_bounds__(256) void cluster_flatten_kernel(const ClusterJob *__restrict__ jobs) {
+    const ClusterJob J = jobs[blockIdx.y];
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= J.h * J.w) return;
+    int *parent = J.parent;
+    if (parent[p] < 0) return;
+    int r = p;
+    while (parent[r] != r) r = parent[r];      // all unions are done: roots are final
+    parent[p] = r;
+}
+
+// one workgroup per image: rank[root] = 1 + number of roots before it in raster order (skimage numbering)
+__global__ __launch_bounds__(1024) void cluster_rank_kernel(const ClusterJob *__restrict__ jobs) {
+    __shared__ int sums[1024];
+    const ClusterJob J = jobs[blockIdx.x];
+    const int npx = J.h * J.w;
+    const int *parent = J.parent;
+    const int chunk = (npx + 1023) / 1024;
+    const int lo = min(npx, (int)threadIdx.x * chunk), hi = min(npx, lo + chunk);
+    int cnt = 0;
+    for (int p = lo; p < hi; ++p) cnt += (parent[p] == p);
+    sums[threadIdx.x] = cnt;
+    __syncthreads();
+    for (int s = 1; s < 1024; s <<= 1) {
+        const int v = threadIdx.x >= s ? sums[threadIdx.x - s] : 0;
+        __syncthreads();
+        sums[threadIdx.x] += v;
+        __syncthreads();
+    }
+    int run = sums[threadIdx.x] - cnt;
+    for (int p = lo; p < hi; ++p)
+        if (parent[p] == p) J.rank[p] = ++run;
 }
 
 // picked[p] = label at centroid(p) (+1, as the reference adds before compress_range); mark presence
-__global__ __launch_bounds__(256) void pick_kernel(const int32_t *__restrict__ centroids,
-                                                   const int32_t *__restrict__ labels, int n, int w,
-                                                   int32_t *__restrict__ picked, int *__restrict__ present) {
+__global__ __launch_bounds__(256) void cluster_pick_kernel(const ClusterJob *__restrict__ jobs) {
+    const ClusterJob J = jobs[blockIdx.y];
+    const int n = J.h * J.w;
     const int p = blockIdx.x * 256 + threadIdx.x;
     if (p >= n) return;
-    const int v = labels[centroids[p] * w + centroids[n + p]] + 1;
-    picked[p] = v;
-    present[v] = 1;
+    const int c = J.centroids[p] * J.w + J.centroids[n + p];
+    const int root = J.parent[c];
+    const int v = (root < 0 ? 0 : J.rank[root]) + 1;
+    J.picked[p] = v;
+    J.present[v] = 1;
 }
 
-// single workgroup: renumber the distinct values of `picked` ascending to 0..K-1 (compress_range,
+// one workgroup per image: renumber the distinct values of `picked` ascending to 0..K-1 (compress_range,
 // misc/imutils.py:182-190; its final "- min" is a no-op because the smallest value maps to 0)
-__global__ __launch_bounds__(1024) void compress_kernel(int *__restrict__ present, int n_vals, int *__restrict__ k_out) {
+__global__ __launch_bounds__(1024) void cluster_compress_kernel(const ClusterJob *__restrict__ jobs) {
     __shared__ int sums[1024];
+    const ClusterJob J = jobs[blockIdx.x];
+    int *present = J.present;
+    const int n_vals = J.h * J.w + 2;       // label values lie in [0, npx/2+1]; +1 shifts them to [1, npx/2+2]
     const int chunk = (n_vals + 1023) / 1024;
     const int lo = min(n_vals, (int)threadIdx.x * chunk), hi = min(n_vals, lo + chunk);
     int cnt = 0;
@@ -189,18 +266,18 @@ __global__ __launch_bounds__(1024) void compress_kernel(int *__restrict__ presen
     }
     int run = sums[threadIdx.x] - cnt;
     for (int v = lo; v < hi; ++v) present[v] = present[v] ? run++ : -1;   // now: new id of value v
-    if (threadIdx.x == 1023) *k_out = sums[1023];
+    if (threadIdx.x == 1023) *J.k_out = sums[1023];
 }
 
-__global__ __launch_bounds__(256) void remap_kernel(const int32_t *__restrict__ picked, const int *__restrict__ newid,
-                                                    int n, int32_t *__restrict__ cluster_map) {
+__global__ __launch_bounds__(256) void cluster_remap_kernel(const ClusterJob *__restrict__ jobs) {
+    const ClusterJob J = jobs[blockIdx.y];
     const int p = blockIdx.x * 256 + threadIdx.x;
-    if (p >= n) return;
-    cluster_map[p] = newid[picked[p]];
+    if (p >= J.h * J.w) return;
+    J.cluster_map[p] = J.present[J.picked[p]];
 }
 
 // ---------------------------------------------------------------------------------------------
-// detect_instance (reference step/make_ins_seg_labels.py:82-105) on the device.
+// detect_instance (reference step/make_ins_seg_labels.py:82-105) on the device, batched over images.
 //
 // The reference labels the 4-connected components of every channel's mask separately; the masks are
 // the one-hot planes of ONE argmax map (:145-147), so they are disjoint and all components come
@@ -208,66 +285,119 @@ __global__ __launch_bounds__(256) void remap_kernel(const int32_t *__restrict__ 
 // Detections are ordered like the reference's: channel ascending, then skimage's label order =
 // raster order of each component's first pixel = of its union-find root.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void det_init_kernel(const int32_t *__restrict__ cls, int *__restrict__ parent, int npx) {
+struct DetJob {
+    const float *rw_up;         // [n_channels,h,w]
+    const int32_t *cls;         // [h,w] argmax (0 = background, c+1 = channel c)
+    int *parent, *prov, *newid, *area, *score_bits;   // [npx] each
+    long long *keys;            // [npx]
+    int32_t *counter;           // -> n_det_dev[i]
+    float *score;               // [n_det]      (emit)
+    int32_t *channel;           // [n_det]      (emit)
+    uint8_t *mask;              // [n_det,h,w]  (emit)
+    double min_area;
+    int h, w, n_det;
+};
+
+__global__ __launch_bounds__(256) void det_init_kernel(const DetJob *__restrict__ jobs) {
+    const DetJob J = jobs[blockIdx.y];
     const int p = blockIdx.x * 256 + threadIdx.x;
-    if (p < npx) parent[p] = cls[p] > 0 ? p : -1;
+    if (p < J.h * J.w) J.parent[p] = J.cls[p] > 0 ? p : -1;
 }
 
-__global__ __launch_bounds__(256) void det_merge_kernel(const int32_t *__restrict__ cls, int *__restrict__ parent, int h, int w) {
+__global__ __launch_bounds__(256) void det_merge_kernel(const DetJob *__restrict__ jobs) {
+    const DetJob J = jobs[blockIdx.y];
     const int p = blockIdx.x * 256 + threadIdx.x;
-    if (p >= h * w) return;
+    if (p >= J.h * J.w) return;
+    const int32_t *__restrict__ cls = J.cls;
     const int c = cls[p];
     if (c <= 0) return;
-    const int y = p / w, x = p - y * w;
-    if (x > 0 && cls[p - 1] == c) uf_union(parent, p, p - 1);
-    if (y > 0 && cls[p - w] == c) uf_union(parent, p, p - w);
+    const int y = p / J.w, x = p - y * J.w;
+    if (x > 0 && cls[p - 1] == c) uf_union(J.parent, p, p - 1);
+    if (y > 0 && cls[p - J.w] == c) uf_union(J.parent, p, p - J.w);
+}
+
+__global__ __launch_bounds__(256) void det_flatten_kernel(const DetJob *__restrict__ jobs) {
+    const DetJob J = jobs[blockIdx.y];
+    const int p = blockIdx.x * 256 + threadIdx.x;
+    if (p >= J.h * J.w) return;
+    int *parent = J.parent;
+    if (parent[p] < 0) return;
+    int r = p;
+    while (parent[r] != r) r = parent[r];
+    parent[p] = r;
 }
 
 // Every root (= first raster pixel of its component) claims a provisional id and records its sort key
 // channel * npx + pixel: detections are ordered channel ascending, then by first pixel (skimage's
 // label order inside a channel).
-__global__ __launch_bounds__(256) void det_roots_kernel(const int32_t *__restrict__ cls, const int *__restrict__ parent,
-                                                         int *__restrict__ prov, long long *__restrict__ keys,
-                                                         int *__restrict__ counter, int npx) {
+__global__ __launch_bounds__(256) void det_roots_kernel(const DetJob *__restrict__ jobs) {
+    const DetJob J = jobs[blockIdx.y];
+    const int npx = J.h * J.w;
     const int p = blockIdx.x * 256 + threadIdx.x;
     if (p >= npx) return;
-    if (parent[p] == p) {
-        const int id = atomicAdd(counter, 1);
-        prov[p] = id;
-        keys[id] = (long long)(cls[p] - 1) * npx + p;
+    if (J.parent[p] == p) {
+        const int id = atomicAdd(J.counter, 1);
+        J.prov[p] = id;
+        J.keys[id] = (long long)(J.cls[p] - 1) * npx + p;
     }
 }
 
-// final id of provisional detection i = number of keys below its own (keys are distinct); n is a few
-// hundred at most, one workgroup does the n^2 / 1024 comparisons.  Also zeroes the statistics.
-__global__ __launch_bounds__(1024) void det_order_kernel(const long long *__restrict__ keys, int *__restrict__ newid,
-                                                         int *__restrict__ area, int *__restrict__ score_bits,
-                                                         int32_t *__restrict__ channel, int n, int npx) {
-    for (int i = threadIdx.x; i < n; i += 1024) {
-        const long long k = keys[i];
-        int r = 0;
-        for (int j = 0; j < n; ++j) r += keys[j] < k;
-        newid[i] = r;
-        channel[r] = (int32_t)(k / npx);
-        area[i] = 0;
-        score_bits[i] = 0;
+// final id of provisional detection i = number of keys below its own (keys are distinct).  A handful to a few
+// hundred detections is the normal case; a noisy class map can have tens of thousands of fragments, so the n^2
+// comparisons are spread over ceil(n / 256) workgroups per image with the keys staged through LDS (the reference's
+// labelling is linear in the fragment count; one 1024-thread workgroup would stall for seconds).  Also zeroes the
+// statistics.
+__global__ __launch_bounds__(256) void det_order_kernel(const DetJob *__restrict__ jobs) {
+    __shared__ long long tile[1024];
+    const DetJob J = jobs[blockIdx.y];
+    const int n = J.n_det;
+    if ((int)blockIdx.x * 256 >= n) return;
+    const int npx = J.h * J.w;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const long long k = i < n ? J.keys[i] : 0;
+    int r = 0;
+    for (int base = 0; base < n; base += 1024) {
+        const int cnt = min(1024, n - base);
+        for (int j = threadIdx.x; j < cnt; j += 256) tile[j] = J.keys[base + j];
+        __syncthreads();
+        for (int j = 0; j < cnt; ++j) r += tile[j] < k;
+        __syncthreads();
+    }
+    if (i < n) {
+        J.newid[i] = r;
+        J.channel[r] = (int32_t)(k / npx);
+        J.area[i] = 0;
+        J.score_bits[i] = 0;
     }
 }
 
-// Pixel p belongs to detection newid[prov[root(p)]]: its mask byte, and area / max score per detection.  Scores are compared as int bit patterns: the reference takes max(score * mask), which
-// is >= 0 whatever the scores are, and so is a maximum that starts from +0.
-__global__ __launch_bounds__(256) void det_stats_kernel(const int32_t *__restrict__ cls, const int *__restrict__ parent,
-                                                        const int *__restrict__ prov, const int *__restrict__ newid,
-                                                        const float *__restrict__ rw_up, int *__restrict__ area,
-                                                        int *__restrict__ score_bits, uint8_t *__restrict__ mask, int npx) {
+__global__ __launch_bounds__(256) void det_zero_masks_kernel(const DetJob *__restrict__ jobs) {
+    const DetJob J = jobs[blockIdx.y];
+    const size_t total = (size_t)J.n_det * J.h * J.w;
+    uint8_t *m = J.mask;
+    // the packed output keeps every mask block 16-byte aligned (irn_detect_instance_batch_emit checks)
+    const size_t n16 = total / 16;
+    uint4 *m16 = reinterpret_cast<uint4 *>(m);
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) m16[i] = make_uint4(0, 0, 0, 0);
+    if (blockIdx.x == 0)
+        for (size_t i = n16 * 16 + threadIdx.x; i < total; i += 256) m[i] = 0;
+}
+
+// Pixel p belongs to detection newid[prov[root(p)]]: its mask byte, and area / max score per detection.  Scores are
+// compared as int bit patterns: the reference takes max(score * mask), which is >= 0 whatever the scores are, and so
+// is a maximum that starts from +0.
+__global__ __launch_bounds__(256) void det_stats_kernel(const DetJob *__restrict__ jobs) {
+    const DetJob J = jobs[blockIdx.y];
+    if (J.n_det < 1) return;
+    const int npx = J.h * J.w;
     const int p = blockIdx.x * 256 + threadIdx.x;
-    const int c = p < npx ? cls[p] : 0;
+    const int c = p < npx ? J.cls[p] : 0;
     const bool fg = c > 0;
     int d = -1, bits = 0;
     if (fg) {
-        d = newid[prov[parent[p]]];
-        mask[(long)d * npx + p] = 1;
-        const float sc = rw_up[(long)(c - 1) * npx + p];
+        d = J.newid[J.prov[J.parent[p]]];
+        J.mask[(long)d * npx + p] = 1;
+        const float sc = J.rw_up[(long)(c - 1) * npx + p];
         bits = sc > 0.f ? __float_as_int(sc) : 0;
     }
     // A wave's 64 consecutive pixels nearly always lie in ONE detection: one pair of atomics per wave then
@@ -279,20 +409,20 @@ __global__ __launch_bounds__(256) void det_stats_kernel(const int32_t *__restric
         int mx = bits;
         for (int sft = 32; sft > 0; sft >>= 1) mx = max(mx, __shfl_xor(mx, sft));
         if ((threadIdx.x & 63) == 0) {
-            atomicAdd(area + d0, __popcll(act));
-            if (mx > 0) atomicMax(score_bits + d0, mx);
+            atomicAdd(J.area + d0, __popcll(act));
+            if (mx > 0) atomicMax(J.score_bits + d0, mx);
         }
     } else if (fg) {
-        atomicAdd(area + d, 1);
-        if (bits > 0) atomicMax(score_bits + d, bits);
+        atomicAdd(J.area + d, 1);
+        if (bits > 0) atomicMax(J.score_bits + d, bits);
     }
 }
 
-__global__ __launch_bounds__(256) void det_final_kernel(const int *__restrict__ area, const int *__restrict__ score_bits,
-                                                        double min_area, float *__restrict__ score, int n_det) {
+__global__ __launch_bounds__(256) void det_final_kernel(const DetJob *__restrict__ jobs) {
+    const DetJob J = jobs[blockIdx.y];
     const int d = blockIdx.x * 256 + threadIdx.x;
-    if (d >= n_det) return;
-    score[d] = ((double)area[d] < min_area) ? 0.f : __int_as_float(score_bits[d]);
+    if (d >= J.n_det) return;
+    J.score[d] = ((double)J.area[d] < J.min_area) ? 0.f : __int_as_float(J.score_bits[d]);   // statistics are kept by FINAL id
 }
 
 int run_label4(const uint8_t *mask, int n, int h, int w, int32_t *labels, int32_t *n_labels, void *scratch,
@@ -320,15 +450,33 @@ int run_label4(const uint8_t *mask, int n, int h, int w, int32_t *labels, int32_
 
 using namespace irn;
 
+extern "C" int irn_find_centroids_batch(int n_images, const float *const *dp_dev, const int32_t *h, const int32_t *w,
+                                        int iterations, int32_t *const *centroids_dev, void *stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (n_images < 1 || !dp_dev || !h || !w || !centroids_dev || iterations < 0)
+        return fail(IRN_ERR_ARG, "irn_find_centroids_batch: bad argument");
+    std::vector<CenJob> jobs(n_images);
+    int max_n = 0;
+    for (int i = 0; i < n_images; ++i) {
+        if (!dp_dev[i] || !centroids_dev[i] || h[i] < 1 || w[i] < 1)
+            return fail(IRN_ERR_ARG, "irn_find_centroids_batch: image %d: bad argument", i);
+        jobs[i] = CenJob{dp_dev[i], centroids_dev[i], h[i], w[i]};
+        max_n = std::max(max_n, h[i] * w[i]);
+    }
+    CenJob *jobs_dev = nullptr;
+    int rc = scratch_upload(jobs.data(), sizeof(CenJob) * n_images, (void **)&jobs_dev, stream);
+    if (rc) return rc;
+    hipLaunchKernelGGL(centroid_kernel, dim3(cdiv(max_n, 256), n_images), dim3(256), 0, stream, jobs_dev, iterations);
+    IRN_LAUNCH_CHECK("centroid_kernel");
+    return scratch_release(stream);
+}
+
 extern "C" int irn_find_centroids(const float *dp_dev, int h, int w, int iterations, int32_t *centroids_dev,
                                   void *stream_) {
-    hipStream_t stream = (hipStream_t)stream_;
     if (!dp_dev || !centroids_dev || h < 1 || w < 1 || iterations < 0)
         return fail(IRN_ERR_ARG, "irn_find_centroids: bad argument");
-    hipLaunchKernelGGL(centroid_kernel, dim3(cdiv(h * w, 256)), dim3(256), 0, stream, dp_dev, h, w, iterations,
-                       centroids_dev);
-    IRN_LAUNCH_CHECK("centroid_kernel");
-    return IRN_OK;
+    const int32_t hh = h, ww = w;
+    return irn_find_centroids_batch(1, &dp_dev, &hh, &ww, iterations, &centroids_dev, stream_);
 }
 
 extern "C" size_t irn_ccl_scratch_bytes(int n, int h, int w) {
@@ -345,13 +493,71 @@ extern "C" int irn_label4(const uint8_t *mask_dev, int n, int h, int w, int32_t 
     return run_label4(mask_dev, n, h, w, labels_dev, n_labels_dev, scratch_dev, stream);
 }
 
-// scratch layout of irn_cluster_centroids:
-//   [ccl scratch (2*npx ints)] [mask npx bytes, padded] [labels npx] [picked npx] [present npx+2] [k 1]
+// scratch of one image in irn_cluster_centroids[_batch]:
+//   [parent npx][rank npx] int32, [picked npx] int32, [present npx+2] int32, [K slot of the single-image form]
+//   (each 256-byte aligned)
 extern "C" size_t irn_cluster_scratch_bytes(int h, int w) {
     if (h < 1 || w < 1) return 0;
     const size_t npx = (size_t)h * w;
-    return irn_ccl_scratch_bytes(1, h, w) + round_up(npx, 256) + round_up(4 * npx, 256) * 2 +
-           round_up(4 * (npx + 2), 256) + 256;
+    return round_up(4 * npx, 256) * 3 + round_up(4 * (npx + 2), 256) + 256;
+}
+
+extern "C" size_t irn_cluster_batch_scratch_bytes(int n_images, const int32_t *h, const int32_t *w) {
+    if (n_images < 1 || !h || !w) return 0;
+    size_t total = 0;
+    for (int i = 0; i < n_images; ++i) total += irn_cluster_scratch_bytes(h[i], w[i]);
+    return total;
+}
+
+extern "C" int irn_cluster_centroids_batch(int n_images, const int32_t *const *centroids_dev, const float *const *dp_dev,
+                                           const int32_t *h, const int32_t *w, float thres,
+                                           int32_t *const *cluster_map_dev, int32_t *k_dev, void *scratch_dev,
+                                           void *stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (n_images < 1 || !centroids_dev || !dp_dev || !h || !w || !cluster_map_dev || !k_dev || !scratch_dev)
+        return fail(IRN_ERR_ARG, "irn_cluster_centroids_batch: bad argument");
+    std::vector<ClusterJob> jobs(n_images);
+    char *s = (char *)scratch_dev;
+    int max_n = 0;
+    for (int i = 0; i < n_images; ++i) {
+        if (!centroids_dev[i] || !dp_dev[i] || !cluster_map_dev[i] || h[i] < 1 || w[i] < 1)
+            return fail(IRN_ERR_ARG, "irn_cluster_centroids_batch: image %d: bad argument", i);
+        if ((long)h[i] * w[i] > (1L << 30)) return fail(IRN_ERR_ARG, "irn_cluster_centroids_batch: image too large");
+        const size_t npx = (size_t)h[i] * w[i];
+        const size_t a = round_up(4 * npx, 256);
+        ClusterJob &J = jobs[i];
+        J.centroids = centroids_dev[i];
+        J.dp = dp_dev[i];
+        J.cluster_map = cluster_map_dev[i];
+        J.parent = (int *)s;
+        J.rank = (int *)(s + a);
+        J.picked = (int32_t *)(s + 2 * a);
+        J.present = (int *)(s + 3 * a);
+        J.k_out = k_dev + i;
+        J.h = h[i];
+        J.w = w[i];
+        s += irn_cluster_scratch_bytes(h[i], w[i]);
+        max_n = std::max(max_n, (int)npx);
+    }
+    ClusterJob *jd = nullptr;
+    int rc = scratch_upload(jobs.data(), sizeof(ClusterJob) * n_images, (void **)&jd, stream);
+    if (rc) return rc;
+    const dim3 px(cdiv(max_n, 256), n_images);
+    hipLaunchKernelGGL(cluster_init_kernel, px, dim3(256), 0, stream, jd, thres);
+    IRN_LAUNCH_CHECK("cluster_init_kernel");
+    hipLaunchKernelGGL(cluster_merge_kernel, px, dim3(256), 0, stream, jd);
+    IRN_LAUNCH_CHECK("cluster_merge_kernel");
+    hipLaunchKernelGGL(cluster_flatten_kernel, px, dim3(256), 0, stream, jd);
+    IRN_LAUNCH_CHECK("cluster_flatten_kernel");
+    hipLaunchKernelGGL(cluster_rank_kernel, dim3(n_images), dim3(1024), 0, stream, jd);
+    IRN_LAUNCH_CHECK("cluster_rank_kernel");
+    hipLaunchKernelGGL(cluster_pick_kernel, px, dim3(256), 0, stream, jd);
+    IRN_LAUNCH_CHECK("cluster_pick_kernel");
+    hipLaunchKernelGGL(cluster_compress_kernel, dim3(n_images), dim3(1024), 0, stream, jd);
+    IRN_LAUNCH_CHECK("cluster_compress_kernel");
+    hipLaunchKernelGGL(cluster_remap_kernel, px, dim3(256), 0, stream, jd);
+    IRN_LAUNCH_CHECK("cluster_remap_kernel");
+    return scratch_release(stream);
 }
 
 extern "C" int irn_cluster_centroids(const int32_t *centroids_dev, const float *dp_dev, int h, int w, float thres,
@@ -359,86 +565,158 @@ extern "C" int irn_cluster_centroids(const int32_t *centroids_dev, const float *
     hipStream_t stream = (hipStream_t)stream_;
     if (!centroids_dev || !dp_dev || !cluster_map_dev || !k_out || !scratch_dev || h < 1 || w < 1)
         return fail(IRN_ERR_ARG, "irn_cluster_centroids: bad argument");
-    const int npx = h * w;
-    char *s = (char *)scratch_dev;
-    void *ccl = s;
-    s += irn_ccl_scratch_bytes(1, h, w);
-    uint8_t *mask = (uint8_t *)s;
-    s += round_up((size_t)npx, 256);
-    int32_t *labels = (int32_t *)s;
-    s += round_up(4 * (size_t)npx, 256);
-    int32_t *picked = (int32_t *)s;
-    s += round_up(4 * (size_t)npx, 256);
-    int *present = (int *)s;
-    s += round_up(4 * ((size_t)npx + 2), 256);
-    int *k_dev = (int *)s;
-
-    const int nb = cdiv(npx, 256);
-    hipLaunchKernelGGL(weak_mask_kernel, dim3(nb), dim3(256), 0, stream, dp_dev, npx, thres, mask);
-    IRN_LAUNCH_CHECK("weak_mask_kernel");
-    int rc = run_label4(mask, 1, h, w, labels, nullptr, ccl, stream);
+    int32_t *k_dev = (int32_t *)((char *)scratch_dev + irn_cluster_scratch_bytes(h, w) - 256);   // the K slot
+    const int32_t hh = h, ww = w;
+    int rc = irn_cluster_centroids_batch(1, &centroids_dev, &dp_dev, &hh, &ww, thres, &cluster_map_dev, k_dev, scratch_dev,
+                                         stream_);
     if (rc) return rc;
-    IRN_HIP_TRY(hipMemsetAsync(present, 0, sizeof(int) * ((size_t)npx + 2), stream));
-    hipLaunchKernelGGL(pick_kernel, dim3(nb), dim3(256), 0, stream, centroids_dev, labels, npx, w, picked, present);
-    IRN_LAUNCH_CHECK("pick_kernel");
-    // label values lie in [0, npx/2+1]; +1 shifts them to [1, npx/2+2] -> npx+2 slots are plenty
-    hipLaunchKernelGGL(compress_kernel, dim3(1), dim3(1024), 0, stream, present, npx + 2, k_dev);
-    IRN_LAUNCH_CHECK("compress_kernel");
-    hipLaunchKernelGGL(remap_kernel, dim3(nb), dim3(256), 0, stream, picked, present, npx, cluster_map_dev);
-    IRN_LAUNCH_CHECK("remap_kernel");
-    IRN_HIP_TRY(hipMemcpyAsync(k_out, k_dev, sizeof(int), hipMemcpyDeviceToHost, stream));
+    int32_t k = 0;
+    IRN_HIP_TRY(hipMemcpyAsync(&k, k_dev, sizeof(int32_t), hipMemcpyDeviceToHost, stream));
     IRN_HIP_TRY(hipStreamSynchronize(stream));
+    *k_out = k;
     return IRN_OK;
 }
 
-// scratch layout of irn_detect_instance_*: [parent npx][prov npx][newid npx][area npx][score_bits npx] int32,
-//                                          [keys npx] int64, [counter]
+// scratch of one image in irn_detect_instance_*: [parent npx][prov npx][newid npx][area npx][score_bits npx] int32,
+//                                                 [keys npx] int64, [counter]
 extern "C" size_t irn_detect_scratch_bytes(int n_channels, int h, int w) {
     if (n_channels < 1 || h < 1 || w < 1) return 0;
     const size_t npx = (size_t)h * w;
     return round_up(4 * npx, 256) * 5 + round_up(8 * npx, 256) + 256;
 }
 
+extern "C" size_t irn_detect_batch_scratch_bytes(int n_images, const int32_t *n_channels, const int32_t *h,
+                                                 const int32_t *w) {
+    if (n_images < 1 || !n_channels || !h || !w) return 0;
+    size_t total = 0;
+    for (int i = 0; i < n_images; ++i) total += irn_detect_scratch_bytes(n_channels[i], h[i], w[i]);
+    return total;
+}
+
 namespace {
-struct DetScratch {
-    int *parent, *prov, *newid, *area, *score_bits, *counter;
-    long long *keys;
-};
-DetScratch det_carve(void *scratch, size_t npx) {
-    char *b = (char *)scratch;
-    DetScratch s;
+// carve the per-image scratch; `counter` = the last 256-byte block (single-image API) unless the caller supplies one
+void det_carve(DetJob &J, char *b, size_t npx) {
     const size_t a = round_up(4 * npx, 256);
-    s.parent = (int *)b;
-    s.prov = (int *)(b + a);
-    s.newid = (int *)(b + 2 * a);
-    s.area = (int *)(b + 3 * a);
-    s.score_bits = (int *)(b + 4 * a);
-    s.keys = (long long *)(b + 5 * a);
-    s.counter = (int *)(b + 5 * a + round_up(8 * npx, 256));
-    return s;
+    J.parent = (int *)b;
+    J.prov = (int *)(b + a);
+    J.newid = (int *)(b + 2 * a);
+    J.area = (int *)(b + 3 * a);
+    J.score_bits = (int *)(b + 4 * a);
+    J.keys = (long long *)(b + 5 * a);
+    J.counter = (int32_t *)(b + 5 * a + round_up(8 * npx, 256));
+}
+
+int det_fill_jobs(const char *who, int n_images, const float *const *rw_up_dev, const int32_t *const *argmax_dev,
+                  const int32_t *n_channels, const int32_t *h, const int32_t *w, void *scratch_dev,
+                  std::vector<DetJob> &jobs, int *max_n) {
+    if (n_images < 1 || !rw_up_dev || !argmax_dev || !n_channels || !h || !w || !scratch_dev)
+        return fail(IRN_ERR_ARG, "%s: bad argument", who);
+    jobs.assign(n_images, DetJob{});
+    char *s = (char *)scratch_dev;
+    *max_n = 0;
+    for (int i = 0; i < n_images; ++i) {
+        if (!rw_up_dev[i] || !argmax_dev[i] || n_channels[i] < 1 || n_channels[i] > 65535 || h[i] < 1 || w[i] < 1)
+            return fail(IRN_ERR_ARG, "%s: image %d: bad argument", who, i);
+        if ((long)h[i] * w[i] > (1L << 30)) return fail(IRN_ERR_ARG, "%s: image too large", who);
+        DetJob &J = jobs[i];
+        J.rw_up = rw_up_dev[i];
+        J.cls = argmax_dev[i];
+        J.h = h[i];
+        J.w = w[i];
+        det_carve(J, s, (size_t)h[i] * w[i]);
+        s += irn_detect_scratch_bytes(n_channels[i], h[i], w[i]);
+        *max_n = std::max(*max_n, h[i] * w[i]);
+    }
+    return IRN_OK;
 }
 }  // namespace
+
+extern "C" int irn_detect_instance_batch_count(int n_images, const float *const *rw_up_dev,
+                                               const int32_t *const *argmax_dev, const int32_t *n_channels,
+                                               const int32_t *h, const int32_t *w, int32_t *n_det_dev,
+                                               void *scratch_dev, void *stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    std::vector<DetJob> jobs;
+    int max_n = 0;
+    int rc = det_fill_jobs("irn_detect_instance_batch_count", n_images, rw_up_dev, argmax_dev, n_channels, h, w,
+                           scratch_dev, jobs, &max_n);
+    if (rc) return rc;
+    if (!n_det_dev) return fail(IRN_ERR_ARG, "irn_detect_instance_batch_count: null n_det_dev");
+    for (int i = 0; i < n_images; ++i) jobs[i].counter = n_det_dev + i;
+    DetJob *jd = nullptr;
+    rc = scratch_upload(jobs.data(), sizeof(DetJob) * n_images, (void **)&jd, stream);
+    if (rc) return rc;
+    IRN_HIP_TRY(hipMemsetAsync(n_det_dev, 0, sizeof(int32_t) * n_images, stream));
+    const dim3 px(cdiv(max_n, 256), n_images);
+    hipLaunchKernelGGL(det_init_kernel, px, dim3(256), 0, stream, jd);
+    IRN_LAUNCH_CHECK("det_init_kernel");
+    hipLaunchKernelGGL(det_merge_kernel, px, dim3(256), 0, stream, jd);
+    IRN_LAUNCH_CHECK("det_merge_kernel");
+    hipLaunchKernelGGL(det_flatten_kernel, px, dim3(256), 0, stream, jd);
+    IRN_LAUNCH_CHECK("det_flatten_kernel");
+    hipLaunchKernelGGL(det_roots_kernel, px, dim3(256), 0, stream, jd);
+    IRN_LAUNCH_CHECK("det_roots_kernel");
+    return scratch_release(stream);
+}
+
+extern "C" int irn_detect_instance_batch_emit(int n_images, const float *const *rw_up_dev,
+                                              const int32_t *const *argmax_dev, const int32_t *n_channels,
+                                              const int32_t *h, const int32_t *w, const int32_t *n_det,
+                                              const double *min_area, float *const *score_dev,
+                                              int32_t *const *channel_dev, uint8_t *const *mask_dev, void *scratch_dev,
+                                              void *stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    std::vector<DetJob> jobs;
+    int max_n = 0;
+    int rc = det_fill_jobs("irn_detect_instance_batch_emit", n_images, rw_up_dev, argmax_dev, n_channels, h, w,
+                           scratch_dev, jobs, &max_n);
+    if (rc) return rc;
+    if (!n_det || !min_area || !score_dev || !channel_dev || !mask_dev)
+        return fail(IRN_ERR_ARG, "irn_detect_instance_batch_emit: null argument");
+    int max_det = 0;
+    for (int i = 0; i < n_images; ++i) {
+        DetJob &J = jobs[i];
+        J.n_det = n_det[i];
+        if (J.n_det < 0 || J.n_det > h[i] * w[i])
+            return fail(IRN_ERR_ARG, "irn_detect_instance_batch_emit: image %d: n_det = %d", i, J.n_det);
+        if (J.n_det == 0) continue;                       // nothing to write for this image
+        if (!score_dev[i] || !channel_dev[i] || !mask_dev[i])
+            return fail(IRN_ERR_ARG, "irn_detect_instance_batch_emit: image %d: null output", i);
+        if (((uintptr_t)mask_dev[i] & 15) != 0)
+            return fail(IRN_ERR_ARG, "irn_detect_instance_batch_emit: image %d: masks must be 16-byte aligned", i);
+        J.score = score_dev[i];
+        J.channel = channel_dev[i];
+        J.mask = mask_dev[i];
+        J.min_area = min_area[i];
+        max_det = std::max(max_det, J.n_det);
+    }
+    if (max_det == 0) return IRN_OK;
+    DetJob *jd = nullptr;
+    rc = scratch_upload(jobs.data(), sizeof(DetJob) * n_images, (void **)&jd, stream);
+    if (rc) return rc;
+    hipLaunchKernelGGL(det_zero_masks_kernel, dim3(64, n_images), dim3(256), 0, stream, jd);
+    IRN_LAUNCH_CHECK("det_zero_masks_kernel");
+    hipLaunchKernelGGL(det_order_kernel, dim3(cdiv(max_det, 256), n_images), dim3(256), 0, stream, jd);
+    IRN_LAUNCH_CHECK("det_order_kernel");
+    hipLaunchKernelGGL(det_stats_kernel, dim3(cdiv(max_n, 256), n_images), dim3(256), 0, stream, jd);
+    IRN_LAUNCH_CHECK("det_stats_kernel");
+    hipLaunchKernelGGL(det_final_kernel, dim3(cdiv(max_det, 256), n_images), dim3(256), 0, stream, jd);
+    IRN_LAUNCH_CHECK("det_final_kernel");
+    return scratch_release(stream);
+}
 
 extern "C" int irn_detect_instance_count(const float *rw_up_dev, const int32_t *argmax_dev, int n_channels, int h,
                                          int w, int *n_det_out, void *scratch_dev, void *stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (!rw_up_dev || !argmax_dev || !n_det_out || !scratch_dev || n_channels < 1 || n_channels > 65535 || h < 1 || w < 1)
         return fail(IRN_ERR_ARG, "irn_detect_instance_count: bad argument");
-    if ((long)h * w > (1L << 30)) return fail(IRN_ERR_ARG, "irn_detect_instance_count: image too large");
-    const int npx = h * w;
-    const DetScratch s = det_carve(scratch_dev, (size_t)npx);
-    const int nb = cdiv(npx, 256);
-    IRN_HIP_TRY(hipMemsetAsync(s.counter, 0, sizeof(int), stream));
-    hipLaunchKernelGGL(det_init_kernel, dim3(nb), dim3(256), 0, stream, argmax_dev, s.parent, npx);
-    IRN_LAUNCH_CHECK("det_init_kernel");
-    hipLaunchKernelGGL(det_merge_kernel, dim3(nb), dim3(256), 0, stream, argmax_dev, s.parent, h, w);
-    IRN_LAUNCH_CHECK("det_merge_kernel");
-    hipLaunchKernelGGL(ccl_flatten_kernel, dim3(nb), dim3(256), 0, stream, s.parent, npx, (long)npx);
-    IRN_LAUNCH_CHECK("ccl_flatten_kernel");
-    hipLaunchKernelGGL(det_roots_kernel, dim3(nb), dim3(256), 0, stream, argmax_dev, s.parent, s.prov, s.keys, s.counter, npx);
-    IRN_LAUNCH_CHECK("det_roots_kernel");
-    int n_det = 0;
-    IRN_HIP_TRY(hipMemcpyAsync(&n_det, s.counter, sizeof(int), hipMemcpyDeviceToHost, stream));
+    const int32_t cc = n_channels, hh = h, ww = w;
+    // the counter of the single-image form is the last block of its own scratch
+    int32_t *counter = (int32_t *)((char *)scratch_dev + irn_detect_scratch_bytes(n_channels, h, w) - 256);
+    int rc = irn_detect_instance_batch_count(1, &rw_up_dev, &argmax_dev, &cc, &hh, &ww, counter, scratch_dev, stream_);
+    if (rc) return rc;
+    int32_t n_det = 0;
+    IRN_HIP_TRY(hipMemcpyAsync(&n_det, counter, sizeof(int32_t), hipMemcpyDeviceToHost, stream));
     IRN_HIP_TRY(hipStreamSynchronize(stream));
     *n_det_out = n_det;
     return IRN_OK;
@@ -447,21 +725,10 @@ extern "C" int irn_detect_instance_count(const float *rw_up_dev, const int32_t *
 extern "C" int irn_detect_instance_emit(const float *rw_up_dev, const int32_t *argmax_dev, int n_channels, int h, int w,
                                         int n_det, double min_area, float *score_dev, int32_t *channel_dev,
                                         uint8_t *mask_dev, void *scratch_dev, void *stream_) {
-    hipStream_t stream = (hipStream_t)stream_;
     if (!rw_up_dev || !argmax_dev || !score_dev || !channel_dev || !mask_dev || !scratch_dev || n_channels < 1 || h < 1 ||
         w < 1 || n_det < 1)
         return fail(IRN_ERR_ARG, "irn_detect_instance_emit: bad argument");
-    const int npx = h * w;
-    const DetScratch s = det_carve(scratch_dev, (size_t)npx);
-    IRN_HIP_TRY(hipMemsetAsync(mask_dev, 0, (size_t)n_det * npx, stream));
-    hipLaunchKernelGGL(det_order_kernel, dim3(1), dim3(1024), 0, stream, s.keys, s.newid, s.area, s.score_bits, channel_dev,
-                       n_det, npx);
-    IRN_LAUNCH_CHECK("det_order_kernel");
-    hipLaunchKernelGGL(det_stats_kernel, dim3(cdiv(npx, 256)), dim3(256), 0, stream, argmax_dev, s.parent, s.prov, s.newid,
-                       rw_up_dev, s.area, s.score_bits, mask_dev, npx);
-    IRN_LAUNCH_CHECK("det_stats_kernel");
-    hipLaunchKernelGGL(det_final_kernel, dim3(cdiv(n_det, 256)), dim3(256), 0, stream, s.area, s.score_bits, min_area,
-                       score_dev, n_det);
-    IRN_LAUNCH_CHECK("det_final_kernel");
-    return IRN_OK;
+    const int32_t cc = n_channels, hh = h, ww = w, nd = n_det;
+    return irn_detect_instance_batch_emit(1, &rw_up_dev, &argmax_dev, &cc, &hh, &ww, &nd, &min_area, &score_dev,
+                                          &channel_dev, &mask_dev, scratch_dev, stream_);
 }

@@ -520,6 +520,7 @@ extern "C" int irn_walk_destroy(irn_walk_ctx *ctx) {
         if (ctx->ev_join[k]) (void)hipEventDestroy(ctx->ev_join[k]);
     }
     if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
+    if (ctx->run_done_ev) (void)hipEventDestroy(ctx->run_done_ev);
     resident_destroy(ctx);
     for (int k = 0; k < 2; ++k) {
         if (ctx->stage[k]) (void)hipHostFree(ctx->stage[k]);
@@ -551,6 +552,12 @@ extern "C" int irn_walk_set_option(irn_walk_ctx *ctx, const char *name, int valu
     } else if (!strcmp(name, "poll_delay")) {
         if (value < 0 || value > 1000) return fail(IRN_ERR_ARG, "poll_delay must be in [0,1000]");
         ctx->res_poll_delay = value;
+    } else if (!strcmp(name, "cooperative")) {
+        ctx->res_cooperative = value ? 1 : 0;
+        ctx->res_coop_refused = false;
+    } else if (!strcmp(name, "inject_timeout")) {      // test hook: the next persistent launch gives up at once
+        ctx->res_inject_timeout = value ? 1 : 0;
+        return IRN_OK;                                  // no re-configure
     } else if (!strcmp(name, "profile")) {
         if (value && !ctx->res_prof_dev) {
             IRN_HIP_TRY(hipMalloc((void **)&ctx->res_prof_dev, 2 * 256 * 4 * sizeof(long long)));
@@ -609,6 +616,10 @@ extern "C" int irn_walk_configure(irn_walk_ctx *ctx, int n_images, const int32_t
     if (!ctx || !h || !w || !c || !workspace_bytes || n_images < 1)
         return fail(IRN_ERR_ARG, "irn_walk_configure: bad argument");
     const int R = ctx->radius;
+    // the tables rewritten below (block map, resident job list, descriptors) may still be read by the previous run
+    // when the caller's stream is not the legacy default stream
+    if (ctx->run_done_ev && ctx->last_valid) IRN_HIP_TRY(hipEventSynchronize(ctx->run_done_ev));
+    ctx->last_valid = false;
     ctx->n = 0;
     ctx->h.assign(h, h + n_images);
     ctx->w.assign(w, w + n_images);
@@ -761,6 +772,83 @@ static int launch_blocked(irn_walk_ctx *ctx, int phase, int last, hipStream_t co
     return rc;
 }
 
+static int timing_events(irn_walk_ctx *ctx, hipEvent_t *ev0, hipEvent_t *ev1) {
+    while (ctx->ev_pool.size() < ctx->ev_used + 2) {
+        hipEvent_t e;
+        IRN_HIP_TRY(hipEventCreate(&e));
+        ctx->ev_pool.push_back(e);
+    }
+    *ev0 = ctx->ev_pool[ctx->ev_used];
+    *ev1 = ctx->ev_pool[ctx->ev_used + 1];
+    return IRN_OK;
+}
+
+// degree + x_0 + n_sweeps streaming sweeps of the configured batch; the weight planes are already in the workspace
+// and the descriptors in imgs_dev.  The path of variants 0/1, of batches the persistent kernel cannot take, and the
+// re-run of irn_walk_sync after a persistent launch gave up.
+int irn::streaming_run(irn_walk_ctx *ctx, int n_sweeps, hipStream_t stream, bool timed) {
+    const DeviceTable &tab = *ctx->tab;
+    const int n = ctx->n;
+    const int pix_blocks = cdiv(ctx->max_n, 256);
+    hipLaunchKernelGGL(degree_kernel, dim3(pix_blocks, n), dim3(256), 0, stream, ctx->imgs_dev, tab.dir_dy, tab.dir_dx,
+                       tab.n_dirs);
+    IRN_LAUNCH_CHECK("degree_kernel");
+    ctx->deg_stale = false;
+    hipLaunchKernelGGL(x0_kernel, dim3(pix_blocks, n), dim3(256), 0, stream, ctx->imgs_dev, n_sweeps == 0 ? 1 : 0);
+    IRN_LAUNCH_CHECK("x0_kernel");
+
+    const bool blocked = ctx->variant >= 1 && ctx->all_blocked_ok;
+    // stream of every channel-chunk class: the class with most workgroups stays on the caller's stream
+    hipStream_t st[4] = {stream, stream, stream, stream};
+    int n_side = 0;
+    if (blocked && !ctx->merged && !ctx->probe && ctx->use_streams && n_sweeps > 0) {
+        int big = 1;
+        for (int k = 2; k <= 4; ++k)
+            if (ctx->cls_count[k] > ctx->cls_count[big]) big = k;
+        for (int k = 1; k <= 4; ++k) {
+            if (k == big || ctx->cls_count[k] == 0) continue;
+            if (!ctx->side[n_side]) {
+                IRN_HIP_TRY(hipStreamCreateWithFlags(&ctx->side[n_side], hipStreamNonBlocking));
+                IRN_HIP_TRY(hipEventCreateWithFlags(&ctx->ev_join[n_side], hipEventDisableTiming));
+            }
+            st[k - 1] = ctx->side[n_side++];
+        }
+        if (n_side && !ctx->ev_fork) IRN_HIP_TRY(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
+    }
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    int rc = IRN_OK;
+    if (timed) {
+        rc = timing_events(ctx, &ev0, &ev1);
+        if (rc) return rc;
+        IRN_HIP_TRY(hipEventRecord(ev0, stream));
+    }
+    if (n_side) {
+        IRN_HIP_TRY(hipEventRecord(ctx->ev_fork, stream));
+        for (int k = 0; k < n_side; ++k) IRN_HIP_TRY(hipStreamWaitEvent(ctx->side[k], ctx->ev_fork, 0));
+    }
+    for (int t = 0; t < n_sweeps; ++t) {
+        const int last = (t == n_sweeps - 1) ? 1 : 0;
+        if (blocked) {
+            rc = ctx->radius == 5 ? launch_blocked<5>(ctx, t, last, st) : launch_blocked<10>(ctx, t, last, st);
+            if (rc) return rc;
+        } else {
+            hipLaunchKernelGGL(sweep_generic_kernel, dim3(pix_blocks, n), dim3(256), 0, stream, ctx->imgs_dev,
+                               tab.dir_dy, tab.dir_dx, tab.n_dirs, t, last);
+            IRN_LAUNCH_CHECK("sweep_generic_kernel");
+        }
+    }
+    for (int k = 0; k < n_side; ++k) {
+        IRN_HIP_TRY(hipEventRecord(ctx->ev_join[k], ctx->side[k]));
+        IRN_HIP_TRY(hipStreamWaitEvent(stream, ctx->ev_join[k], 0));
+    }
+    if (timed) {
+        IRN_HIP_TRY(hipEventRecord(ev1, stream));
+        ctx->ev_used += 2;
+        ctx->pending_launches += n_sweeps;
+    }
+    return IRN_OK;
+}
+
 extern "C" int irn_walk_run(irn_walk_ctx *ctx, const float *const *edge_dev, const float *const *cam_dev,
                             const int32_t *const *inst_map_dev, const int32_t *k_inst,
                             float *const *out_dev, float beta, int n_sweeps, void *workspace_dev,
@@ -823,76 +911,34 @@ extern "C" int irn_walk_run(irn_walk_ctx *ctx, const float *const *edge_dev, con
     IRN_LAUNCH_CHECK("zero_pad_kernel");
     int rc = launch_affinity(ctx->jobs_dev, n, ctx->max_h, ctx->max_w, tab, true, beta, stream);
     if (rc) return rc;
-    const int pix_blocks = cdiv(ctx->max_n, 256);
     const bool resident = ctx->variant == 2 && ctx->res_ok && n_sweeps > 0;
     // the resident kernel sums the degree from the weights it holds in registers; the inv_deg array is then
-    // only filled on demand (irn_walk_export_weights)
+    // only filled on demand (irn_walk_export_weights, or the streaming re-run of irn_walk_sync)
     ctx->deg_stale = resident;
-    if (!resident) {
-        hipLaunchKernelGGL(degree_kernel, dim3(pix_blocks, n), dim3(256), 0, stream, ctx->imgs_dev, tab.dir_dy,
-                           tab.dir_dx, tab.n_dirs);
-        IRN_LAUNCH_CHECK("degree_kernel");
-        hipLaunchKernelGGL(x0_kernel, dim3(pix_blocks, n), dim3(256), 0, stream, ctx->imgs_dev, n_sweeps == 0 ? 1 : 0);
-        IRN_LAUNCH_CHECK("x0_kernel");
-    }
-
-    const bool blocked = ctx->variant >= 1 && ctx->all_blocked_ok;
-    // stream of every channel-chunk class: the class with most workgroups stays on the caller's stream
-    hipStream_t st[4] = {stream, stream, stream, stream};
-    int n_side = 0;
-    if (blocked && !resident && !ctx->merged && !ctx->probe && ctx->use_streams && n_sweeps > 0) {
-        int big = 1;
-        for (int k = 2; k <= 4; ++k)
-            if (ctx->cls_count[k] > ctx->cls_count[big]) big = k;
-        for (int k = 1; k <= 4; ++k) {
-            if (k == big || ctx->cls_count[k] == 0) continue;
-            if (!ctx->side[n_side]) {
-                IRN_HIP_TRY(hipStreamCreateWithFlags(&ctx->side[n_side], hipStreamNonBlocking));
-                IRN_HIP_TRY(hipEventCreateWithFlags(&ctx->ev_join[n_side], hipEventDisableTiming));
-            }
-            st[k - 1] = ctx->side[n_side++];
-        }
-        if (n_side && !ctx->ev_fork) IRN_HIP_TRY(hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming));
-    }
+    ctx->last_stream = stream;
+    ctx->last_n_sweeps = n_sweeps;
+    ctx->last_resident = resident;
+    ctx->last_valid = true;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    if (ctx->timing) {
-        while (ctx->ev_pool.size() < ctx->ev_used + 2) {
-            hipEvent_t e;
-            IRN_HIP_TRY(hipEventCreate(&e));
-            ctx->ev_pool.push_back(e);
-        }
-        ev0 = ctx->ev_pool[ctx->ev_used];
-        ev1 = ctx->ev_pool[ctx->ev_used + 1];
+    if (ctx->timing && resident) {
+        rc = timing_events(ctx, &ev0, &ev1);
+        if (rc) return rc;
         IRN_HIP_TRY(hipEventRecord(ev0, stream));
-    }
-    if (n_side) {
-        IRN_HIP_TRY(hipEventRecord(ctx->ev_fork, stream));
-        for (int k = 0; k < n_side; ++k) IRN_HIP_TRY(hipStreamWaitEvent(ctx->side[k], ctx->ev_fork, 0));
     }
     if (resident) {
         rc = resident_run(ctx, n_sweeps, stream);
         if (rc) return rc;
-    }
-    for (int t = 0; t < (resident ? 0 : n_sweeps); ++t) {
-        const int last = (t == n_sweeps - 1) ? 1 : 0;
-        if (blocked) {
-            rc = ctx->radius == 5 ? launch_blocked<5>(ctx, t, last, st) : launch_blocked<10>(ctx, t, last, st);
-            if (rc) return rc;
-        } else {
-            hipLaunchKernelGGL(sweep_generic_kernel, dim3(pix_blocks, n), dim3(256), 0, stream, ctx->imgs_dev,
-                               tab.dir_dy, tab.dir_dx, tab.n_dirs, t, last);
-            IRN_LAUNCH_CHECK("sweep_generic_kernel");
+        if (ctx->timing) {
+            IRN_HIP_TRY(hipEventRecord(ev1, stream));
+            ctx->ev_used += 2;
+            ctx->pending_launches += n_sweeps;
         }
+    } else {
+        rc = streaming_run(ctx, n_sweeps, stream, ctx->timing != 0);
+        if (rc) return rc;
     }
-    for (int k = 0; k < n_side; ++k) {
-        IRN_HIP_TRY(hipEventRecord(ctx->ev_join[k], ctx->side[k]));
-        IRN_HIP_TRY(hipStreamWaitEvent(stream, ctx->ev_join[k], 0));
-    }
-    if (ctx->timing) {
-        IRN_HIP_TRY(hipEventRecord(ev1, stream));
-        ctx->ev_used += 2;
-        ctx->pending_launches += n_sweeps;
-    }
+    if (!ctx->run_done_ev) IRN_HIP_TRY(hipEventCreateWithFlags(&ctx->run_done_ev, hipEventDisableTiming));
+    IRN_HIP_TRY(hipEventRecord(ctx->run_done_ev, stream));
     return IRN_OK;
 }
 
@@ -907,6 +953,28 @@ extern "C" int irn_walk_check(irn_walk_ctx *ctx) {
     }
     return IRN_OK;
 }
+
+// Wait for the last irn_walk_run.  If it ran on the persistent kernel and a tile gave up its bounded wait (the grid
+// was not co-resident in time: another process or stream held compute units), the batch is run again on the
+// streaming sweeps — same operator, kernel boundaries instead of in-launch hand-offs — so the caller's outputs are
+// valid when this returns IRN_OK.
+extern "C" int irn_walk_sync(irn_walk_ctx *ctx, int *fell_back) {
+    if (!ctx) return fail(IRN_ERR_ARG, "null ctx");
+    if (fell_back) *fell_back = 0;
+    if (!ctx->last_valid || !ctx->run_done_ev) return IRN_OK;
+    IRN_HIP_TRY(hipEventSynchronize(ctx->run_done_ev));
+    if (!ctx->last_resident || !ctx->res_err_host || ctx->res_err_host[0] == 0) return IRN_OK;
+    ctx->res_err_host[0] = 0;
+    ctx->last_resident = false;
+    ++ctx->fallback_runs;
+    if (fell_back) *fell_back = 1;
+    int rc = streaming_run(ctx, ctx->last_n_sweeps, ctx->last_stream, false);
+    if (rc) return rc;
+    IRN_HIP_TRY(hipStreamSynchronize(ctx->last_stream));
+    return IRN_OK;
+}
+
+extern "C" int irn_walk_fallback_runs(irn_walk_ctx *ctx) { return ctx ? ctx->fallback_runs : 0; }
 
 extern "C" int irn_walk_read_profile(irn_walk_ctx *ctx, long long *host_out) {
     if (!ctx || !host_out) return fail(IRN_ERR_ARG, "null argument");

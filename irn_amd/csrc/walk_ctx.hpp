@@ -61,7 +61,8 @@ struct irn_walk_ctx {
     using AffJob = irn::AffJob;
     int radius = 0;
     const DeviceTable *tab = nullptr;   // raster order
-    int variant = 1;                    // 0 generic, 1 blocked (radius 5/10 only)
+    int variant = 1;                    // 0 generic, 1 blocked streaming sweeps, 2 weights-stationary persistent walk
+                                        // (irn_walk_create picks 2 for radius 5/10, 0 otherwise)
     int xcd_map = 1;                    // keep all tiles of an image on one XCD
     int tile = 8;                       // index into kTiles (8x128 tile, 4 px/thread, MAXW 2: best measured)
     int use_streams = 1;                // run the channel-chunk classes of a sweep on separate streams
@@ -100,6 +101,7 @@ struct irn_walk_ctx {
     // weights-stationary persistent kernel (variant 2, walk_resident.hip)
     int4 *res_jobs_dev = nullptr;          // [res_rounds][res_nwg] (image, tile row0, tile col0, -)
     int res_cap_jobs = 0, res_rounds = 0, res_nwg = 0;
+    int res_max_round_channels = 1;        // most channels of any image of the batch (bounds the waits of the launch)
     unsigned *res_err_dev = nullptr;       // [4] time-out diagnostics written by the kernel
     unsigned *res_err_host = nullptr;      // pinned mirror
     long long *res_prof_dev = nullptr;     // [2][256][4] time stamps (option "profile")
@@ -111,6 +113,16 @@ struct irn_walk_ctx {
     bool deg_stale = false;    // last run was resident: the inv_deg array of the workspace was not written
     bool res_ok = false;                   // the configured batch fits the resident kernel
     int res_sweeps_per_launch = 0;         // 0 = all sweeps in one launch; k = relaunch every k sweeps (test hook)
+    int res_cooperative = 1;               // launch with hipLaunchCooperativeKernel (co-residency of the grid is requested,
+                                           // not assumed); falls back to a plain launch when the runtime refuses
+    bool res_coop_refused = false;         // the runtime refused a cooperative launch once: plain launches from then on
+    int res_inject_timeout = 0;            // test hook: the next resident launch reports a timeout without waiting
+    // last irn_walk_run (for irn_walk_sync: wait, and re-run on the streaming sweeps if the persistent kernel gave up)
+    hipStream_t last_stream = nullptr;
+    hipEvent_t run_done_ev = nullptr;      // recorded behind every irn_walk_run
+    bool last_valid = false, last_resident = false;
+    int last_n_sweeps = 0;
+    int fallback_runs = 0;                 // batches re-run on the streaming sweeps after a resident time-out
 };
 
 namespace irn {
@@ -118,5 +130,7 @@ namespace irn {
 bool resident_supported(const irn_walk_ctx *ctx);
 int resident_configure(irn_walk_ctx *ctx);
 int resident_run(irn_walk_ctx *ctx, int n_sweeps, hipStream_t stream);
+// walk.hip: degree + x0 + n_sweeps streaming sweeps of the configured batch (weights already built)
+int streaming_run(irn_walk_ctx *ctx, int n_sweeps, hipStream_t stream, bool timed);
 void resident_destroy(irn_walk_ctx *ctx);
 }  // namespace irn

@@ -47,6 +47,7 @@ typedef unsigned long long u64;
 typedef const double IRN_GLOBAL *gcd_t;
 typedef float IRN_GLOBAL *gf_t;
 typedef float f4a __attribute__((ext_vector_type(4)));
+typedef float f2a __attribute__((ext_vector_type(2)));
 
 constexpr int kSlabH = 8, kSlabW = 32;     // 64 lanes x 4 px
 constexpr int kWaves = 8;                  // 512 threads
@@ -104,7 +105,7 @@ struct Geom {
     static_assert(SLABS * Q == kWaves, "8 waves per workgroup");
     // LDS carve (bytes)
     static constexpr int XS_BYTES = 2 * LH * LW * 4;               // [2][LH][LW] fp32, double-buffered per step
-    static constexpr int PART_BYTES = 2 * kWaves * 4 * 64 * 8;      // [2][wave][lane][j] fp64
+    static constexpr int PART_BYTES = 2 * kWaves * 4 * 64 * 8;      // [2][wave][lane][j]: fp64 for the degree (prologue), fp32 chains in the steps
     static constexpr int INVD_BYTES = SLABS * 4 * 64 * 8;           // [slab][row][column] fp64
     static constexpr int LDS_BYTES = XS_BYTES + PART_BYTES + INVD_BYTES + 16;
 };
@@ -213,23 +214,47 @@ struct RowInfo {
     static constexpr int N4 = (c_hi - c_lo) / 4 + 1;          // aligned 16-byte reads of the state window
 };
 
-constexpr int kMaxWin = 7;   // (2 * 9 + 4 + 3) / 4 + ...: a full radius-10 row needs 7 float4
+constexpr int kMaxWin = 7;   // a full radius-10 row spans 22 floats = 7 aligned float4 slots
 
+// The state window of a neighbour row: floats c_lo .. c_lo + 4*N4 - 1 relative to the lane's first pixel, of which
+// dx_lo .. dx_hi + 3 are used.  Interior slots are 16-byte LDS reads; the two end slots read only what is used (a
+// full row over-reads 6 of 28 floats with 16-byte reads throughout: the arithmetic phase is paced by LDS bytes,
+// DESIGN.md §4 lesson 7).  Everything is compile-time, so `w` stays in registers.
 template <int R, int QI, int DY>
-__device__ __forceinline__ void load_window(f4a (&w)[kMaxWin], const float *xrow) {
+__device__ __forceinline__ void load_window(float (&w)[kMaxWin * 4], const float *xrow) {
     using RW = RowInfo<R, QI, DY>;
     static_assert(RW::N4 <= kMaxWin, "window");
     const float *row = xrow + DY * Geom<R>::LW + RW::c_lo;
-#pragma unroll
-    for (int k = 0; k < RW::N4; ++k) w[k] = *reinterpret_cast<const f4a *>(row + 4 * k);
+    constexpr int first = kDisc<R>.dx[RW::lo] - RW::c_lo;            // first used float of the window
+    constexpr int last = kDisc<R>.dx[RW::hi] + 3 - RW::c_lo;         // last used float
+    static_for<RW::N4>([&](auto ik) __attribute__((always_inline)) {
+        constexpr int k = decltype(ik)::value;
+        constexpr int lo = first > 4 * k ? first - 4 * k : 0;         // used range inside slot k
+        constexpr int hi = last < 4 * k + 3 ? last - 4 * k : 3;
+        if constexpr (lo == hi) {
+            w[4 * k + lo] = row[4 * k + lo];
+        } else if constexpr ((lo == 2 && hi == 3) || (lo == 0 && hi == 1)) {
+            const f2a v = *reinterpret_cast<const f2a *>(row + 4 * k + lo);
+            w[4 * k + lo] = v.x;
+            w[4 * k + lo + 1] = v.y;
+        } else {
+            const f4a v = *reinterpret_cast<const f4a *>(row + 4 * k);
+            w[4 * k] = v.x;
+            w[4 * k + 1] = v.y;
+            w[4 * k + 2] = v.z;
+            w[4 * k + 3] = v.w;
+        }
+    });
 }
 
-// one fp32 chain per pixel over the neighbours of the row (<= 19 terms), folded into fp64.  (More chains
-// for ILP and packed FMAs were both measured: slower / no gain.)
+// ONE fp32 chain per pixel over all neighbours of the wave's part (<= 38 terms at radius 10, 34 at radius 5); the Q
+// chains of a pixel are combined in fp64 together with the centre term and the normalisation.  A numpy model of this
+// scheme (tests/test_precision_model.py) is as close to the exact operator as folding every neighbour row into fp64
+// separately (1.5e-6 after 256 sweeps: the floor set by storing the state in fp32), and it saves 2 x 4 conversions /
+// fp64 additions per row segment and wave.  (More chains for ILP and packed FMAs were both measured: slower / no gain.)
 template <int R, int QI, int DY>
-__device__ __forceinline__ void fma_window(const float (&wr)[Geom<R>::NS][4], const f4a (&w)[kMaxWin], double (&acc)[4]) {
+__device__ __forceinline__ void fma_window(const float (&wr)[Geom<R>::NS][4], const float (&w)[kMaxWin * 4], float (&pf)[4]) {
     using RW = RowInfo<R, QI, DY>;
-    float pf[4] = {0.f, 0.f, 0.f, 0.f};
     static_for<RW::hi - RW::lo + 1>([&](auto is) __attribute__((always_inline)) {
         constexpr int s = RW::lo + decltype(is)::value;
         constexpr int dx = kDisc<R>.dx[s];
@@ -237,11 +262,9 @@ __device__ __forceinline__ void fma_window(const float (&wr)[Geom<R>::NS][4], co
         static_for<4>([&](auto ij) __attribute__((always_inline)) {
             constexpr int j = decltype(ij)::value;
             constexpr int e = dx + j - RW::c_lo;
-            pf[j] = fmaf(wr[k][j], w[e / 4][e % 4], pf[j]);
+            pf[j] = fmaf(wr[k][j], w[e], pf[j]);
         });
     });
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[j] += (double)pf[j];
 }
 
 // The window of row r+1 is read BEFORE the FMAs of row r (two windows live).  Isolated in
@@ -249,24 +272,24 @@ __device__ __forceinline__ void fma_window(const float (&wr)[Geom<R>::NS][4], co
 // then FMAs row after row 0.78 us (no overlap at all: every wave of the CU is in the same phase), this
 // order 0.62 us; reading every window of the part first 0.70 us.
 template <int R, int QI, int HALF>
-__device__ __forceinline__ void partial_sums(const float (&wr)[Geom<R>::NS][4], const float *xrow, double (&acc)[4]) {
+__device__ __forceinline__ void partial_sums(const float (&wr)[Geom<R>::NS][4], const float *xrow, float (&pf)[4]) {
     constexpr int NR = kRowList<R, QI, HALF>.n;
-    if constexpr (HALF != 1) acc[0] = acc[1] = acc[2] = acc[3] = 0.0;
+    if constexpr (HALF != 1) pf[0] = pf[1] = pf[2] = pf[3] = 0.f;
     if constexpr (NR > 0 && R == 5) {
         // radius 5: row after row (the double-buffered order spills in that instantiation)
         static_for<NR>([&](auto ir) __attribute__((always_inline)) {
-            f4a w1[kMaxWin];
+            float w1[kMaxWin * 4];
             load_window<R, QI, kRowList<R, QI, HALF>.dy[decltype(ir)::value]>(w1, xrow);
-            fma_window<R, QI, kRowList<R, QI, HALF>.dy[decltype(ir)::value]>(wr, w1, acc);
+            fma_window<R, QI, kRowList<R, QI, HALF>.dy[decltype(ir)::value]>(wr, w1, pf);
         });
     } else if constexpr (NR > 0) {
-        f4a w[2][kMaxWin];
+        float w[2][kMaxWin * 4];
         load_window<R, QI, kRowList<R, QI, HALF>.dy[0]>(w[0], xrow);
         static_for<NR>([&](auto ir) __attribute__((always_inline)) {
             constexpr int r = decltype(ir)::value;
             if constexpr (r + 1 < NR) load_window<R, QI, kRowList<R, QI, HALF>.dy[r + 1 < NR ? r + 1 : r]>(w[(r + 1) & 1], xrow);
             __builtin_amdgcn_sched_barrier(0);
-            fma_window<R, QI, kRowList<R, QI, HALF>.dy[r]>(wr, w[r & 1], acc);
+            fma_window<R, QI, kRowList<R, QI, HALF>.dy[r]>(wr, w[r & 1], pf);
             __builtin_amdgcn_sched_barrier(0);
         });
     }
@@ -568,7 +591,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             // ---- [C] partial sums -> LDS -> fp64 combine -> store ----
             {
                 const float *xrow = xsb + (ly + H) * LW + lx + HP;
-                double acc[4];
+                float acc[4];
                 if (R == 10 && C == 2) {
                     switch (qi) {
                         case 0: partial_sums<R, 0, 0>(wr, xrow, acc); break;
@@ -606,9 +629,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     }
                     if (polled && poller && C == 2) issue(state_rsrc(tn), cn * ch_bytes);   // radius 5
                 }
-                double *pw = part + (k & 1) * (kWaves * 256) + wv * 256 + lane * 4;     // [buffer][wave][lane][j]
-#pragma unroll
-                for (int j = 0; j < 4; ++j) pw[j] = acc[j];
+                // the wave's four chains leave as ONE 16-byte LDS write; [buffer][wave][lane][j] fp32
+                float *partf = reinterpret_cast<float *>(part);
+                *reinterpret_cast<f4a *>(partf + (k & 1) * (kWaves * 256) + wv * 256 + lane * 4) = f4a{acc[0], acc[1], acc[2], acc[3]};
                 __syncthreads();
                 if (PROF && pslot) pslot[2] = wall_clock64();
                 // One pixel per combining thread, consecutive threads = consecutive pixels of a tile row (their
@@ -621,10 +644,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     const int s2 = i >> 8, prow = (i >> 5) & 7, x = i & 31;
                     const int py = (s2 / G::C::SL_X) * kSlabH + prow;
                     const int px = (s2 % G::C::SL_X) * kSlabW + x;
-                    const double *pr = part + (k & 1) * (kWaves * 256) + (s2 * Q) * 256 + (prow * 8 + (x >> 2)) * 4 + (x & 3);
+                    const float *pr = partf + (k & 1) * (kWaves * 256) + (s2 * Q) * 256 + (prow * 8 + (x >> 2)) * 4 + (x & 3);
                     double sum = (double)xsb[(py + H) * LW + px + HP];
 #pragma unroll
-                    for (int q = 0; q < Q; ++q) sum += pr[q * 256];
+                    for (int q = 0; q < Q; ++q) sum += (double)pr[q * 256];
                     const float res = (float)(sum * invd[i]);
                     const float other = __shfl_xor(res, 1);
                     const int yy = ty0 + py, xx = tx0 + px;
@@ -653,13 +676,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                             const int s2 = i >> 7, prow = (i >> 4) & 7, x = (i & 15) * 2;
                             const int py = (s2 / G::C::SL_X) * kSlabH + prow;
                             const int px = (s2 % G::C::SL_X) * kSlabW + x;
-                            const double *pr = part + (k & 1) * (kWaves * 256) + (s2 * Q) * 256 + (prow * 8 + (x >> 2)) * 4 + (x & 3);
+                            const float *pr = partf + (k & 1) * (kWaves * 256) + (s2 * Q) * 256 + (prow * 8 + (x >> 2)) * 4 + (x & 3);
                             const float *xc = xsb + (py + H) * LW + px + HP;
                             double sum0 = (double)xc[0], sum1 = (double)xc[1];
 #pragma unroll
                             for (int q = 0; q < Q; ++q) {
-                                sum0 += pr[q * 256];
-                                sum1 += pr[q * 256 + 1];
+                                sum0 += (double)pr[q * 256];
+                                sum1 += (double)pr[q * 256 + 1];
                             }
                             const int ii = s2 * 256 + prow * 32 + x;
                             r0v[it] = (float)(sum0 * invd[ii]);
@@ -711,6 +734,9 @@ static void tile_shape(int radius, int *th, int *tw) {
 }
 
 bool resident_supported(const irn_walk_ctx *ctx) { return ctx->radius == 5 || ctx->radius == 10; }
+
+template <int R, bool PROF>
+static int resident_capacity(int n_cu, int *capacity);
 
 void resident_destroy(irn_walk_ctx *ctx) {
     if (ctx->res_jobs_dev) (void)hipFree(ctx->res_jobs_dev);
@@ -802,28 +828,77 @@ int resident_configure(irn_walk_ctx *ctx) {
         IRN_HIP_TRY(hipHostMalloc((void **)&ctx->res_err_host, 4 * sizeof(unsigned), hipHostMallocDefault));
     }
     ctx->res_rounds = (int)rounds.size();
-    ctx->res_ok = true;
+    ctx->res_max_round_channels = 1;
+    for (int i = 0; i < n; ++i) ctx->res_max_round_channels = std::max(ctx->res_max_round_channels, ctx->c[i]);
+    // the grid must be co-resident: ask the runtime how many workgroups of this kernel fit (a partitioned device or a
+    // different LDS / register budget changes the answer); otherwise the streaming sweeps take the batch
+    int capacity = 0;
+    const int rc_cap = ctx->radius == 10 ? resident_capacity<10, false>(n_wg, &capacity) : resident_capacity<5, false>(n_wg, &capacity);
+    if (rc_cap) return rc_cap;
+    ctx->res_ok = capacity >= n_wg;
+    return IRN_OK;
+}
+
+// One workgroup per compute unit only works if every workgroup of the grid is resident at the same time (tiles wait
+// for each other inside the launch).  How many fit is asked of the runtime, not assumed: 1 workgroup of 8 waves x 256
+// VGPRs and ~100 KB of LDS per compute unit on an idle MI355X.
+template <int R, bool PROF>
+static int resident_capacity(int n_cu, int *capacity) {
+    using G = Geom<R>;
+    int dev = 0;
+    IRN_HIP_TRY(hipGetDevice(&dev));
+    static bool attr_set[64] = {};                  // the dynamic-LDS limit is a per-device function attribute
+    if (dev < 0 || dev >= 64) return fail(IRN_ERR_STATE, "device ordinal %d out of range", dev);
+    if (!attr_set[dev]) {
+        IRN_HIP_TRY(hipFuncSetAttribute((const void *)resident_kernel<R, PROF>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        G::LDS_BYTES));
+        attr_set[dev] = true;
+    }
+    int per_cu = 0;
+    IRN_HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)resident_kernel<R, PROF>, 512,
+                                                             G::LDS_BYTES));
+    *capacity = per_cu * n_cu;
     return IRN_OK;
 }
 
 template <int R, bool PROF>
 static int launch_resident(irn_walk_ctx *ctx, int t_first, int t_count, int t_total, hipStream_t stream) {
     using G = Geom<R>;
-    static bool attr_set = false;
-    if (!attr_set) {
-        IRN_HIP_TRY(hipFuncSetAttribute((const void *)resident_kernel<R, PROF>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                        G::LDS_BYTES));
-        attr_set = true;
+    int capacity = 0;
+    int rc = resident_capacity<R, PROF>(ctx->res_nwg, &capacity);
+    if (rc) return rc;
+    if (capacity < ctx->res_nwg)
+        return fail(IRN_ERR_STATE, "resident walk: only %d of %d workgroups can be resident", capacity, ctx->res_nwg);
+    // Bounded waits: a tile that cannot make progress reports instead of hanging.  The bound covers the slowest legal
+    // wait — a workgroup that has moved on to its next round waits for neighbours still busy with a heavy image of the
+    // previous one — so it grows with the work of the launch (3 us per channel-step is twice the measured rate).
+    long long ticks = 200000000LL;                  // 2 s of the 100 MHz wall clock
+    ticks += 4LL * 300LL * (long long)ctx->res_max_round_channels * (long long)t_count * (long long)std::max(ctx->res_rounds, 1);
+    if (ctx->res_inject_timeout) {                  // test hook: every poll that misses once gives up
+        ticks = -1;
+        ctx->res_inject_timeout = 0;
     }
-    const long long timeout_ticks = 200000000LL;   // 2 s of the 100 MHz wall clock
     unsigned long long *votes = nullptr;
     if (R == 5 && ctx->res_plain_store) {           // one vote word per image, cleared before every launch
         votes = ctx->res_votes_dev;
         IRN_HIP_TRY(hipMemsetAsync(votes, 0, sizeof(unsigned long long) * ctx->n, stream));
     }
-    hipLaunchKernelGGL((resident_kernel<R, PROF>), dim3(ctx->res_nwg), dim3(512), G::LDS_BYTES, stream, ctx->imgs_dev,
-                       ctx->res_jobs_dev, ctx->res_rounds, t_first, t_count, t_total, ctx->res_err_dev, timeout_ticks,
-                       ctx->res_prof_dev, ctx->res_poll_delay | (ctx->res_poll_delay_plain << 16), votes);
+    const WalkImg *imgs = ctx->imgs_dev;
+    const int4 *jobs = ctx->res_jobs_dev;
+    int n_rounds = ctx->res_rounds;
+    unsigned *err = ctx->res_err_dev;
+    long long *prof = ctx->res_prof_dev;
+    int delays = ctx->res_poll_delay | (ctx->res_poll_delay_plain << 16);
+    if (ctx->res_cooperative && !ctx->res_coop_refused) {
+        void *args[] = {&imgs, &jobs, &n_rounds, &t_first, &t_count, &t_total, &err, &ticks, &prof, &delays, &votes};
+        const hipError_t e = hipLaunchCooperativeKernel((const void *)resident_kernel<R, PROF>, dim3(ctx->res_nwg), dim3(512),
+                                                        args, G::LDS_BYTES, stream);
+        if (e == hipSuccess) return IRN_OK;
+        (void)hipGetLastError();                    // refused (e.g. a partition without cooperative queues): plain launch,
+        ctx->res_coop_refused = true;               // the occupancy check above still holds
+    }
+    hipLaunchKernelGGL((resident_kernel<R, PROF>), dim3(ctx->res_nwg), dim3(512), G::LDS_BYTES, stream, imgs, jobs, n_rounds,
+                       t_first, t_count, t_total, err, ticks, prof, delays, votes);
     IRN_LAUNCH_CHECK("resident_kernel");
     return IRN_OK;
 }

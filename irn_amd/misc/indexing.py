@@ -259,9 +259,23 @@ class RandomWalk:
         check(lib.irn_walk_set_option(self._ctx, name.encode(), int(value)))
         self._sig = None
 
+    def sync(self):
+        """Wait for the last run and make its outputs valid: if the persistent kernel (variant 2) gave up its bounded
+        wait for a neighbouring tile — the grid was not co-resident in time — the batch is run again on the streaming
+        sweeps (irn_walk_sync).  Returns True when that happened.  Call before consuming the outputs."""
+        fell = C.c_int()
+        with torch.cuda.device(self.device):
+            check(lib.irn_walk_sync(self._ctx, C.byref(fell)))
+        return bool(fell.value)
+
+    @property
+    def fallback_runs(self):
+        return int(lib.irn_walk_fallback_runs(self._ctx))
+
     def check(self):
         """Raise if a weights-stationary launch (option variant=2) gave up waiting for a neighbouring
-        tile.  Synchronises the device first (the kernel reports through a pinned word)."""
+        tile and `sync()` has not repaired it.  Synchronises the device first (the kernel reports through a
+        pinned word).  For benchmarks, where a silent re-run on the slower path would misreport."""
         torch.cuda.synchronize(self.device)
         check(lib.irn_walk_check(self._ctx))
 
@@ -370,4 +384,7 @@ def propagate_to_edge(x, edge, radius=5, beta=10, exp_times=8):
     _need_cuda(edge, "edge")
     beta = float(beta)                 # run_sample.py passes CLI strings for --beta/--exp_times
     exp_times = int(exp_times)
-    return _walker(x.device, radius)([edge], [x], beta=beta, exp_times=exp_times)[0]
+    walker = _walker(x.device, radius)
+    out = walker([edge], [x], beta=beta, exp_times=exp_times)[0]
+    walker.sync()          # the reference's call is synchronous too; a launch that gave up is re-run on the streaming sweeps
+    return out

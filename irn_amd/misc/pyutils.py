@@ -1,69 +1,73 @@
-"""API mirror of the reference misc/pyutils.py pieces the steps use: Logger tee (:6-17), Timer
-(:50-83), to_one_hot (:86-101)."""
+"""Small host utilities behind the names run_sample.py and the steps use from the reference's
+misc/pyutils.py: a stdout tee (`Logger`, reference :6-17), a step stopwatch (`Timer`, :50-83) and
+`to_one_hot` (:86-101).  Only the behaviour the label-generation steps rely on is provided."""
+import contextlib
 import sys
 import time
 
 import numpy as np
 
 
-class Logger(object):
-    """Replaces sys.stdout with a tee into `outfile` (misc/pyutils.py:6-17)."""
+class Logger:
+    """`Logger(path)` makes every later `print` go to the terminal and to `path` (the reference installs
+    itself as sys.stdout the same way).  Works as a context manager too; `close()` restores sys.stdout."""
 
     def __init__(self, outfile):
-        self.terminal = sys.stdout
-        self.log = open(outfile, "w")
+        self._streams = (sys.stdout, open(outfile, "w"))
         sys.stdout = self
 
-    def write(self, message):
-        self.terminal.write(message)
-        self.log.write(message)
+    def write(self, text):
+        for s in self._streams:
+            s.write(text)
+        return len(text)
 
     def flush(self):
-        self.terminal.flush()
+        for s in self._streams:
+            with contextlib.suppress(ValueError):      # log file already closed
+                s.flush()
 
+    def isatty(self):
+        return False
 
-class Timer:
-    """Wall-clock timer that prints a start stamp when given a message (misc/pyutils.py:50-83)."""
-
-    def __init__(self, starting_msg=None):
-        self.start = time.time()
-        self.stage_start = self.start
-        if starting_msg is not None:
-            print(starting_msg, time.ctime(time.time()))
+    def close(self):
+        if sys.stdout is self:
+            sys.stdout = self._streams[0]
+        self._streams[1].close()
 
     def __enter__(self):
         return self
 
-    def __exit__(self, exc_type, exc_val, exc_tb):
-        return
+    def __exit__(self, *exc):
+        self.close()
 
-    def update_progress(self, progress):
-        self.elapsed = time.time() - self.start
-        self.est_total = self.elapsed / progress
-        self.est_remaining = self.est_total - self.elapsed
-        self.est_finish = int(self.start + self.est_total)
 
-    def str_estimated_complete(self):
-        return str(time.ctime(self.est_finish))
+class Timer:
+    """Stopwatch on the monotonic clock.  `Timer("step.make_cam:")` prints the message with the wall-clock
+    date like the reference; `lapse()` returns the seconds since the previous lap (or the start) and starts
+    a new lap; `elapsed()` the seconds since construction."""
 
-    def get_stage_elapsed(self):
-        return time.time() - self.stage_start
+    def __init__(self, starting_msg=None):
+        self._t0 = self._lap = time.perf_counter()
+        if starting_msg is not None:
+            print(starting_msg, time.ctime())
 
-    def reset_stage(self):
-        self.stage_start = time.time()
+    def elapsed(self):
+        return time.perf_counter() - self._t0
 
     def lapse(self):
-        out = time.time() - self.stage_start
-        self.stage_start = time.time()
-        return out
+        now = time.perf_counter()
+        dt, self._lap = now - self._lap, now
+        return dt
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        return False
 
 
 def to_one_hot(sparse_integers, maximum_val=None, dtype=np.bool_):
-    """[...] ints -> [K, ...] one-hot (misc/pyutils.py:86-101)."""
-    sparse_integers = np.asarray(sparse_integers)
-    if maximum_val is None:
-        maximum_val = int(np.max(sparse_integers)) + 1
-    flat = sparse_integers.reshape(-1)
-    one_hot = np.zeros((maximum_val, flat.shape[0]), dtype)
-    one_hot[flat, np.arange(flat.shape[0])] = 1
-    return one_hot.reshape([maximum_val] + list(sparse_integers.shape))
+    """[...] ints -> [K, ...] one-hot planes, K = maximum_val or max+1 (misc/pyutils.py:86-101)."""
+    ids = np.asarray(sparse_integers)
+    k = int(ids.max()) + 1 if maximum_val is None else int(maximum_val)
+    return (ids[None] == np.arange(k).reshape((k,) + (1,) * ids.ndim)).astype(dtype)

@@ -42,3 +42,9 @@ class CAM(Net):
     def forward(self, x):
         a = F.relu(F.conv2d(self.features(x), self.classifier.weight))
         return a[0] + a[1].flip(-1)
+
+    def forward_batch(self, x):
+        """[2B,3,H,W] = B (image, h-flipped image) pairs of ONE size back to back -> [B,20,h,w]: the forward above for
+        every pair in one pass of the trunk (the steps stack the images of a size group per scale)."""
+        a = F.relu(F.conv2d(self.features(x), self.classifier.weight))
+        return a[0::2] + a[1::2].flip(-1)

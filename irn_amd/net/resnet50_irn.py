@@ -120,6 +120,21 @@ class EdgeDisplacement(Net):
         d = d[..., :h, :w]
         return torch.sigmoid(e[0] / 2 + e[1].flip(-1) / 2), d[0]
 
+    def forward_batch(self, items):
+        """list of [2,3,H_i,W_i] (image, flip) pairs of ANY sizes <= crop_size -> list of (edge [1,h_i,w_i],
+        dp [2,h_i,w_i]).  Every item is zero-padded to the crop like `forward` pads it (:225), so the ragged batch is ONE
+        [2B,3,crop,crop] pass of the trunk and heads; each result is cropped and merged exactly as in `forward`."""
+        cs = self.crop_size
+        x = torch.stack([F.pad(it, [0, cs - it.shape[3], 0, cs - it.shape[2]]) for it in items]).flatten(0, 1)
+        e, d = Net.forward(self, x)
+        out = []
+        for i, it in enumerate(items):
+            H, W = it.shape[2:]
+            h, w = (H - 1) // self.stride + 1, (W - 1) // self.stride + 1
+            ei, di = e[2 * i:2 * i + 2, :, :h, :w], d[2 * i:2 * i + 2, :, :h, :w]
+            out.append((torch.sigmoid(ei[0] / 2 + ei[1].flip(-1) / 2), di[0]))
+        return out
+
 
 class AffinityDisplacementLoss(Net):
     """Training-time losses of IRNet (net/resnet50_irn.py:144-213): same constructor (a ``PathIndex``), same four

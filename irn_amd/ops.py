@@ -197,6 +197,44 @@ def cluster_centroids(centroids, displacement, thres=2.5, as_one_hot=False):
     return cmap, k.value
 
 
+def find_centroids_batch(displacements, iterations=300):
+    """Batched find_centroids_with_refinement: list of GPU fp32 [2,h,w] -> list of GPU int32 [2,h,w]; one launch for
+    the whole batch (irn_find_centroids_batch), nothing synchronises."""
+    dps = []
+    for d in displacements:
+        _need_cuda(d, "displacement")
+        dps.append(d.contiguous().float())
+    dev = dps[0].device
+    outs = [torch.empty((2,) + tuple(d.shape[1:]), dtype=torch.int32, device=dev) for d in dps]
+    with torch.cuda.device(dev):
+        check(lib.irn_find_centroids_batch(len(dps), ptr_array([d.data_ptr() for d in dps]),
+                                           i32_array([d.shape[1] for d in dps]), i32_array([d.shape[2] for d in dps]),
+                                           int(iterations), ptr_array([o.data_ptr() for o in outs]), _stream()))
+    return outs
+
+
+def cluster_centroids_batch(centroids, displacements, thres=2.5):
+    """Batched cluster_centroids: -> (list of GPU int32 [h,w] cluster maps with values 0..K_i-1, list of K_i).
+    One launch sequence for the batch and ONE device-to-host transfer for all the K (irn_cluster_centroids_batch)."""
+    n = len(centroids)
+    dps = [d.contiguous().float() for d in displacements]
+    cens = []
+    for c in centroids:
+        _need_cuda(c, "centroids")
+        cens.append(c.to(torch.int32).contiguous())
+    dev = dps[0].device
+    hs, ws = i32_array([d.shape[1] for d in dps]), i32_array([d.shape[2] for d in dps])
+    cmaps = [torch.empty(tuple(d.shape[1:]), dtype=torch.int32, device=dev) for d in dps]
+    k_dev = torch.empty(n, dtype=torch.int32, device=dev)
+    scratch = _cached("cluster_scratch", dev, lib.irn_cluster_batch_scratch_bytes(n, hs, ws), torch.uint8)
+    with torch.cuda.device(dev):
+        check(lib.irn_cluster_centroids_batch(n, ptr_array([c.data_ptr() for c in cens]),
+                                              ptr_array([d.data_ptr() for d in dps]), hs, ws, float(thres),
+                                              ptr_array([m.data_ptr() for m in cmaps]), k_dev.data_ptr(),
+                                              scratch.data_ptr(), _stream()))
+    return cmaps, [int(k) for k in k_dev.cpu().tolist()]
+
+
 def label4(mask):
     """4-connected components of a GPU mask [n,h,w] or [h,w] (non-zero = foreground): int32 ids 1..
     per image in raster order of each component's first pixel, 0 background; and counts [n]."""
@@ -259,6 +297,67 @@ def detect_instance(rw_up, argmax, class_ids, n_channels, max_fragment_size=0):
     chan = raw[4 * nd:head].view(np.int32)
     mask = raw[head:head + nd * npx].view(np.bool_).reshape(nd, h, w).copy()
     return {"score": score, "mask": mask, "class": class_ids[chan]}
+
+
+def detect_instance_batch(rw_ups, argmaxes, class_ids, n_channels, max_fragment_sizes):
+    """detect_instance for a batch of images with two host round trips in total (the per-image form has three per
+    image): one 4-byte-per-image transfer of the detection counts, one packed transfer of every image's
+    {score, channel, masks} (irn_detect_instance_batch_count / _emit).  Arguments are lists (one entry per image) of
+    what `detect_instance` takes.  Returns a list with, per image, the reference's numpy dict or — for an image without
+    any foreground pixel — the ValueError `detect_instance` would raise."""
+    n = len(rw_ups)
+    dev = rw_ups[0].device
+    scs, ams, hs, ws = [], [], [], []
+    for i in range(n):
+        _need_cuda(rw_ups[i], "rw_up")
+        _need_cuda(argmaxes[i], "argmax")
+        am = argmaxes[i].to(torch.int32).contiguous()
+        sc = rw_ups[i].contiguous().float()
+        h, w = am.shape
+        if sc.shape != (int(n_channels[i]), h, w):
+            raise ValueError("rw_up[%d] must be [%d,%d,%d], got %s" % (i, n_channels[i], h, w, tuple(sc.shape)))
+        scs.append(sc); ams.append(am); hs.append(h); ws.append(w)
+    cs_a, hs_a, ws_a = i32_array(n_channels), i32_array(hs), i32_array(ws)
+    sc_p, am_p = ptr_array([t.data_ptr() for t in scs]), ptr_array([t.data_ptr() for t in ams])
+    scratch = _cached("det_scratch_b", dev, lib.irn_detect_batch_scratch_bytes(n, cs_a, hs_a, ws_a), torch.uint8)
+    n_det_dev = torch.empty(n, dtype=torch.int32, device=dev)
+    with torch.cuda.device(dev):
+        check(lib.irn_detect_instance_batch_count(n, sc_p, am_p, cs_a, hs_a, ws_a, n_det_dev.data_ptr(),
+                                                  scratch.data_ptr(), _stream()))
+        nds = [int(v) for v in n_det_dev.cpu().tolist()]                       # host round trip 1
+        # packed output: per image [score fp32 x nd | channel int32 x nd | pad to 16 | masks uint8 nd x h x w | pad to 16]
+        offs, total = [], 0
+        for i in range(n):
+            head = (8 * nds[i] + 15) // 16 * 16
+            offs.append((total, total + 4 * nds[i], total + head))
+            total += head + (nds[i] * hs[i] * ws[i] + 15) // 16 * 16
+        if total == 0:
+            return [ValueError("detect_instance: no foreground pixel in any channel") for _ in range(n)]
+        packed = _cached("det_out_b", dev, total + 16, torch.uint8)
+        base = (packed.data_ptr() + 15) // 16 * 16
+        shift = base - packed.data_ptr()
+        live = [nd > 0 for nd in nds]
+        check(lib.irn_detect_instance_batch_emit(
+            n, sc_p, am_p, cs_a, hs_a, ws_a, i32_array(nds), (C.c_double * n)(*[float(v) for v in max_fragment_sizes]),
+            ptr_array([base + o[0] if l else None for o, l in zip(offs, live)]),
+            ptr_array([base + o[1] if l else None for o, l in zip(offs, live)]),
+            ptr_array([base + o[2] if l else None for o, l in zip(offs, live)]), scratch.data_ptr(), _stream()))
+        host = _cached("det_host_b", "pinned", total, torch.uint8)
+        host[:total].copy_(packed[shift:shift + total], non_blocking=True)
+        torch.cuda.current_stream().synchronize()                              # host round trip 2
+    raw = host.numpy()
+    out = []
+    for i in range(n):
+        nd = nds[i]
+        if nd == 0:
+            out.append(ValueError("detect_instance: no foreground pixel in any channel"))
+            continue
+        o_sc, o_ch, o_mk = offs[i]
+        score = raw[o_sc:o_sc + 4 * nd].view(np.float32).copy()
+        chan = raw[o_ch:o_ch + 4 * nd].view(np.int32)
+        mask = raw[o_mk:o_mk + nd * hs[i] * ws[i]].view(np.bool_).reshape(nd, hs[i], ws[i]).copy()
+        out.append({"score": score, "mask": mask, "class": np.asarray(class_ids[i])[chan]})
+    return out
 
 
 _CACHE = {}

@@ -47,6 +47,59 @@ def device_images(pack, scales, normal=None):
     return [i[0].cuda(non_blocking=True) for i in imgs]
 
 
+class CamStore:
+    """CAMs of this process kept on the device between steps: `make_cam` puts every image's
+    {keys, cam} here besides writing the reference's `.npy` (step/make_cam.py:55-56), and the label steps take them
+    from here instead of reading the 1-6 MB pickle back and uploading it again (step/make_sem_seg_labels.py:34-39).
+    A miss — another process or an earlier run made the CAM — falls back to the file, so results never depend on the
+    store.  One store per process and device; a 128x128 CAM is 64 KB per class, so all of VOC12 train_aug (10 582
+    images) is ~1 GB of the 288 GB: capped at `max_bytes` anyway."""
+
+    def __init__(self, max_bytes=16 << 30):
+        self._items = {}
+        self._bytes = 0
+        self._max = max_bytes
+        self.hits = self.misses = 0
+
+    def put(self, name, keys_cpu, keys_dev, cam):
+        nbytes = cam.numel() * cam.element_size()
+        if name in self._items or self._bytes + nbytes > self._max:
+            return
+        self._items[name] = (keys_cpu, keys_dev, cam)
+        self._bytes += nbytes
+
+    def get(self, name, cam_out_dir, device):
+        """-> (keys int64 on the CPU, keys on the device, cam fp32 [K,h,w] on the device)."""
+        hit = self._items.get(name)
+        if hit is not None and hit[2].device == device:
+            self.hits += 1
+            return hit
+        self.misses += 1
+        import os
+        import numpy as np
+        d = np.load(os.path.join(cam_out_dir, name + ".npy"), allow_pickle=True).item()
+        keys = torch.as_tensor(d["keys"])
+        return keys, keys.to(device), torch.as_tensor(d["cam"]).to(device)
+
+    def clear(self):
+        self._items.clear()
+        self._bytes = 0
+
+
+CAM_STORE = CamStore()
+
+
+def keep_cams(args):
+    return bool(getattr(args, "keep_cams_on_device", True))
+
+
+def walk_radius(args, default):
+    """The reference hard-codes radius 5 at its call sites (step/make_sem_seg_labels.py:41,
+    step/make_ins_seg_labels.py:135); `args.radius` (run_sample.py --radius) overrides it, e.g. 10 for BASELINE
+    configs[2]."""
+    return int(getattr(args, "radius", 0) or default)
+
+
 def progress(process_id, n_workers, it, n_items):
     """The reference prints 5 % ticks from the last rank and divides by len//20 (ZeroDivision for
     shards under 20 images, step/make_cam.py:58); guarded here."""

@@ -7,10 +7,13 @@ Writes args.cam_out_dir/<name>.npy = {"keys": LongTensor[K], "cam": FloatTensor[
 
 The per-scale inputs are built on the GPU from the decoded uint8 image (irn_msf_pack: Pillow-exact bicubic,
 normalise, flip pair; args.device_preprocess=False keeps the reference's PIL loop in the loader workers).
-The ResNet-50 forward passes run on PyTorch-ROCm (MIOpen); the merge (step/make_cam.py:38-52) is
-one HIP kernel pair (irn_cam_merge).  One process per GPU over strided shards, no communication.
+The ResNet-50 forward passes run on PyTorch-ROCm (MIOpen), `cam_batch` images of one size per pass (default 8;
+the reference: one image + its flip); the merge (step/make_cam.py:38-52) is one HIP kernel pair (irn_cam_merge).
+Every image's {keys, cam} also stays on the device (`_common.CAM_STORE`) for label steps that run later in the same
+process.  One process per GPU over strided shards, no communication.
 """
 import os
+import warnings
 
 import numpy as np
 import torch
@@ -54,24 +57,56 @@ def merge_scales_torch(outputs, size, label):
     return valid_cat, strided_cam, highres
 
 
+def _flush_group(model, group, scales, args, writer, store):
+    """One trunk pass per scale for all images of a size group ([image, flip, image, flip, ...]), then the per-image
+    merge (irn_cam_merge) and the asynchronous write of the reference's dictionary."""
+    if not group:
+        return
+    outs = [model.forward_batch(torch.cat([g["imgs"][si] for g in group])) for si in range(len(scales))]
+    for i, g in enumerate(group):
+        keys, cam, high_res = merge_scales([o[i] for o in outs], g["size"], g["label"])
+        keys_cpu = keys.cpu()
+        if store is not None:
+            store.put(g["name"], keys_cpu, keys, cam)
+        writer.submit(np.save, os.path.join(args.cam_out_dir, g["name"] + ".npy"),
+                      {"keys": keys_cpu, "cam": cam.cpu(), "high_res": high_res.cpu().numpy()})
+    group.clear()
+
+
 def _work(process_id, model, dataset, args):
     databin = dataset[process_id]
     n_gpus = len(dataset)
     loader = DataLoader(databin, shuffle=False, num_workers=int(args.num_workers) // n_gpus, pin_memory=False)
     writer = _common.AsyncWriter()
     scales = tuple(float(s) for s in args.cam_scales)
-    with torch.no_grad(), torch.cuda.device(process_id):
-        model.cuda()
-        for it, pack in enumerate(loader):
-            img_name = pack["name"][0]
-            label = pack["label"][0]
-            size = (int(pack["size"][0]), int(pack["size"][1]))
-            outputs = [model(img) for img in _common.device_images(pack, scales)]
-            keys, cam, high_res = merge_scales(outputs, size, label.cuda())
-            writer.submit(np.save, os.path.join(args.cam_out_dir, img_name + ".npy"),
-                          {"keys": keys.cpu(), "cam": cam.cpu(), "high_res": high_res.cpu().numpy()})
-            _common.progress(process_id, n_gpus, it, len(databin))
-    writer.close()
+    # images per trunk pass (the reference runs batch 2 = one image + flip, step/make_cam.py:32-33); images of one size
+    # are stacked per scale — VOC is mostly 500x375 / 375x500 — and every size group is flushed at the end
+    batch = int(getattr(args, "cam_batch", 0) or 8)
+    store = _common.CAM_STORE if _common.keep_cams(args) else None
+    groups = {}
+    try:
+        with torch.no_grad(), torch.cuda.device(process_id):
+            model.cuda()
+            for it, pack in enumerate(loader):
+                img_name = pack["name"][0]
+                if not isinstance(img_name, str):
+                    img_name = voc12_dataloader.decode_int_filename(img_name)
+                label = pack["label"][0]
+                size = (int(pack["size"][0]), int(pack["size"][1]))
+                if float(label.sum()) == 0:
+                    # the reference would write an empty dictionary here and crash later in the label steps
+                    warnings.warn("%s: no positive class in the image-level label, skipped" % img_name)
+                    continue
+                group = groups.setdefault(size, [])
+                group.append({"name": img_name, "size": size, "label": label.cuda(),
+                              "imgs": _common.device_images(pack, scales)})
+                if len(group) == batch:
+                    _flush_group(model, group, scales, args, writer, store)
+                _common.progress(process_id, n_gpus, it, len(databin))
+            for group in groups.values():
+                _flush_group(model, group, scales, args, writer, store)
+    finally:
+        writer.close()
 
 
 def run(args):

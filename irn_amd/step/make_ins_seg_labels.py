@@ -20,7 +20,7 @@ from torch.utils.data import DataLoader
 from .. import ops
 from ..misc import indexing, torchutils
 from ..voc12 import dataloader as voc12_dataloader
-from . import _common
+from . import _common, make_sem_seg_labels
 
 RADIUS = 5   # step/make_ins_seg_labels.py:135
 
@@ -31,32 +31,24 @@ detect_instance = ops.detect_instance
 
 def instance_labels_batch(walker, items, beta, exp_times, bg_thres):
     """step/make_ins_seg_labels.py:131-150 for a batch of images.  items: dicts with GPU tensors
-    `edge` [1,h,w], `dp` [2,h,w], `cam` [C,h,w], CPU/GPU `keys` [C] and `size` (H, W).  The instance
-    front-end runs per image (cluster_centroids returns K to the host), the random walk and the
-    label epilogue run ONCE for the whole batch (a 128x128 grid is 16 tiles at radius 5 — one image
-    uses 1/16 of the GPU), detection runs per image.  Returns a list of detection dicts (or the
-    ValueError of an image without detections, in its slot)."""
-    cmaps, ks = [], []
-    for it in items:
-        centroids = ops.find_centroids_with_refinement(it["dp"])
-        cmap, k = ops.cluster_centroids(centroids, it["dp"])
-        cmaps.append(cmap)
-        ks.append(k)
+    `edge` [1,h,w], `dp` [2,h,w], `cam` [C,h,w], CPU/GPU `keys` [C] and `size` (H, W).  Every stage runs ONCE for the
+    whole batch — centroid refinement, clustering, random walk (a 128x128 grid is 16 tiles at radius 5: one image uses
+    1/16 of the GPU), label epilogue, detection — with three host round trips per BATCH: the instance counts K (they
+    size the walk's channels), the detection counts, and the packed detections.  Returns a list of detection dicts
+    (or the ValueError of an image without detections, in its slot)."""
+    dps = [it["dp"] for it in items]
+    cmaps, ks = ops.cluster_centroids_batch(ops.find_centroids_batch(dps), dps)
     rws = walker([it["edge"] for it in items], [it["cam"] for it in items], beta=beta, exp_times=exp_times,
                  inst_maps=cmaps, k_inst=ks)
     ep = ops.label_epilogue(rws, [it["size"] for it in items], bg_thres, want_labels=False, want_argmax=True,
                             want_rw_up=True)
-    out = []
-    for i, it in enumerate(items):
-        n_cls = it["cam"].shape[0]
-        class_ids = np.repeat(np.asarray(torch.as_tensor(it["keys"]).cpu()), ks[i])
-        try:
-            out.append(ops.detect_instance(ep["rw_up"][i], ep["argmax"][i], class_ids, n_cls * ks[i],
-                                           max_fragment_size=it["size"][0] * it["size"][1] * 0.01))
-        except ValueError as e:
-            out.append(e)
-    walker.check()                          # the persistent walk reports a stuck tile instead of hanging
-    return out
+    if walker.sync():                       # the persistent walk gave up and the batch was re-run on the streaming sweeps
+        ep = ops.label_epilogue(rws, [it["size"] for it in items], bg_thres, want_labels=False, want_argmax=True,
+                                want_rw_up=True)
+    n_ch = [it["cam"].shape[0] * k for it, k in zip(items, ks)]
+    class_ids = [np.repeat(np.asarray(torch.as_tensor(it["keys"]).cpu()), k) for it, k in zip(items, ks)]
+    return ops.detect_instance_batch(ep["rw_up"], ep["argmax"], class_ids, n_ch,
+                                     [it["size"][0] * it["size"][1] * 0.01 for it in items])
 
 
 def instance_labels(walker, edge, dp, cams, keys, size, beta, exp_times, bg_thres):
@@ -68,9 +60,10 @@ def instance_labels(walker, edge, dp, cams, keys, size, beta, exp_times, bg_thre
     return det
 
 
-def _flush(walker, pend, args, writer):
+def _flush(model, walker, pend, args, writer):
     if not pend:
         return
+    make_sem_seg_labels.edges_for(model, pend, int(getattr(args, "irn_batch", 0) or 8))
     dets = instance_labels_batch(walker, pend, float(args.beta), int(args.exp_times), float(args.ins_seg_bg_thres))
     for it, det in zip(pend, dets):
         if isinstance(det, Exception):
@@ -85,26 +78,28 @@ def _work(process_id, model, dataset, args):
     n_gpus = len(dataset)
     loader = DataLoader(databin, shuffle=False, num_workers=int(args.num_workers) // n_gpus, pin_memory=False)
     batch = int(getattr(args, "walk_batch", 0) or 32)   # images per walk launch (results per image unchanged)
-    with torch.no_grad(), torch.cuda.device(process_id):
-        model.cuda()
-        walker = indexing.RandomWalk(RADIUS)
-        writer = _common.AsyncWriter()
-        pend = []
-        for it, pack in enumerate(loader):
-            name = pack["name"][0]
-            if not isinstance(name, str):
-                name = voc12_dataloader.decode_int_filename(name)
-            size = (int(pack["size"][0]), int(pack["size"][1]))
-            edge, dp = model(_common.device_images(pack, (1.0,))[0])
-            cam_dict = np.load(os.path.join(args.cam_out_dir, name + ".npy"), allow_pickle=True).item()
-            pend.append({"name": name, "size": size, "edge": edge, "dp": dp,
-                         "cam": torch.as_tensor(cam_dict["cam"]).cuda(), "keys": torch.as_tensor(cam_dict["keys"])})
-            if len(pend) == batch:
-                _flush(walker, pend, args, writer)
-            _common.progress(process_id, n_gpus, it, len(databin))
-        _flush(walker, pend, args, writer)
+    writer = _common.AsyncWriter()
+    try:
+        with torch.no_grad(), torch.cuda.device(process_id):
+            model.cuda()
+            dev = torch.device("cuda", process_id)
+            walker = indexing.RandomWalk(_common.walk_radius(args, RADIUS))
+            pend = []
+            for it, pack in enumerate(loader):
+                name = pack["name"][0]
+                if not isinstance(name, str):
+                    name = voc12_dataloader.decode_int_filename(name)
+                size = (int(pack["size"][0]), int(pack["size"][1]))
+                keys, _keys_dev, cam = _common.CAM_STORE.get(name, args.cam_out_dir, dev)
+                pend.append({"name": name, "size": size, "img": _common.device_images(pack, (1.0,))[0],
+                             "cam": cam, "keys": keys})
+                if len(pend) == batch:
+                    _flush(model, walker, pend, args, writer)
+                _common.progress(process_id, n_gpus, it, len(databin))
+            _flush(model, walker, pend, args, writer)
+            walker.close()
+    finally:
         writer.close()
-        walker.close()
 
 
 def run(args):

@@ -4,10 +4,12 @@ Reads  args.irn_network, args.irn_weights_name, args.infer_list, args.voc12_root
        args.beta, args.exp_times, args.sem_seg_bg_thres, args.num_workers
 Writes args.sem_seg_out_dir/<name>.png  uint8 [H,W] (0 = background, class+1 otherwise)
 
-Per image (step/make_sem_seg_labels.py:28-51): EdgeDisplacement forward (PyTorch-ROCm) -> edge;
-CAM dict from disk; random walk of the CAMs over the edge affinities and the label epilogue run in
-libirn_hip.so.  Unlike the reference's batch-1 loop the walk is issued for `walk_batch` images at a
-time (default 64) so one launch fills the GPU for several rounds; results per image are unchanged.
+Per image (step/make_sem_seg_labels.py:28-51): EdgeDisplacement forward (PyTorch-ROCm) -> edge; the image's CAM —
+from the device store when make_cam ran in this process, else from its file; random walk of the CAMs over the edge
+affinities and the label epilogue run in libirn_hip.so.  Unlike the reference's batch-1 loop the IRNet forward runs
+`irn_batch` images per pass (default 8) and the walk is issued for `walk_batch` images at a time (default 64) so one
+launch fills the GPU for several rounds; results per image are unchanged.  `args.radius` (default 5 = the
+reference's hard-coded value) selects the walk radius.
 """
 import os
 
@@ -28,15 +30,26 @@ def _save_png(path, label):
     Image.fromarray(label).save(path)
 
 
-def _flush(walker, pend, args, writer):
+def edges_for(model, pend, irn_batch):
+    """EdgeDisplacement forward for the pending images, `irn_batch` at a time: ragged images are padded to the
+    512^2 crop like the reference pads each one (net/resnet50_irn.py:225), so a chunk is ONE trunk pass."""
+    for i in range(0, len(pend), irn_batch):
+        chunk = pend[i:i + irn_batch]
+        for p, (edge, dp) in zip(chunk, model.forward_batch([p.pop("img") for p in chunk])):
+            p["edge"], p["dp"] = edge, dp
+
+
+def _flush(model, walker, pend, args, writer):
     if not pend:
         return
+    edges_for(model, pend, int(getattr(args, "irn_batch", 0) or 8))
     rws = walker([p["edge"] for p in pend], [p["cam"] for p in pend],
                  beta=float(args.beta), exp_times=int(args.exp_times))
-    out = ops.label_epilogue(rws, [p["size"] for p in pend], float(args.sem_seg_bg_thres),
-                             keys=[p["keys"] for p in pend])
+    sizes, keys = [p["size"] for p in pend], [p["keys_dev"] for p in pend]
+    out = ops.label_epilogue(rws, sizes, float(args.sem_seg_bg_thres), keys=keys)
+    if walker.sync():                       # the persistent walk gave up and the batch was re-run on the streaming sweeps
+        out = ops.label_epilogue(rws, sizes, float(args.sem_seg_bg_thres), keys=keys)
     labels = [lab.cpu().numpy() for lab in out["labels"]]
-    walker.check()                          # the persistent walk reports a stuck tile instead of hanging
     for p, lab in zip(pend, labels):
         writer.submit(_save_png, os.path.join(args.sem_seg_out_dir, p["name"] + ".png"), lab)
     pend.clear()
@@ -47,27 +60,29 @@ def _work(process_id, model, dataset, args):
     n_gpus = len(dataset)
     loader = DataLoader(databin, shuffle=False, num_workers=int(args.num_workers) // n_gpus, pin_memory=False)
     batch = int(getattr(args, "walk_batch", 0) or 64)   # 64 VOC-size images = 3-4 rounds of the resident walk
-    with torch.no_grad(), torch.cuda.device(process_id):
-        model.cuda()
-        walker = indexing.RandomWalk(RADIUS)
-        writer = _common.AsyncWriter()
-        pend = []
-        for it, pack in enumerate(loader):
-            name = pack["name"][0]
-            if not isinstance(name, str):
-                name = voc12_dataloader.decode_int_filename(name)
-            size = (int(pack["size"][0]), int(pack["size"][1]))
-            edge, _dp = model(_common.device_images(pack, (1.0,))[0])
-            cam_dict = np.load(os.path.join(args.cam_out_dir, name + ".npy"), allow_pickle=True).item()
-            pend.append({"name": name, "size": size, "edge": edge,
-                         "cam": torch.as_tensor(cam_dict["cam"]).cuda(),
-                         "keys": torch.as_tensor(cam_dict["keys"]).cuda()})
-            if len(pend) == batch:
-                _flush(walker, pend, args, writer)
-            _common.progress(process_id, n_gpus, it, len(databin))
-        _flush(walker, pend, args, writer)
+    writer = _common.AsyncWriter()
+    try:
+        with torch.no_grad(), torch.cuda.device(process_id):
+            model.cuda()
+            dev = torch.device("cuda", process_id)
+            walker = indexing.RandomWalk(_common.walk_radius(args, RADIUS))
+            pend = []
+            for it, pack in enumerate(loader):
+                name = pack["name"][0]
+                if not isinstance(name, str):
+                    name = voc12_dataloader.decode_int_filename(name)
+                size = (int(pack["size"][0]), int(pack["size"][1]))
+                # CAM of this image: still on the device when make_cam ran in this process, else from its file
+                _keys, keys_dev, cam = _common.CAM_STORE.get(name, args.cam_out_dir, dev)
+                pend.append({"name": name, "size": size, "img": _common.device_images(pack, (1.0,))[0],
+                             "cam": cam, "keys_dev": keys_dev})
+                if len(pend) == batch:
+                    _flush(model, walker, pend, args, writer)
+                _common.progress(process_id, n_gpus, it, len(databin))
+            _flush(model, walker, pend, args, writer)
+            walker.close()
+    finally:
         writer.close()
-        walker.close()
 
 
 def run(args):

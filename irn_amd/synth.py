@@ -105,3 +105,14 @@ def photo(h, w, seed=0):
     img += rng.normal(0, 6, img.shape)
     return np.clip(np.rint(img), 0, 255).astype(np.uint8)
 
+
+
+def image_pair(h, w, seed=0, mean=(0.485, 0.456, 0.406), std=(0.229, 0.224, 0.225)):
+    """float32 [2,3,h,w]: a `photo` normalised like TorchvisionNormalize (reference voc12/dataloader.py:65-78),
+    channel-major, followed by its horizontal flip — the network input of one scale of a dataset item
+    (voc12/dataloader.py:196-199).  Regenerated from the seed wherever it is needed (6 MB at 512^2: not committed)."""
+    img = photo(h, w, seed)
+    out = np.empty((3, h, w), np.float32)
+    for c in range(3):
+        out[c] = (img[..., c] / 255. - mean[c]) / std[c]
+    return np.stack([out, out[..., ::-1]]).astype(np.float32)

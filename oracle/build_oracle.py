@@ -31,6 +31,9 @@ def load(native=False, out_dir=None):
     lib.irn_oracle_walk.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double,
                                     C.c_int, C.c_void_p]
     lib.irn_oracle_threads.restype = C.c_int
+    lib.irn_oracle_walk_batch.restype = C.c_int
+    lib.irn_oracle_walk_batch.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int,
+                                          C.c_double, C.c_int, C.c_void_p]
     return lib
 
 
@@ -46,6 +49,25 @@ def walk(lib, cam, edge, radius, beta, n_sweeps):
     if rc:
         raise MemoryError("irn_oracle_walk failed")
     return out
+
+
+def walk_batch(lib, cams, edges, radius, beta, n_sweeps):
+    """The image-parallel row-vectorised form (the CPU baseline of bench.py): lists of cams [C_i,h_i,w_i] and edges
+    [h_i,w_i] -> list of float32 [C_i,1,h_i,w_i]; one image per OpenMP thread."""
+    import ctypes as C
+    import numpy as np
+    n = len(cams)
+    cams = [np.ascontiguousarray(np.asarray(c, np.float32).reshape((-1,) + c.shape[-2:])) for c in cams]
+    edges = [np.ascontiguousarray(np.asarray(e, np.float32).reshape(c.shape[-2:])) for e, c in zip(edges, cams)]
+    outs = [np.empty((c.shape[0], 1) + c.shape[-2:], np.float32) for c in cams]
+    ptrs = lambda arrs: (C.c_void_p * n)(*[a.ctypes.data for a in arrs])
+    ints = lambda vals: (C.c_int * n)(*[int(v) for v in vals])
+    rc = lib.irn_oracle_walk_batch(n, ptrs(edges), ptrs(cams), ints([c.shape[0] for c in cams]),
+                                   ints([c.shape[1] for c in cams]), ints([c.shape[2] for c in cams]), int(radius),
+                                   float(beta), int(n_sweeps), ptrs(outs))
+    if rc:
+        raise MemoryError("irn_oracle_walk_batch: %d images failed" % rc)
+    return outs
 
 
 if __name__ == "__main__":

@@ -38,6 +38,14 @@ def build_parser():
     p.add_argument("--exp_times", default=8, type=int)
     p.add_argument("--ins_seg_bg_thres", default=0.25, type=float)
     p.add_argument("--sem_seg_bg_thres", default=0.25, type=float)
+    p.add_argument("--radius", default=5, type=int,
+                   help="random-walk radius of the label steps (not a flag of the reference, which hard-codes 5 at "
+                        "step/make_sem_seg_labels.py:41 and step/make_ins_seg_labels.py:135; 10 = BASELINE configs[2])")
+    p.add_argument("--cam_batch", default=0, type=int, help="images of one size per CAM trunk pass (0 = 8)")
+    p.add_argument("--irn_batch", default=0, type=int, help="images per IRNet trunk pass (0 = 8)")
+    p.add_argument("--keep_cams_on_device", default=True, type=_flag,
+                   help="hand the CAMs of make_cam to the label steps in device memory when they run in the same process "
+                        "(the .npy files are written all the same)")
     p.add_argument("--walk_batch", default=0, type=int,
                    help="images per random-walk launch (not in the reference); 0 = the step's default (64 sem-seg, 32 ins-seg)")
     p.add_argument("--log_name", default="sample_train_eval", type=str)

@@ -162,13 +162,22 @@ WALK_CASES = [
 ]
 
 
-def gen_walk(only=None):
+# The headline grid (BASELINE configs[2]: 512^2 images = 128x128 stride-4 grids) on the reference itself: one dense
+# propagate_to_edge run is ~5 min and ~5 GB here (18 354^2 fp32 matrices squared 8 times), so these live in their own
+# file (walk128.npz) and are generated with `--only walk128`.
+WALK_BIG_CASES = [
+    ("r10_b10_e8_128", 128, 128, 3, 10, 10, 8, 21),
+    ("r5_b10_e8_128", 128, 128, 2, 5, 10, 8, 22),
+]
+
+
+def gen_walk(only=None, cases=None, fname="walk.npz"):
     from misc import indexing
     out = {}
-    path = os.path.join(OUT, "walk.npz")
+    path = os.path.join(OUT, fname)
     if only and os.path.exists(path):
         out = dict(np.load(path))
-    for name, h, w, C, r, beta, e, seed in WALK_CASES:
+    for name, h, w, C, r, beta, e, seed in (cases or WALK_CASES):
         if only and name not in only:
             continue
         t0 = time.time()
@@ -336,6 +345,44 @@ def gen_nets():
         r50.model_zoo.load_url = real_load
 
 
+def gen_nets512():
+    """The backbones at the headline input size (BASELINE configs[1]/[2]: 512^2 VOC images): the reference's
+    CAM.forward on [2,3,512,512] and EdgeDisplacement.forward on a ragged [2,3,375,500] item (crop_size 512), seeded
+    random weights.  Inputs are `synth.image_pair(h, w, seed)` and are NOT stored (regenerated by the tests)."""
+    import net.resnet50 as r50
+    from irn_amd.net import weights as wgen
+
+    real_load = r50.model_zoo.load_url
+    r50.model_zoo.load_url = lambda *a, **k: dict(wgen.random_resnet50_state(seed=0), **{
+        "fc.weight": torch.zeros(1), "fc.bias": torch.zeros(1)})
+    try:
+        import net.resnet50_cam as rc
+        import net.resnet50_irn as ri
+        out = {}
+        cam = rc.CAM()
+        cam.load_state_dict(wgen.random_cam_state(seed=1), strict=True)
+        cam.eval()
+        irn = ri.EdgeDisplacement()
+        irn.load_state_dict(wgen.random_irn_state(seed=2), strict=False)
+        irn.eval()
+        with torch.no_grad():
+            out["cam512_seed"] = np.asarray([512, 512, 71], np.int32)
+            out["cam512_out"] = cam(torch.from_numpy(synth.image_pair(512, 512, 71))).numpy()
+            out["cam768_seed"] = np.asarray([768, 768, 72], np.int32)          # the 1.5x scale of make_cam
+            out["cam768_out"] = cam(torch.from_numpy(synth.image_pair(768, 768, 72))).numpy()
+            out["irn_seed"] = np.asarray([375, 500, 73], np.int32)
+            edge, dp = irn(torch.from_numpy(synth.image_pair(375, 500, 73)))
+            out["irn_edge"] = edge.numpy()
+            out["irn_dp"] = dp.numpy()
+            out["irn512_seed"] = np.asarray([512, 512, 74], np.int32)
+            edge, dp = irn(torch.from_numpy(synth.image_pair(512, 512, 74)))
+            out["irn512_edge"] = edge.numpy()
+            out["irn512_dp"] = dp.numpy()
+        np.savez_compressed(os.path.join(OUT, "nets512.npz"), **out)
+    finally:
+        r50.model_zoo.load_url = real_load
+
+
 def gen_msf():
     """Multi-scale dataset item: the reference's own VOC12ClassificationDatasetMSF.__getitem__
     (voc12/dataloader.py:185-205) on synthetic photos (imageio.imread stubbed to hand them over), i.e.
@@ -377,7 +424,7 @@ def gen_msf():
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", nargs="*", default=None,
-                    help="subset of: path affinity affinity_grad walk semseg instance cam_merge nets msf pair_disp; or walk case names")
+                    help="subset of: path affinity affinity_grad walk walk128 semseg instance cam_merge nets nets512 msf pair_disp; or walk case names")
     a = ap.parse_args()
     _install_reference()
     torch.set_num_threads(os.cpu_count())
@@ -395,6 +442,8 @@ def main():
     walk_names = {c[0] for c in WALK_CASES}
     if want("walk") or (sel and sel & walk_names):
         gen_walk(only=(sel & walk_names) if sel and not want("walk") else None)
+    if sel and "walk128" in sel:                      # never part of the default run (10 minutes)
+        gen_walk(cases=WALK_BIG_CASES, fname="walk128.npz")
     if want("semseg"):
         gen_semseg()
     if want("instance"):
@@ -403,6 +452,8 @@ def main():
         gen_cam_merge()
     if want("nets"):
         gen_nets()
+    if want("nets512"):
+        gen_nets512()
     if want("msf"):
         gen_msf()
     if want("pair_disp"):

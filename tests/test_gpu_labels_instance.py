@@ -168,3 +168,60 @@ def test_instance_labels_batch_equals_reference_golden(golden):
         assert np.array_equal(det["class"], ins[name + "_det_class"])
         assert np.abs(det["score"] - ins[name + "_det_score"]).max() <= 1e-4
     walker.close()
+
+
+def test_batched_front_end_equals_single_image_calls(golden):
+    """irn_find_centroids_batch / irn_cluster_centroids_batch on a ragged batch (golden images + fresh fields) give,
+    image by image, what the single-image entry points give — and those are pinned on the reference above."""
+    from irn_amd import ops, synth
+    ins = golden("instance")
+    dps = [ins[n + "_dp"] for n in ("a", "b", "c", "cen64", "cen_ragged")]
+    dps += [synth.displacement_field(h, w, seed=s, strength=0.3) for h, w, s in ((128, 128, 5), (7, 9, 6), (94, 125, 7))]
+    dev_dps = [torch.from_numpy(d).to(_dev()) for d in dps]
+    cens = ops.find_centroids_batch(dev_dps)
+    cmaps, ks = ops.cluster_centroids_batch(cens, dev_dps)
+    for i, dp in enumerate(dev_dps):
+        cen1 = ops.find_centroids_with_refinement(dp)
+        assert torch.equal(cens[i], cen1), i
+        cmap1, k1 = ops.cluster_centroids(cen1, dp)
+        assert ks[i] == k1 and torch.equal(cmaps[i], cmap1), i
+    for i, n in enumerate(("a", "b", "c", "cen64", "cen_ragged")):
+        oh = cmaps[i][None] == torch.arange(ks[i], device=_dev(), dtype=torch.int32)[:, None, None]
+        assert np.array_equal(oh.cpu().numpy(), _unpack(ins, n + "_instance_map"))
+
+
+def test_detect_instance_batch_vs_oracle_incl_empty_and_fragmented():
+    """irn_detect_instance_batch_*: a ragged batch with an all-background image in the middle and a salt-and-pepper
+    class map with thousands of one-pixel fragments (the ranking of detections runs over several workgroups)."""
+    from irn_amd import ops
+    rng = np.random.RandomState(11)
+    specs = [(37, 41, 5, 0.4, 0.0), (16, 16, 2, 1.0, 0.0), (96, 120, 7, 0.3, 0.0), (64, 80, 12, 0.2, 6.5)]
+    scores, clss, cids, thrs = [], [], [], []
+    for (h, w, c, p_bg, thr) in specs:
+        if p_bg == 0.3:                                   # iid classes per pixel: ~4000 fragments
+            cls = rng.randint(0, c + 1, size=(h, w))
+        else:
+            cls = np.kron(rng.randint(0, c + 1, size=((h + 3) // 4, (w + 3) // 4)), np.ones((4, 4), int))[:h, :w]
+        cls[rng.rand(h, w) < p_bg] = 0
+        scores.append(rng.rand(c, h, w).astype(np.float32))
+        clss.append(cls.astype(np.int32))
+        cids.append(np.arange(50, 50 + c))
+        thrs.append(thr)
+    got = ops.detect_instance_batch([torch.from_numpy(s).to(_dev()) for s in scores],
+                                    [torch.from_numpy(c).to(_dev()) for c in clss], cids, [s[2] for s in specs], thrs)
+    assert isinstance(got[1], ValueError)
+    n_frag = 0
+    for i in (0, 2, 3):
+        c = specs[i][2]
+        one_hot = np.stack([clss[i] == k + 1 for k in range(c)])
+        ref = O.detect_instance(scores[i], one_hot, cids[i], max_fragment_size=thrs[i])
+        assert got[i]["mask"].shape == ref["mask"].shape, i
+        assert np.array_equal(got[i]["mask"], ref["mask"].astype(bool)), i
+        assert np.array_equal(got[i]["class"], ref["class"]), i
+        assert np.array_equal(got[i]["score"], np.asarray(ref["score"], np.float32)), i
+        n_frag = max(n_frag, len(ref["score"]))
+    assert n_frag > 2048
+    # and the single-image form agrees on the fragmented map
+    one = ops.detect_instance(torch.from_numpy(scores[2]).to(_dev()), torch.from_numpy(clss[2]).to(_dev()), cids[2],
+                              specs[2][2], max_fragment_size=0.0)
+    assert np.array_equal(one["mask"], got[2]["mask"]) and np.array_equal(one["score"], got[2]["score"])

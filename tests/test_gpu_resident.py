@@ -207,3 +207,75 @@ def test_radius5_plain_store_vote_is_bitwise_equal_and_radius10_refuses():
     ref_w.close()
     with pytest.raises(IrnHipError, match="radius 5"):
         _walker(10, plain_store=1)
+
+
+def test_timeout_is_repaired_by_sync_and_reported_by_check():
+    """A persistent launch that gives up its bounded wait (test hook `inject_timeout`: the first poll that misses twice
+    gives up) must never hand garbage to the caller: `sync()` re-runs the batch on the streaming sweeps and says so;
+    `check()` — the benchmark's call — raises instead; the next run is healthy again."""
+    from irn_amd._lib import IrnHipError
+    shapes = [(128, 128, 1), (128, 128, 2), (94, 125, 3)]
+    edges, cams = _inputs(shapes, 2100)
+    wk = _walker(10)
+    ref = [o.clone() for o in wk(edges, cams, beta=10, n_sweeps=48)]
+    assert wk.sync() is False and wk.fallback_runs == 0
+    wk.set_option("poll_delay", 0)                 # early polls: plenty of misses
+    wk.set_option("inject_timeout", 1)
+    out = wk(edges, cams, beta=10, n_sweeps=48)
+    assert wk.sync() is True and wk.fallback_runs == 1
+    for i in range(len(shapes)):
+        assert (out[i] - ref[i]).abs().max().item() <= 2e-6, i      # streaming kernel: same operator, fp32 rounding apart
+    wk.check()                                     # handled: nothing left to report
+    wk.set_option("inject_timeout", 1)
+    wk(edges, cams, beta=10, n_sweeps=48)
+    with pytest.raises(IrnHipError, match="timed out"):
+        wk.check()
+    wk.set_option("poll_delay", 10)
+    out = wk(edges, cams, beta=10, n_sweeps=48)
+    assert wk.sync() is False
+    for i in range(len(shapes)):
+        assert torch.equal(out[i], ref[i]), i
+    wk.close()
+
+
+def test_propagate_to_edge_never_returns_a_timed_out_result():
+    """The drop-in entry point waits and repairs (the reference's call is synchronous too)."""
+    from irn_amd.misc import indexing
+    edges, cams = _inputs([(128, 128, 2)], 2200)
+    ref = indexing.propagate_to_edge(cams[0], edges[0][None], radius=10, beta=10, exp_times=5).clone()
+    wk = indexing._walker(_dev(), 10)
+    wk.set_option("poll_delay", 0)
+    wk.set_option("inject_timeout", 1)
+    n0 = wk.fallback_runs
+    out = indexing.propagate_to_edge(cams[0], edges[0][None], radius=10, beta=10, exp_times=5)
+    assert wk.fallback_runs == n0 + 1
+    assert (out - ref).abs().max().item() <= 2e-6
+    wk.set_option("poll_delay", 10)
+
+
+@pytest.mark.parametrize("cooperative", [1, 0])
+def test_walk_while_another_stream_holds_the_compute_units(cooperative):
+    """Co-residency of the persistent grid is requested from the runtime (cooperative launch), not assumed: with a
+    GEMM chain running on a second stream the walk's workgroups become resident as compute units drain, the tiles wait
+    for each other a little longer, and the result is the same — bit for bit unless the bounded wait expired, in which
+    case `sync()` has re-run the batch on the streaming sweeps."""
+    shapes = [(128, 128, 1 + i % 3) for i in range(8)]
+    edges, cams = _inputs(shapes, 2300)
+    wk = _walker(10, cooperative=cooperative)
+    ref = [o.clone() for o in wk(edges, cams, beta=10, n_sweeps=64)]
+    assert wk.sync() is False
+    a = torch.randn(8192, 8192, device=_dev())
+    side = torch.cuda.Stream()
+    torch.cuda.synchronize()
+    with torch.cuda.stream(side):
+        for _ in range(30):
+            a = (a @ a) * 1e-4
+    out = wk(edges, cams, beta=10, n_sweeps=64)
+    fell = wk.sync()
+    torch.cuda.synchronize()
+    for i in range(len(shapes)):
+        if fell:
+            assert (out[i] - ref[i]).abs().max().item() <= 2e-6, i
+        else:
+            assert torch.equal(out[i], ref[i]), i
+    wk.close()

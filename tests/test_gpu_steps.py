@@ -35,6 +35,26 @@ def _make_voc(tmp, n=4):
     return root, names, labels
 
 
+def _edges_like_the_step(args, root, names, chunk):
+    """edge / dp maps of the images exactly as the label steps compute them: decoded JPEG -> irn_msf_pack at scale 1 ->
+    EdgeDisplacement.forward_batch in the step's chunks (so MIOpen sees the same shapes)."""
+    from irn_amd import ops
+    from irn_amd.net import resnet50_irn
+    dev = torch.device("cuda", 0)
+    model = resnet50_irn.EdgeDisplacement()
+    model.load_state_dict(torch.load(args.irn_weights_name, map_location="cpu"), strict=False)
+    model = model.to(dev).eval()
+    edges, dps = {}, {}
+    with torch.no_grad():
+        for i in range(0, len(names), chunk):
+            part = names[i:i + chunk]
+            imgs = [torch.from_numpy(np.array(Image.open(root / "JPEGImages" / (n + ".jpg")).convert("RGB"))).to(dev) for n in part]
+            outs = model.forward_batch([ops.msf_pack(im, (1.0,))[0] for im in imgs])
+            for n, (e, d) in zip(part, outs):
+                edges[n], dps[n] = e[0].cpu().numpy(), d.cpu().numpy()
+    return edges, dps
+
+
 def test_steps_end_to_end(tmp_path):
     from irn_amd.net import weights
     from irn_amd.step import make_cam, make_ins_seg_labels, make_sem_seg_labels
@@ -77,13 +97,45 @@ def test_steps_end_to_end(tmp_path):
         # last bits (MIOpen picks solvers by timing), so the files are compared at the parity bar of SURVEY.md §8(d)
         assert (a["cam"] - b["cam"]).abs().max().item() <= 1e-4 and np.abs(a["high_res"] - b["high_res"]).max() <= 1e-4
 
+    from irn_amd.step import _common
+    hits0, misses0 = _common.CAM_STORE.hits, _common.CAM_STORE.misses
     make_sem_seg_labels.run(args)
+    assert _common.CAM_STORE.hits - hits0 == len(names) and _common.CAM_STORE.misses == misses0   # CAMs came from device memory
+    edges, dps = _edges_like_the_step(args, root, names, chunk=3)
+    from oracle import build_oracle, irn_oracle as O
+    olib = build_oracle.load()
     for n in names:
         png = np.asarray(Image.open(os.path.join(args.sem_seg_out_dir, n + ".png")))
         W, H = Image.open(root / "JPEGImages" / (n + ".jpg")).size
         assert png.dtype == np.uint8 and png.shape == (H, W)
         present = set(np.nonzero(labels[int(n.replace("_", ""))])[0] + 1) | {0}
         assert set(np.unique(png)) <= present
+        # VALUES: the oracle's walk + epilogue (step/make_sem_seg_labels.py:36-49) on the same edge map and the CAM file
+        d = np.load(os.path.join(args.cam_out_dir, n + ".npy"), allow_pickle=True).item()
+        rw = build_oracle.walk(olib, d["cam"].numpy(), edges[n], 5, 10, 256)
+        _, want, _ = O.sem_seg_epilogue(rw, (H, W), d["keys"].numpy(), 0.25)
+        assert (png != want).mean() <= 1e-3, (n, (png != want).mean())
+
+    # the same step reading the CAM files (no device hand-off) and with the walk radius of BASELINE configs[2]
+    file_args = argparse.Namespace(**{**vars(args), "sem_seg_out_dir": str(tmp_path / "sem_files")})
+    os.makedirs(file_args.sem_seg_out_dir)
+    _common.CAM_STORE.clear()
+    make_sem_seg_labels.run(file_args)
+    assert _common.CAM_STORE.misses - misses0 == len(names)
+    for n in names:
+        a = np.asarray(Image.open(os.path.join(args.sem_seg_out_dir, n + ".png")))
+        b = np.asarray(Image.open(os.path.join(file_args.sem_seg_out_dir, n + ".png")))
+        assert np.array_equal(a, b), n
+    r10_args = argparse.Namespace(**{**vars(args), "sem_seg_out_dir": str(tmp_path / "sem_r10"), "radius": 10})
+    os.makedirs(r10_args.sem_seg_out_dir)
+    make_sem_seg_labels.run(r10_args)
+    n = names[0]
+    W, H = Image.open(root / "JPEGImages" / (n + ".jpg")).size
+    d = np.load(os.path.join(args.cam_out_dir, n + ".npy"), allow_pickle=True).item()
+    rw = build_oracle.walk(olib, d["cam"].numpy(), edges[n], 10, 10, 256)
+    _, want, _ = O.sem_seg_epilogue(rw, (H, W), d["keys"].numpy(), 0.25)
+    png = np.asarray(Image.open(os.path.join(r10_args.sem_seg_out_dir, n + ".png")))
+    assert (png != want).mean() <= 1e-3
 
     make_ins_seg_labels.run(args)
     written = [n for n in names if os.path.exists(os.path.join(args.ins_seg_out_dir, n + ".npy"))]
@@ -96,6 +148,14 @@ def test_steps_end_to_end(tmp_path):
         assert len(d["score"]) == len(d["mask"]) == len(d["class"])
         # masks of one image never overlap (they come from an argmax)
         assert d["mask"].sum(0).max() <= 1
+        # VALUES: the oracle's instance pipeline (step/make_ins_seg_labels.py:131-150) on the same edge / dp / CAM
+        cd = np.load(os.path.join(args.cam_out_dir, n + ".npy"), allow_pickle=True).item()
+        walk = lambda x, e, radius, beta, exp_times: build_oracle.walk(olib, x, e, radius, beta, 2 ** exp_times)
+        _, _, _, _, want = O.instance_labels(cd["cam"].numpy(), cd["keys"].numpy(), edges[n], dps[n], (H, W), walk=walk)
+        assert len(want["score"]) == len(d["score"]), n
+        assert np.array_equal(np.asarray(want["class"]), d["class"]), n
+        assert (want["mask"].astype(bool) != d["mask"]).mean() <= 1e-3, n
+        assert np.abs(np.asarray(want["score"], np.float32) - d["score"]).max() <= 1e-3, n
 
 
 def test_cam_merge_kernel_vs_oracle_and_reference_golden(golden):
@@ -134,27 +194,32 @@ def test_cam_merge_kernel_vs_oracle_and_reference_golden(golden):
 
 
 def test_bench_contract_one_json_line():
-    """python bench.py (small batch) prints ONE JSON line with the driver's fields, the `roofline` object of
-    the dominant kernel and the `cpu_baseline` object."""
+    """python bench.py (small batch) prints ONE JSON line with the driver's fields, the `roofline` object of the dominant
+    kernel (binding ceiling at the top level), the `cpu_baseline` object (port + reference algorithm) and the `legs`."""
     import json
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "2", "--warmup", "1", "--batch", "8",
-                          "--cpu-images", "1"], capture_output=True, text=True, timeout=600, cwd=root)
+                          "--cpu-images", "2", "--legs", "coco,ins"], capture_output=True, text=True, timeout=900, cwd=root)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1
     r = json.loads(lines[0])
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
-                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "legs"):
         assert key in r, key
     assert r["unit"] == "images/s" and r["n_gpus"] == 1 and r["steps"] == 2 and r["scaling"] == "weak"
     assert r["higher_is_better"] is True and r["vs_baseline"] is None and r["data"] == "synthetic" and r["dtype"] == "f32"
     assert "workload" in r["config"] and "model" not in r["config"]
     rf = r["roofline"]
-    assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0
-    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9 and rf["achieved"] > 0 and "traffic" in rf
+    assert rf["bound"] == "fp32_vector" and rf["unit"] == "TFLOP/s" and rf["peak"] == 157.3
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9 and 0 < rf["frac"] < 1 and "traffic" in rf
+    assert rf["hbm_equivalent"]["unit"] == "GB/s" and rf["hbm_equivalent"]["peak"] == 8000.0
     assert abs(r["value"] - 2 * 8 / (r["ms_per_step"] * 2e-3)) / r["value"] < 1e-6
     cb = r["cpu_baseline"]
-    assert cb["kind"] in ("port", "reference") and cb["cores"] >= 1 and cb["value"] > 0 and cb["unit"] == "images/s" and cb["sample"]
+    assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and cb["unit"] == "images/s" and cb["sample"]
+    ra = cb["reference_algorithm"]
+    assert ra["extrapolated"] is True and ra["value"] > 0 and ra["seconds_measured"]
+    for leg in ("coco", "ins"):
+        assert r["legs"][leg].get("value", 0) > 0, r["legs"][leg]

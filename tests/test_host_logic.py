@@ -163,3 +163,77 @@ def test_dataset_raw_mode_hands_over_the_decoded_image(tmp_path):
     from oracle import msf_oracle as M
     for a, b in zip(ref["img"], M.msf_item(decoded, (1.0, 0.5))):
         assert np.array_equal(a, b)
+
+
+def test_dense_operator_mirrors_match_reference(golden):
+    """irn_amd.misc.indexing.affinity_sparse2dense / to_transition_matrix (API-completeness mirrors of reference
+    misc/indexing.py:112-139; the walk itself never densifies) against the oracle's restatement and, chained the way
+    misc/indexing.py:141-165 chains them, against the reference's own propagate_to_edge output."""
+    import torch.nn.functional as F
+    from irn_amd.misc import indexing
+    from oracle import irn_oracle as O
+    af = golden("affinity")
+    for r in (3, 5):
+        edge = af["r%d_edge" % r]
+        h, w = edge.shape
+        pi = indexing.PathIndex(r, (h + r, w + 2 * r))
+        aff = torch.from_numpy(af["r%d_aff" % r])
+        dense = indexing.affinity_sparse2dense(aff, pi.src_indices, pi.dst_indices, (h + r) * (w + 2 * r))
+        want = O.affinity_dense(af["r%d_aff" % r], pi.src_indices, pi.dst_indices, (h + r) * (w + 2 * r))
+        assert np.array_equal(dense.numpy(), want)
+        assert torch.equal(dense, dense.t()) and float(dense.diagonal().min()) == 1.0
+        t = indexing.to_transition_matrix(dense[:64, :64].contiguous() + 0.01, 10, 2)
+        want_t = O.to_transition_matrix(want[:64, :64] + np.float32(0.01), 10, 2)
+        assert np.abs(t.numpy() - want_t).max() <= 1e-6
+    wk = golden("walk")
+    name = "r5_b10_e4"
+    h, w, c, r, beta, e = (int(v) for v in wk[name + "_params"])
+    edge = torch.from_numpy(wk[name + "_edge"])[None]
+    pi = indexing.PathIndex(r, (h + r, w + 2 * r))
+    ep = F.pad(edge, (r, r, 0, r), value=1.0).reshape(-1).numpy()
+    aff = torch.from_numpy(O.edge_to_affinity(ep, pi.path_indices))
+    dense = indexing.affinity_sparse2dense(aff, pi.src_indices, pi.dst_indices, (h + r) * (w + 2 * r))
+    dense = dense.view(h + r, w + 2 * r, h + r, w + 2 * r)[:-r, r:-r, :-r, r:-r].reshape(h * w, h * w)
+    t = indexing.to_transition_matrix(dense, beta, e)
+    x = torch.from_numpy(wk[name + "_cam"]).view(-1, h, w) * (1 - edge)
+    rw = torch.matmul(x.view(-1, h * w), t).view(-1, 1, h, w)
+    assert np.abs(rw.numpy() - wk[name + "_rw"]).max() <= 1e-6
+
+
+def test_logger_and_timer(tmp_path, capsys):
+    import sys
+    import time
+    log = pyutils.Logger(str(tmp_path / "run.log"))
+    try:
+        t = pyutils.Timer("step.make_cam:")
+        print("hello")
+        time.sleep(0.01)
+        assert t.lapse() >= 0.01 and t.elapsed() >= 0.01
+    finally:
+        log.close()
+    assert sys.stdout is not log
+    text = (tmp_path / "run.log").read_text()
+    assert "step.make_cam:" in text and "hello" in text
+    assert "hello" in capsys.readouterr().out
+
+
+def test_backbones_at_512_match_reference(golden):
+    """CAM.forward on [2,3,512,512] and EdgeDisplacement.forward on a ragged VOC-size item vs the reference's CPU forwards
+    (tests/golden/nets512.npz); the GPU forms of these checks live in tests/test_gpu_parity_r2.py."""
+    from irn_amd import synth
+    from irn_amd.net import resnet50_cam, resnet50_irn, weights
+    g = golden("nets512")
+    cam = resnet50_cam.CAM()
+    cam.load_state_dict(weights.random_cam_state(seed=1), strict=True)
+    cam.eval()
+    irn = resnet50_irn.EdgeDisplacement()
+    irn.load_state_dict(weights.random_irn_state(seed=2), strict=False)
+    irn.eval()
+    with torch.no_grad():
+        h, w, seed = (int(v) for v in g["cam512_seed"])
+        y = cam(torch.from_numpy(synth.image_pair(h, w, seed))).numpy()
+        assert np.abs(y - g["cam512_out"]).max() <= 1e-4 * np.abs(g["cam512_out"]).max()
+        h, w, seed = (int(v) for v in g["irn_seed"])
+        edge, dp = irn(torch.from_numpy(synth.image_pair(h, w, seed)))
+        assert np.abs(edge.numpy() - g["irn_edge"]).max() <= 1e-4
+        assert np.abs(dp.numpy() - g["irn_dp"]).max() <= 1e-4 * max(1.0, np.abs(g["irn_dp"]).max())

@@ -79,6 +79,27 @@ def test_walk_dense_restatement_small(golden):
         assert np.abs(de - wk[n + "_rw"]).max() <= 5e-4, n
 
 
+def test_dense_torch_restatement_vs_reference_golden(golden):
+    """oracle/dense_ref.py (the reference's own dense algorithm op for op on torch CPU tensors: what bench.py times as
+    `cpu_baseline.reference_algorithm`) reproduces the reference's outputs bit for bit where the same torch kernels
+    run the same sizes, i.e. on every small golden case."""
+    from oracle import dense_ref
+    wk, names = _walk_cases(golden)
+    n_checked = 0
+    for n in names:
+        h, w, c, r, b, e = wk[n + "_params"]
+        if h * w > 1100:
+            continue
+        x = wk[n + "_cam"]
+        if n.endswith("_ck"):
+            x = x.reshape(2, c // 2, h, w)
+        de = dense_ref.propagate_to_edge(x, wk[n + "_edge"][None], int(r), int(b), int(e)).numpy()
+        assert de.shape == wk[n + "_rw"].shape
+        assert np.abs(de - wk[n + "_rw"]).max() <= 1e-6, n
+        n_checked += 1
+    assert n_checked >= 5
+
+
 def test_stencil_conserves_degree_weighted_mass(golden):
     wk, _ = _walk_cases(golden)
     n = "r5_b10_e8"
