@@ -267,7 +267,7 @@ int irn_detect_instance_emit(const float *rw_up_dev, const int32_t *argmax_dev, 
 /* Batched forms: one labelling pass sequence for all images of a batch.  _batch_count writes the detection counts
  * to n_det_dev (dev int32 [n_images]) and does NOT synchronise; the caller reads them with one transfer, sizes the
  * outputs and calls _batch_emit with the same inputs and scratch plus the counts (host) — images with n_det[i] == 0
- * are skipped (their output pointers may be NULL); every mask block must be 16-byte aligned.  min_area: host [n_images].
+ * are skipped (their output pointers may be NULL).  min_area: host [n_images].
  * scratch: irn_detect_batch_scratch_bytes. */
 size_t irn_detect_batch_scratch_bytes(int n_images, const int32_t *n_channels, const int32_t *h, const int32_t *w);
 int irn_detect_instance_batch_count(int n_images, const float *const *rw_up_dev, const int32_t *const *argmax_dev,

@@ -374,13 +374,17 @@ __global__ __launch_bounds__(256) void det_order_kernel(const DetJob *__restrict
 __global__ __launch_bounds__(256) void det_zero_masks_kernel(const DetJob *__restrict__ jobs) {
     const DetJob J = jobs[blockIdx.y];
     const size_t total = (size_t)J.n_det * J.h * J.w;
+    if (total == 0) return;
     uint8_t *m = J.mask;
-    // the packed output keeps every mask block 16-byte aligned (irn_detect_instance_batch_emit checks)
-    const size_t n16 = total / 16;
-    uint4 *m16 = reinterpret_cast<uint4 *>(m);
+    // bytes up to the first 16-byte boundary, 16-byte stores for the body, bytes for the tail
+    const size_t pre = std::min(total, (size_t)((16 - ((uintptr_t)m & 15)) & 15));
+    const size_t n16 = (total - pre) / 16;
+    uint4 *m16 = reinterpret_cast<uint4 *>(m + pre);
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (size_t)gridDim.x * 256) m16[i] = make_uint4(0, 0, 0, 0);
-    if (blockIdx.x == 0)
-        for (size_t i = n16 * 16 + threadIdx.x; i < total; i += 256) m[i] = 0;
+    if (blockIdx.x == 0) {
+        for (size_t i = threadIdx.x; i < pre; i += 256) m[i] = 0;
+        for (size_t i = pre + n16 * 16 + threadIdx.x; i < total; i += 256) m[i] = 0;
+    }
 }
 
 // Pixel p belongs to detection newid[prov[root(p)]]: its mask byte, and area / max score per detection.  Scores are
@@ -682,8 +686,6 @@ extern "C" int irn_detect_instance_batch_emit(int n_images, const float *const *
         if (J.n_det == 0) continue;                       // nothing to write for this image
         if (!score_dev[i] || !channel_dev[i] || !mask_dev[i])
             return fail(IRN_ERR_ARG, "irn_detect_instance_batch_emit: image %d: null output", i);
-        if (((uintptr_t)mask_dev[i] & 15) != 0)
-            return fail(IRN_ERR_ARG, "irn_detect_instance_batch_emit: image %d: masks must be 16-byte aligned", i);
         J.score = score_dev[i];
         J.channel = channel_dev[i];
         J.mask = mask_dev[i];

@@ -1,0 +1,55 @@
+#!/bin/bash
+# One gpurun call of round 2 (the script is rewritten per session; results land in gpurun_out/r2_sN/).
+# usage: tools/gpu_session.sh <N> [what...]      what: tests bench ab prof pmc
+set -u
+S=${1:-1}; shift || true
+WHAT=${*:-tests bench ab prof pmc}
+OUT=gpurun_out/r2_s$S
+mkdir -p $OUT
+export TMPDIR=/tmp MIOPEN_FIND_MODE=${MIOPEN_FIND_MODE:-2}
+for w in $WHAT; do
+case $w in
+tests)
+  timeout 900 python -m pytest tests -m gpu -q --maxfail=25 -x --durations=15 > $OUT/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> $OUT/pytest_gpu.log
+  tail -40 $OUT/pytest_gpu.log ;;
+tests_all)
+  timeout 1200 python -m pytest tests -m gpu -q --maxfail=25 --durations=15 > $OUT/pytest_gpu.log 2>&1; echo "pytest rc=$?" >> $OUT/pytest_gpu.log
+  tail -60 $OUT/pytest_gpu.log ;;
+bench)
+  timeout 600 python bench.py --steps 10 --warmup 3 --json-out $OUT/bench_default.json > $OUT/bench_default.log 2>&1; echo "bench rc=$?"
+  tail -c 6000 $OUT/bench_default.log ;;
+ab)
+  for lib in libirn_hip.so libirn_hip_prev.so; do
+    [ -f irn_amd/lib/$lib ] || continue
+    for wl in walk coco walk_r5; do
+      IRN_HIP_LIB=$PWD/irn_amd/lib/$lib timeout 300 python bench.py --workload $wl --steps 6 --warmup 2 --no-legs --no-cpu-baseline \
+         --json-out $OUT/ab_${wl}_${lib%.so}.json > $OUT/ab_${wl}_${lib%.so}.log 2>&1
+      python - <<PY
+import json
+try:
+    r = json.load(open("$OUT/ab_${wl}_${lib%.so}.json"))
+    print("$lib $wl: %.1f img/s, launch %.3f ms, frac %.4f" % (r["value"], r["roofline"]["avg_launch_ms"], r["roofline"]["frac"]))
+except Exception as e:
+    print("$lib $wl: FAILED", e)
+PY
+    done
+  done ;;
+prof)
+  R=$PWD; cd /tmp
+  timeout 300 rocprofv3 --kernel-trace --stats -d $R/$OUT/prof_trace -o walk -f csv -- python $R/bench.py --steps 4 --warmup 1 --no-legs --no-cpu-baseline > $R/$OUT/prof_trace.log 2>&1
+  cd $R
+  find $OUT/prof_trace -name "*kernel_stats*" -exec cp {} $OUT/kernel_stats.csv \;
+  head -12 $OUT/kernel_stats.csv ;;
+pmc)
+  R=$PWD; cd /tmp
+  for c in FETCH_SIZE WRITE_SIZE; do
+    timeout 300 rocprofv3 --pmc $c -d $R/$OUT/prof_$c -o walk -f csv -- python $R/bench.py --steps 1 --warmup 0 --no-legs --no-cpu-baseline > $R/$OUT/prof_$c.log 2>&1
+  done
+  cd $R
+  python tools/reduce_prof.py $OUT > $OUT/prof_summary.txt 2>&1; grep -E "resident_k|affinity_k" $OUT/prof_summary.txt | cut -c1-24,96-200 | head -12
+  find $OUT -name "walk_kernel_trace.csv" -delete; find $OUT -name "walk_counter_collection.csv" -delete ;;
+legs)
+  timeout 900 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --json-out $OUT/bench_legs.json > $OUT/bench_legs.log 2>&1; tail -c 4000 $OUT/bench_legs.log ;;
+esac
+done
+du -sh $OUT
