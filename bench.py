@@ -52,7 +52,7 @@ def parse(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="walk", choices=["walk", "walk_r5", "ins", "coco", "cam", "e2e", "steps"])
+    ap.add_argument("--workload", default="walk", choices=["walk", "walk_r5", "ins", "ins_r10", "coco", "cam", "e2e", "steps"])
     ap.add_argument("--batch", type=int, default=0, help="images per GPU per step (0 = workload default)")
     ap.add_argument("--unique", type=int, default=96, help="distinct synthetic images per GPU")
     ap.add_argument("--variant", type=int, default=2, help="0 generic sweep, 1 blocked streaming sweep, 2 weights-stationary persistent walk")
@@ -65,7 +65,8 @@ def parse(argv=None):
                     help="extra irn_walk_set_option settings (tuning experiments), e.g. poll_delay=8")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-legs", action="store_true", help="skip the short secondary runs (cam, e2e, steps, walk_r5, ins, coco)")
-    ap.add_argument("--legs", default="cam,e2e,steps,walk_r5,ins,coco")
+    ap.add_argument("--legs", default="cam,e2e,steps,walk_r5,ins,ins_r10,coco")
+    ap.add_argument("--loader-workers", type=int, default=4, help="DataLoader workers of the `steps` workload")
     ap.add_argument("--cpu-images", type=int, default=0, help="images of the CPU port sample (0 = 2 per host thread, at most 256)")
     ap.add_argument("--json-out", default=None)
     return ap.parse_args(argv)
@@ -75,7 +76,8 @@ WORKLOADS = {
     #            h    w    radius beta exp  out      default batch
     "walk":    (128, 128, 10, 10.0, 8, (512, 512), 192),     # BASELINE configs[2]
     "walk_r5": (128, 128, 5, 10.0, 8, (512, 512), 256),     # configs[0]'s operator setting at full batch
-    "ins":     (128, 128, 10, 10.0, 8, (512, 512), 64),     # configs[3]: instance labels (cfg3's walk + dp)
+    "ins":     (128, 128, 5, 10.0, 8, (512, 512), 64),      # configs[3]: instance labels, radius 5 = the reference's call site (step/make_ins_seg_labels.py:135)
+    "ins_r10": (128, 128, 10, 10.0, 8, (512, 512), 64),     # the same at SURVEY.md 8(d)'s row 4 radius
     "coco":    (256, 256, 10, 10.0, 8, (1024, 1024), 2),    # configs[4]: 80 classes, 1024^2
 }
 
@@ -90,7 +92,7 @@ def make_inputs(workload, n_unique, seed0, device):
         edges.append(torch.from_numpy(synth.edge_field(h, w, seed)).to(device))
         cams.append(torch.from_numpy(synth.cam_blobs(k, h, w, seed)).to(device))
         keys.append(torch.from_numpy(synth.voc_keys(min(k, 20), seed) if k <= 20 else np.arange(k)).to(device))
-        if workload == "ins":
+        if workload in ("ins", "ins_r10"):
             dps.append(torch.from_numpy(synth.displacement_field(h, w, seed=seed, strength=0.3)).to(device))
     return edges, cams, keys, dps
 
@@ -245,17 +247,17 @@ def run_walk(a, workload, rank, world, device, dist, parallel, steps, warmup, ba
             "label_checksum": checksum}
 
 
-def run_ins(a, rank, world, device, dist, parallel, steps, warmup, batch=0):
+def run_ins(a, workload, rank, world, device, dist, parallel, steps, warmup, batch=0):
     """configs[3]: instance pseudo-labels from resident edge / displacement / CAM tensors — centroid refinement,
     clustering, per-instance CAM split + random walk, label epilogue, per-mask connected components, and the transfer
     of the detections to the host (step/make_ins_seg_labels.py:131-152 for every image of the batch)."""
     from irn_amd import synth
     from irn_amd.misc import indexing
     from irn_amd.step import make_ins_seg_labels as mis
-    h, w, radius, beta, exp_times, out_hw, default_batch = WORKLOADS["ins"]
+    h, w, radius, beta, exp_times, out_hw, default_batch = WORKLOADS[workload]
     batch = batch or default_batch
     n_unique = min(a.unique, batch)
-    edges_u, cams_u, keys_u, dps_u = make_inputs("ins", n_unique, 1000 * (rank + 1), device)
+    edges_u, cams_u, keys_u, dps_u = make_inputs(workload, n_unique, 1000 * (rank + 1), device)
     items = [{"edge": edges_u[i % n_unique][None], "dp": dps_u[i % n_unique], "cam": cams_u[i % n_unique],
               "keys": keys_u[i % n_unique].cpu(), "size": out_hw} for i in range(batch)]
     walker = indexing.RandomWalk(radius, device)
@@ -356,7 +358,7 @@ def run_steps(a, rank, world, device, dist, parallel, steps, warmup, batch=0):
         torch.save(weights.random_cam_state(1), os.path.join(tmp, "res50_cam.pth"))
         torch.save(weights.random_irn_state(2), os.path.join(tmp, "res50_irn.pth"))
         args = argparse.Namespace(
-            num_workers=min(8, os.cpu_count() or 1), voc12_root=root, train_list=os.path.join(tmp, "train.txt"),
+            num_workers=int(a.loader_workers), voc12_root=root, train_list=os.path.join(tmp, "train.txt"),
             infer_list=os.path.join(tmp, "train.txt"), cam_network="net.resnet50_cam",
             cam_weights_name=os.path.join(tmp, "res50_cam"), cam_scales=(1.0, 0.5, 1.5, 2.0), irn_network="net.resnet50_irn",
             irn_weights_name=os.path.join(tmp, "res50_irn.pth"), beta=10, exp_times=8, sem_seg_bg_thres=0.25,
@@ -384,13 +386,18 @@ def run_steps(a, rank, world, device, dist, parallel, steps, warmup, batch=0):
             def flush(self):
                 pass
 
+        pass_s = {"make_cam": 0.0, "make_sem_seg_labels": 0.0}
+
         def step():
             real = sys.stdout
             sys.stdout = _Quiet()                      # progress ticks of the steps would break the one-JSON-line contract
             try:
                 _common.CAM_STORE.clear()
+                t0 = time.perf_counter()
                 _on_device(dev_index, make_cam._work, model_c, ds_c, args)
+                t1 = time.perf_counter()
                 _on_device(dev_index, make_sem_seg_labels._work, model_i, ds_i, args)
+                pass_s["make_cam"], pass_s["make_sem_seg_labels"] = t1 - t0, time.perf_counter() - t1
             finally:
                 sys.stdout = real
 
@@ -399,7 +406,8 @@ def run_steps(a, rank, world, device, dist, parallel, steps, warmup, batch=0):
         if n_png != batch:
             raise RuntimeError("steps leg: %d label maps written for %d images" % (n_png, batch))
         return {"value": steps * batch * world / elapsed, "ms_per_step": 1e3 * elapsed / steps, "batch": batch,
-                "cam_store_hits": _common.CAM_STORE.hits}
+                "cam_store_hits": _common.CAM_STORE.hits, "loader_workers": args.num_workers,
+                "last_pass_seconds": dict(pass_s)}
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
 
@@ -420,7 +428,7 @@ def describe(workload, r):
                 "+ x4 upsample/argmax label epilogue; K~VOC label histogram%s; inputs resident in HBM" %
                 (workload, r["out_hw"][0], r["out_hw"][1], r["h"], r["w"], r["radius"], r["beta"], r["exp_times"],
                  " (80 classes)" if workload == "coco" else ""))
-    if workload == "ins":
+    if workload in ("ins", "ins_r10"):
         return ("ins: VOC12-shaped %dx%d images (%dx%d grids), instance labels: displacement-field centroids + clustering + "
                 "per-instance random walk radius=%d beta=%g 2^%d + epilogue + connected-component detections copied to the "
                 "host; edge / displacement / CAM tensors resident in HBM" %
@@ -436,15 +444,15 @@ def describe(workload, r):
 def run_workload(a, workload, rank, world, device, dist, parallel, steps, warmup, batch=0):
     if workload in ("walk", "walk_r5", "coco"):
         return run_walk(a, workload, rank, world, device, dist, parallel, steps, warmup, batch)
-    if workload == "ins":
-        return run_ins(a, rank, world, device, dist, parallel, steps, warmup, batch)
+    if workload in ("ins", "ins_r10"):
+        return run_ins(a, workload, rank, world, device, dist, parallel, steps, warmup, batch)
     if workload == "steps":
         return run_steps(a, rank, world, device, dist, parallel, steps, warmup, batch)
     return run_backbone(a, workload, rank, world, device, dist, parallel, steps, warmup, batch)
 
 
 LEG_RUNS = {   # short runs for the `legs` object of the default line: (steps, warmup, batch)
-    "cam": (2, 1, 8), "e2e": (2, 1, 8), "steps": (1, 1, 32), "walk_r5": (3, 1, 256), "ins": (3, 1, 64), "coco": (3, 1, 2),
+    "cam": (2, 1, 8), "e2e": (2, 1, 8), "steps": (1, 1, 32), "walk_r5": (3, 1, 256), "ins": (3, 1, 64), "ins_r10": (3, 1, 64), "coco": (3, 1, 2),
 }
 
 
@@ -505,6 +513,7 @@ def main(argv=None):
     if rank == 0:
         stage = {"walk": "random-walk label generation stage", "walk_r5": "random-walk label generation stage, radius 5",
                  "coco": "random-walk label generation stage, COCO shape", "ins": "instance label generation stage",
+                 "ins_r10": "instance label generation stage, radius 10",
                  "cam": "multi-scale CAM inference stage", "e2e": "CAM + IRNet + walk + labels, end to end",
                  "steps": "run_sample.py step API, make_cam + make_sem_seg_labels"}[a.workload]
         res = {
@@ -519,12 +528,12 @@ def main(argv=None):
         if "shapes" in r:
             res["config"].update({"variant": a.variant, "mean_channels": float(np.mean([s[2] for s in r["shapes"]]))})
             res["label_checksum"] = r["label_checksum"]
-        for k in ("detections_per_image", "fallback_runs", "cam_store_hits"):
+        for k in ("detections_per_image", "fallback_runs", "cam_store_hits", "loader_workers", "last_pass_seconds"):
             if k in r:
                 res["config"][k] = r[k]
         res["cpu_baseline"] = None
-        if world == 1 and not a.no_cpu_baseline and a.workload in ("walk", "walk_r5", "coco", "ins"):
-            res["cpu_baseline"] = cpu_baseline(a.workload if a.workload != "ins" else "walk", a.cpu_images, 1000)
+        if world == 1 and not a.no_cpu_baseline and a.workload in ("walk", "walk_r5", "coco"):
+            res["cpu_baseline"] = cpu_baseline(a.workload, a.cpu_images, 1000)
         if world == 1 and not a.no_legs and a.workload == "walk":
             legs = {}
             for name in [n for n in a.legs.split(",") if n]:
@@ -537,7 +546,7 @@ def main(argv=None):
                     if "shapes" in lr:
                         ro = roofline_object(a, name, lr)
                         legs[name]["fp32_vector_frac"] = ro["frac"] if ro.get("bound") == "fp32_vector" else ro["fp32_vector"]["frac"]
-                    for k in ("detections_per_image", "cam_store_hits"):
+                    for k in ("detections_per_image", "cam_store_hits", "loader_workers", "last_pass_seconds"):
                         if k in lr:
                             legs[name][k] = lr[k]
                 except Exception as e:                      # a leg must never cost the headline line

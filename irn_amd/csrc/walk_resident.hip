@@ -57,10 +57,12 @@ struct RCfg;
 template <>
 struct RCfg<10> {
     static constexpr int Q = 8, SL_Y = 1, SL_X = 1;
+    static constexpr bool PREFETCH_ROWS = true;     // read the next neighbour row's window ahead of this row's FMAs
 };
 template <>
 struct RCfg<5> {
     static constexpr int Q = 2, SL_Y = 2, SL_X = 2;
+    static constexpr bool PREFETCH_ROWS = false;
 };
 
 // The neighbour disc (dy,dx) != (0,0), dx^2 + dy^2 < R^2, in raster order: the union of the
@@ -275,8 +277,8 @@ template <int R, int QI, int HALF>
 __device__ __forceinline__ void partial_sums(const float (&wr)[Geom<R>::NS][4], const float *xrow, float (&pf)[4]) {
     constexpr int NR = kRowList<R, QI, HALF>.n;
     if constexpr (HALF != 1) pf[0] = pf[1] = pf[2] = pf[3] = 0.f;
-    if constexpr (NR > 0 && R == 5) {
-        // radius 5: row after row (the double-buffered order spills in that instantiation)
+    if constexpr (NR > 0 && !RCfg<R>::PREFETCH_ROWS) {
+        // row after row
         static_for<NR>([&](auto ir) __attribute__((always_inline)) {
             float w1[kMaxWin * 4];
             load_window<R, QI, kRowList<R, QI, HALF>.dy[decltype(ir)::value]>(w1, xrow);

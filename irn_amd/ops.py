@@ -346,21 +346,32 @@ def detect_instance_batch(rw_ups, argmaxes, class_ids, n_channels, max_fragment_
         host[:total].copy_(packed[shift:shift + total], non_blocking=True)
         torch.cuda.current_stream().synchronize()                              # host round trip 2
     raw = host.numpy()
-    out = []
-    for i in range(n):
+
+    def unpack(i):
         nd = nds[i]
         if nd == 0:
-            out.append(ValueError("detect_instance: no foreground pixel in any channel"))
-            continue
+            return ValueError("detect_instance: no foreground pixel in any channel")
         o_sc, o_ch, o_mk = offs[i]
         score = raw[o_sc:o_sc + 4 * nd].view(np.float32).copy()
         chan = raw[o_ch:o_ch + 4 * nd].view(np.int32)
         mask = raw[o_mk:o_mk + nd * hs[i] * ws[i]].view(np.bool_).reshape(nd, hs[i], ws[i]).copy()
-        out.append({"score": score, "mask": mask, "class": np.asarray(class_ids[i])[chan]})
-    return out
+        return {"score": score, "mask": mask, "class": np.asarray(class_ids[i])[chan]}
+
+    # the staging buffer is reused by the next batch, so every image's masks (1-3 MB) are copied out of it: on a few
+    # host threads (numpy releases the GIL for the copy), or this memcpy is as long as the GPU work of the batch
+    return list(_copy_pool().map(unpack, range(n)))
 
 
 _CACHE = {}
+_POOL = []
+
+
+def _copy_pool():
+    if not _POOL:
+        from concurrent.futures import ThreadPoolExecutor
+        _POOL.append(ThreadPoolExecutor(max_workers=8))
+    return _POOL[0]
+
 
 
 def _cached(tag, dev, nbytes, dtype):

@@ -35,24 +35,25 @@ def _make_voc(tmp, n=4):
     return root, names, labels
 
 
-def _edges_like_the_step(args, root, names, chunk):
-    """edge / dp maps of the images exactly as the label steps compute them: decoded JPEG -> irn_msf_pack at scale 1 ->
-    EdgeDisplacement.forward_batch in the step's chunks (so MIOpen sees the same shapes)."""
-    from irn_amd import ops
-    from irn_amd.net import resnet50_irn
-    dev = torch.device("cuda", 0)
-    model = resnet50_irn.EdgeDisplacement()
-    model.load_state_dict(torch.load(args.irn_weights_name, map_location="cpu"), strict=False)
-    model = model.to(dev).eval()
-    edges, dps = {}, {}
-    with torch.no_grad():
-        for i in range(0, len(names), chunk):
-            part = names[i:i + chunk]
-            imgs = [torch.from_numpy(np.array(Image.open(root / "JPEGImages" / (n + ".jpg")).convert("RGB"))).to(dev) for n in part]
-            outs = model.forward_batch([ops.msf_pack(im, (1.0,))[0] for im in imgs])
-            for n, (e, d) in zip(part, outs):
-                edges[n], dps[n] = e[0].cpu().numpy(), d.cpu().numpy()
-    return edges, dps
+class _CaptureEdges:
+    """Records the edge / displacement maps the label steps actually computed (by wrapping make_sem_seg_labels.edges_for,
+    which both label steps call), so that the oracle can be run on exactly the inputs the HIP path saw — a second
+    forward of the backbone need not be bit-identical (MIOpen picks solvers by timing)."""
+
+    def __init__(self, module):
+        self.module, self.orig, self.edges, self.dps = module, module.edges_for, {}, {}
+
+    def __enter__(self):
+        def wrapped(model, pend, irn_batch):
+            self.orig(model, pend, irn_batch)
+            for p in pend:
+                self.edges[p["name"]] = p["edge"][0].cpu().numpy()
+                self.dps[p["name"]] = p["dp"].cpu().numpy()
+        self.module.edges_for = wrapped
+        return self
+
+    def __exit__(self, *exc):
+        self.module.edges_for = self.orig
 
 
 def test_steps_end_to_end(tmp_path):
@@ -99,9 +100,10 @@ def test_steps_end_to_end(tmp_path):
 
     from irn_amd.step import _common
     hits0, misses0 = _common.CAM_STORE.hits, _common.CAM_STORE.misses
-    make_sem_seg_labels.run(args)
+    with _CaptureEdges(make_sem_seg_labels) as cap:
+        make_sem_seg_labels.run(args)
+    edges = cap.edges
     assert _common.CAM_STORE.hits - hits0 == len(names) and _common.CAM_STORE.misses == misses0   # CAMs came from device memory
-    edges, dps = _edges_like_the_step(args, root, names, chunk=3)
     from oracle import build_oracle, irn_oracle as O
     olib = build_oracle.load()
     for n in names:
@@ -114,7 +116,7 @@ def test_steps_end_to_end(tmp_path):
         d = np.load(os.path.join(args.cam_out_dir, n + ".npy"), allow_pickle=True).item()
         rw = build_oracle.walk(olib, d["cam"].numpy(), edges[n], 5, 10, 256)
         _, want, _ = O.sem_seg_epilogue(rw, (H, W), d["keys"].numpy(), 0.25)
-        assert (png != want).mean() <= 1e-3, (n, (png != want).mean())
+        assert (png != want).mean() <= 2e-4, (n, (png != want).mean())
 
     # the same step reading the CAM files (no device hand-off) and with the walk radius of BASELINE configs[2]
     file_args = argparse.Namespace(**{**vars(args), "sem_seg_out_dir": str(tmp_path / "sem_files")})
@@ -128,16 +130,18 @@ def test_steps_end_to_end(tmp_path):
         assert np.array_equal(a, b), n
     r10_args = argparse.Namespace(**{**vars(args), "sem_seg_out_dir": str(tmp_path / "sem_r10"), "radius": 10})
     os.makedirs(r10_args.sem_seg_out_dir)
-    make_sem_seg_labels.run(r10_args)
+    with _CaptureEdges(make_sem_seg_labels) as cap10:
+        make_sem_seg_labels.run(r10_args)
     n = names[0]
     W, H = Image.open(root / "JPEGImages" / (n + ".jpg")).size
     d = np.load(os.path.join(args.cam_out_dir, n + ".npy"), allow_pickle=True).item()
-    rw = build_oracle.walk(olib, d["cam"].numpy(), edges[n], 10, 10, 256)
+    rw = build_oracle.walk(olib, d["cam"].numpy(), cap10.edges[n], 10, 10, 256)
     _, want, _ = O.sem_seg_epilogue(rw, (H, W), d["keys"].numpy(), 0.25)
     png = np.asarray(Image.open(os.path.join(r10_args.sem_seg_out_dir, n + ".png")))
-    assert (png != want).mean() <= 1e-3
+    assert (png != want).mean() <= 2e-4
 
-    make_ins_seg_labels.run(args)
+    with _CaptureEdges(make_sem_seg_labels) as capi:
+        make_ins_seg_labels.run(args)
     written = [n for n in names if os.path.exists(os.path.join(args.ins_seg_out_dir, n + ".npy"))]
     assert written, "no instance file written"
     for n in written:
@@ -151,11 +155,15 @@ def test_steps_end_to_end(tmp_path):
         # VALUES: the oracle's instance pipeline (step/make_ins_seg_labels.py:131-150) on the same edge / dp / CAM
         cd = np.load(os.path.join(args.cam_out_dir, n + ".npy"), allow_pickle=True).item()
         walk = lambda x, e, radius, beta, exp_times: build_oracle.walk(olib, x, e, radius, beta, 2 ** exp_times)
-        _, _, _, _, want = O.instance_labels(cd["cam"].numpy(), cd["keys"].numpy(), edges[n], dps[n], (H, W), walk=walk)
-        assert len(want["score"]) == len(d["score"]), n
-        assert np.array_equal(np.asarray(want["class"]), d["class"]), n
-        assert (want["mask"].astype(bool) != d["mask"]).mean() <= 1e-3, n
-        assert np.abs(np.asarray(want["score"], np.float32) - d["score"]).max() <= 1e-3, n
+        _, _, _, _, want = O.instance_labels(cd["cam"].numpy(), cd["keys"].numpy(), capi.edges[n], capi.dps[n], (H, W), walk=walk)
+        # the class-id map the detections paint (masks are disjoint): identical up to argmax ties between the fp32 walk and
+        # the fp64 oracle; when no tie moved a fragment, detections agree one by one
+        paint = lambda det: (np.asarray(det["mask"]).astype(np.int64) * (np.asarray(det["class"], np.int64) + 1)[:, None, None]).sum(0)
+        assert (paint(want) != paint(d)).mean() <= 2e-4, n
+        if len(want["score"]) == len(d["score"]):
+            assert np.array_equal(np.asarray(want["class"]), d["class"]), n
+            assert (np.asarray(want["mask"]).astype(bool) != d["mask"]).mean() <= 2e-4, n
+            assert np.abs(np.asarray(want["score"], np.float32) - d["score"]).max() <= 1e-3, n
 
 
 def test_cam_merge_kernel_vs_oracle_and_reference_golden(golden):

@@ -48,6 +48,31 @@ pmc)
   cd $R
   python tools/reduce_prof.py $OUT > $OUT/prof_summary.txt 2>&1; grep -E "resident_k|affinity_k" $OUT/prof_summary.txt | cut -c1-24,96-200 | head -12
   find $OUT -name "walk_kernel_trace.csv" -delete; find $OUT -name "walk_counter_collection.csv" -delete ;;
+ins)
+  for r in 5 10; do timeout 200 python tools/ins_step_breakdown.py $r 64 5 > $OUT/ins_breakdown_r$r.txt 2>&1; cat $OUT/ins_breakdown_r$r.txt | grep -v Warning; done
+  timeout 300 python tools/ins_step_bench.py 64 > $OUT/ins_step_bench.txt 2>&1; grep walk_batch $OUT/ins_step_bench.txt ;;
+sweep)
+  for d in 6 8 12 14; do
+    timeout 200 python bench.py --steps 5 --warmup 2 --no-legs --no-cpu-baseline --walk-option poll_delay=$d --json-out $OUT/sweep_pd$d.json > /dev/null 2>&1
+    python -c "import json; r=json.load(open('$OUT/sweep_pd$d.json')); print('poll_delay $d: %.1f img/s launch %.3f ms' % (r['value'], r['roofline']['avg_launch_ms']))"
+  done
+  for d in 1 3 4; do
+    timeout 200 python bench.py --workload walk_r5 --steps 5 --warmup 2 --no-legs --no-cpu-baseline --walk-option poll_delay_plain=$d --json-out $OUT/sweep_r5_pdp$d.json > /dev/null 2>&1
+    python -c "import json; r=json.load(open('$OUT/sweep_r5_pdp$d.json')); print('r5 poll_delay_plain $d: %.1f img/s launch %.3f ms' % (r['value'], r['roofline']['avg_launch_ms']))"
+  done ;;
+abalt)
+  for lib in libirn_hip.so libirn_hip_alt.so; do
+    for wl in walk_r5 ins; do
+      IRN_HIP_LIB=$PWD/irn_amd/lib/$lib timeout 300 python bench.py --workload $wl --steps 6 --warmup 2 --no-legs --no-cpu-baseline \
+         --json-out $OUT/abalt_${wl}_${lib%.so}.json > $OUT/abalt_${wl}_${lib%.so}.log 2>&1
+      python -c "import json; r=json.load(open('$OUT/abalt_${wl}_${lib%.so}.json')); print('$lib $wl: %.1f img/s, %.3f ms/step' % (r['value'], r['ms_per_step']))" || tail -3 $OUT/abalt_${wl}_${lib%.so}.log
+    done
+  done ;;
+stepsleg)
+  for nw in 0 4; do
+    timeout 600 python bench.py --workload steps --steps 1 --warmup 1 --batch 32 --loader-workers $nw --json-out $OUT/steps_w$nw.json > $OUT/steps_w$nw.log 2>&1
+    python -c "import json; r=json.load(open('$OUT/steps_w$nw.json')); print('steps workers $nw: %.1f img/s' % r['value'], r['config'].get('last_pass_seconds'))" || tail -5 $OUT/steps_w$nw.log
+  done ;;
 legs)
   timeout 900 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --json-out $OUT/bench_legs.json > $OUT/bench_legs.log 2>&1; tail -c 4000 $OUT/bench_legs.log ;;
 esac
