@@ -62,7 +62,7 @@ struct RCfg<10> {
 template <>
 struct RCfg<5> {
     static constexpr int Q = 2, SL_Y = 2, SL_X = 2;
-    static constexpr bool PREFETCH_ROWS = false;
+    static constexpr bool PREFETCH_ROWS = true;     // fits since the fp32 chains freed the fp64 accumulators (250 VGPRs)
 };
 
 // The neighbour disc (dy,dx) != (0,0), dx^2 + dy^2 < R^2, in raster order: the union of the
@@ -545,6 +545,15 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 if (!polled) {
                     if (!fresh) nap(job_delay);
                     issue(src, c * ch_bytes);
+                }
+                if (timeout_ticks < 0 && k > 0) {       // test hook (option inject_timeout): give up at the first hand-off
+                    if (lane == 0 && atomicCAS(err, 0u, 1u) == 0u) {
+                        err[1] = (unsigned)je.x;
+                        err[2] = (unsigned)t;
+                        err[3] = blockIdx.x;
+                    }
+                    *abort_flag = 1;
+                    pend = 0;
                 }
                 long long t_start = 0;
                 for (;;) {

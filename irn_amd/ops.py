@@ -299,12 +299,14 @@ def detect_instance(rw_up, argmax, class_ids, n_channels, max_fragment_size=0):
     return {"score": score, "mask": mask, "class": class_ids[chan]}
 
 
-def detect_instance_batch(rw_ups, argmaxes, class_ids, n_channels, max_fragment_sizes):
+def detect_instance_batch(rw_ups, argmaxes, class_ids, n_channels, max_fragment_sizes, timings=None):
     """detect_instance for a batch of images with two host round trips in total (the per-image form has three per
     image): one 4-byte-per-image transfer of the detection counts, one packed transfer of every image's
     {score, channel, masks} (irn_detect_instance_batch_count / _emit).  Arguments are lists (one entry per image) of
     what `detect_instance` takes.  Returns a list with, per image, the reference's numpy dict or — for an image without
     any foreground pixel — the ValueError `detect_instance` would raise."""
+    import time
+    t_start = time.perf_counter()
     n = len(rw_ups)
     dev = rw_ups[0].device
     scs, ams, hs, ws = [], [], [], []
@@ -325,6 +327,7 @@ def detect_instance_batch(rw_ups, argmaxes, class_ids, n_channels, max_fragment_
         check(lib.irn_detect_instance_batch_count(n, sc_p, am_p, cs_a, hs_a, ws_a, n_det_dev.data_ptr(),
                                                   scratch.data_ptr(), _stream()))
         nds = [int(v) for v in n_det_dev.cpu().tolist()]                       # host round trip 1
+        t_count = time.perf_counter()
         # packed output: per image [score fp32 x nd | channel int32 x nd | pad to 16 | masks uint8 nd x h x w | pad to 16]
         offs, total = [], 0
         for i in range(n):
@@ -345,6 +348,7 @@ def detect_instance_batch(rw_ups, argmaxes, class_ids, n_channels, max_fragment_
         host = _cached("det_host_b", "pinned", total, torch.uint8)
         host[:total].copy_(packed[shift:shift + total], non_blocking=True)
         torch.cuda.current_stream().synchronize()                              # host round trip 2
+    t_emit = time.perf_counter()
     raw = host.numpy()
 
     def unpack(i):
@@ -359,7 +363,13 @@ def detect_instance_batch(rw_ups, argmaxes, class_ids, n_channels, max_fragment_
 
     # the staging buffer is reused by the next batch, so every image's masks (1-3 MB) are copied out of it: on a few
     # host threads (numpy releases the GIL for the copy), or this memcpy is as long as the GPU work of the batch
-    return list(_copy_pool().map(unpack, range(n)))
+    out = list(_copy_pool().map(unpack, range(n)))
+    if timings is not None:          # seconds: labelling + count transfer, emit + packed transfer, host-side unpacking
+        timings["count"] = timings.get("count", 0.0) + t_count - t_start
+        timings["emit_d2h"] = timings.get("emit_d2h", 0.0) + t_emit - t_count
+        timings["unpack"] = timings.get("unpack", 0.0) + time.perf_counter() - t_emit
+        timings["bytes"] = timings.get("bytes", 0) + total
+    return out
 
 
 _CACHE = {}

@@ -100,6 +100,33 @@ def walk_radius(args, default):
     return int(getattr(args, "radius", 0) or default)
 
 
+def make_loader(databin, num_workers, prefetch=4):
+    """Items of `databin` in order, each collated like `DataLoader(databin, batch_size=1, shuffle=False)` collates it
+    (what the reference's steps iterate over, step/make_cam.py:22).  The reference's loader workers are processes; here
+    they are THREADS: the work of an item is JPEG decoding (and, with device_preprocess off, PIL resizes), which runs
+    inside Pillow with the GIL released, while forking worker processes from a process that holds a HIP context costs
+    2-3 s per loader on the GPU box (the parent's address space is large) — more than a 1 000-image shard takes."""
+    from torch.utils.data import default_collate
+    n = len(databin)
+    if num_workers <= 0:
+        for i in range(n):
+            yield default_collate([databin[i]])
+        return
+    from collections import deque
+    pool = ThreadPoolExecutor(max_workers=num_workers)
+    pending = deque()
+    try:
+        nxt = 0
+        depth = num_workers * prefetch
+        while nxt < n or pending:
+            while nxt < n and len(pending) < depth:
+                pending.append(pool.submit(lambda i=nxt: default_collate([databin[i]])))
+                nxt += 1
+            yield pending.popleft().result()
+    finally:
+        pool.shutdown(wait=False, cancel_futures=True)
+
+
 def progress(process_id, n_workers, it, n_items):
     """The reference prints 5 % ticks from the last rank and divides by len//20 (ZeroDivision for
     shards under 20 images, step/make_cam.py:58); guarded here."""

@@ -18,7 +18,6 @@ import warnings
 import numpy as np
 import torch
 import torch.nn.functional as F
-from torch.utils.data import DataLoader
 
 from ..misc import imutils, torchutils
 from ..voc12 import dataloader as voc12_dataloader
@@ -76,7 +75,7 @@ def _flush_group(model, group, scales, args, writer, store):
 def _work(process_id, model, dataset, args):
     databin = dataset[process_id]
     n_gpus = len(dataset)
-    loader = DataLoader(databin, shuffle=False, num_workers=int(args.num_workers) // n_gpus, pin_memory=False)
+    loader = _common.make_loader(databin, int(args.num_workers) // n_gpus)
     writer = _common.AsyncWriter()
     scales = tuple(float(s) for s in args.cam_scales)
     # images per trunk pass (the reference runs batch 2 = one image + flip, step/make_cam.py:32-33); images of one size

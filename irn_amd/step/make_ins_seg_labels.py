@@ -15,7 +15,6 @@ import warnings
 
 import numpy as np
 import torch
-from torch.utils.data import DataLoader
 
 from .. import ops
 from ..misc import indexing, torchutils
@@ -76,7 +75,7 @@ def _flush(model, walker, pend, args, writer):
 def _work(process_id, model, dataset, args):
     databin = dataset[process_id]
     n_gpus = len(dataset)
-    loader = DataLoader(databin, shuffle=False, num_workers=int(args.num_workers) // n_gpus, pin_memory=False)
+    loader = _common.make_loader(databin, int(args.num_workers) // n_gpus)
     batch = int(getattr(args, "walk_batch", 0) or 32)   # images per walk launch (results per image unchanged)
     writer = _common.AsyncWriter()
     try:

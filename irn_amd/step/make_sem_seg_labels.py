@@ -16,7 +16,6 @@ import os
 import numpy as np
 import torch
 from PIL import Image
-from torch.utils.data import DataLoader
 
 from .. import ops
 from ..misc import indexing, torchutils
@@ -58,7 +57,7 @@ def _flush(model, walker, pend, args, writer):
 def _work(process_id, model, dataset, args):
     databin = dataset[process_id]
     n_gpus = len(dataset)
-    loader = DataLoader(databin, shuffle=False, num_workers=int(args.num_workers) // n_gpus, pin_memory=False)
+    loader = _common.make_loader(databin, int(args.num_workers) // n_gpus)
     batch = int(getattr(args, "walk_batch", 0) or 64)   # 64 VOC-size images = 3-4 rounds of the resident walk
     writer = _common.AsyncWriter()
     try:

@@ -237,3 +237,35 @@ def test_backbones_at_512_match_reference(golden):
         edge, dp = irn(torch.from_numpy(synth.image_pair(h, w, seed)))
         assert np.abs(edge.numpy() - g["irn_edge"]).max() <= 1e-4
         assert np.abs(dp.numpy() - g["irn_dp"]).max() <= 1e-4 * max(1.0, np.abs(g["irn_dp"]).max())
+
+
+def test_thread_loader_collates_like_dataloader(tmp_path):
+    """irn_amd.step._common.make_loader (thread prefetcher) yields exactly what DataLoader(batch_size=1, shuffle=False)
+    yields for the multi-scale dataset, raw and pre-scaled items, with and without worker threads."""
+    from PIL import Image
+    from torch.utils.data import DataLoader
+    from irn_amd.step import _common
+    from irn_amd.voc12 import dataloader as vd
+    (tmp_path / "JPEGImages").mkdir()
+    names, labels = [], {}
+    rng = np.random.RandomState(0)
+    for i in range(5):
+        n = "2008_%06d" % (i + 1)
+        names.append(n)
+        Image.fromarray((rng.rand(40 + i, 50, 3) * 255).astype(np.uint8)).save(tmp_path / "JPEGImages" / (n + ".jpg"))
+        labels[int(n.replace("_", ""))] = np.eye(20, dtype=np.float32)[i]
+    (tmp_path / "train.txt").write_text("\n".join(names) + "\n")
+    np.save(tmp_path / "cls_labels.npy", labels)
+    for raw in (True, False):
+        ds = vd.VOC12ClassificationDatasetMSF(str(tmp_path / "train.txt"), voc12_root=str(tmp_path), scales=(1.0, 0.5), raw=raw)
+        want = list(DataLoader(ds, shuffle=False, num_workers=0))
+        for nw in (0, 3):
+            got = list(_common.make_loader(ds, nw))
+            assert len(got) == len(want)
+            for x, y in zip(want, got):
+                assert x["name"] == y["name"] and torch.equal(x["label"], y["label"])
+                assert [int(v) for v in x["size"]] == [int(v) for v in y["size"]]
+                if raw:
+                    assert torch.equal(x["img"], y["img"])
+                else:
+                    assert all(torch.equal(p, q) for p, q in zip(x["img"], y["img"]))

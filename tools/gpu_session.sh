@@ -73,6 +73,9 @@ stepsleg)
     timeout 600 python bench.py --workload steps --steps 1 --warmup 1 --batch 32 --loader-workers $nw --json-out $OUT/steps_w$nw.json > $OUT/steps_w$nw.log 2>&1
     python -c "import json; r=json.load(open('$OUT/steps_w$nw.json')); print('steps workers $nw: %.1f img/s' % r['value'], r['config'].get('last_pass_seconds'))" || tail -5 $OUT/steps_w$nw.log
   done ;;
+profile)
+  for c in 1 2 3 4; do timeout 100 python tools/resident_profile.py 10 4 $c 2>&1 | grep "wg 0"; done
+  for c in 1 2 3; do timeout 100 python tools/resident_profile.py 5 16 $c 2>&1 | grep "wg 0"; done ;;
 legs)
   timeout 900 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --json-out $OUT/bench_legs.json > $OUT/bench_legs.log 2>&1; tail -c 4000 $OUT/bench_legs.log ;;
 esac

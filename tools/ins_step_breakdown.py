@@ -27,6 +27,7 @@ for i in range(N):
                   "keys": torch.from_numpy(synth.voc_keys(k, 1000 + i)), "size": (512, 512)})
 walker = indexing.RandomWalk(radius, dev)
 acc = {}
+det_t = {}
 
 
 def tick(name, t0):
@@ -38,6 +39,7 @@ def tick(name, t0):
 for rep in range(reps + 1):
     if rep == 1:
         acc.clear()
+        det_t.clear()
     t = time.perf_counter()
     dps = [it["dp"] for it in items]
     cens = ops.find_centroids_batch(dps)
@@ -51,7 +53,7 @@ for rep in range(reps + 1):
     t = tick("epilogue (argmax + rw_up)", t)
     n_ch = [it["cam"].shape[0] * k for it, k in zip(items, ks)]
     cids = [np.repeat(it["keys"].numpy(), k) for it, k in zip(items, ks)]
-    dets = ops.detect_instance_batch(ep["rw_up"], ep["argmax"], cids, n_ch, [512 * 512 * 0.01] * N)
+    dets = ops.detect_instance_batch(ep["rw_up"], ep["argmax"], cids, n_ch, [512 * 512 * 0.01] * N, timings=det_t)
     t = tick("detect (count, emit, D2H, unpack)", t)
 tot = sum(acc.values())
 nd = sum(0 if isinstance(d, Exception) else len(d["score"]) for d in dets)
@@ -59,3 +61,6 @@ print("radius %d, batch %d: %.1f images/s; %.1f channels and %.1f detections per
       (radius, N, reps * N / tot, float(np.mean(n_ch)), nd / float(N)))
 for k, v in acc.items():
     print("  %-36s %7.3f ms per image  (%4.1f %%)" % (k, 1e3 * v / (reps * N), 100 * v / tot))
+print("  detect split: labelling + counts %.3f, emit + transfer %.3f (%.1f MB per image), host unpack %.3f ms per image" %
+      (1e3 * det_t["count"] / (reps * N), 1e3 * det_t["emit_d2h"] / (reps * N), det_t["bytes"] / (reps * N) / 1e6,
+       1e3 * det_t["unpack"] / (reps * N)))
