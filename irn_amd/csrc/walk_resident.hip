@@ -47,7 +47,6 @@ typedef unsigned long long u64;
 typedef const double IRN_GLOBAL *gcd_t;
 typedef float IRN_GLOBAL *gf_t;
 typedef float f4a __attribute__((ext_vector_type(4)));
-typedef float f2a __attribute__((ext_vector_type(2)));
 
 constexpr int kSlabH = 8, kSlabW = 32;     // 64 lanes x 4 px
 constexpr int kWaves = 8;                  // 512 threads
@@ -218,34 +217,24 @@ struct RowInfo {
 
 constexpr int kMaxWin = 7;   // a full radius-10 row spans 22 floats = 7 aligned float4 slots
 
-// The state window of a neighbour row: floats c_lo .. c_lo + 4*N4 - 1 relative to the lane's first pixel, of which
-// dx_lo .. dx_hi + 3 are used.  Interior slots are 16-byte LDS reads; the two end slots read only what is used (a
-// full row over-reads 6 of 28 floats with 16-byte reads throughout: the arithmetic phase is paced by LDS bytes,
-// DESIGN.md §4 lesson 7).  Everything is compile-time, so `w` stays in registers.
+// The state window of a neighbour row: floats c_lo .. c_lo + 4*N4 - 1 relative to the lane's first pixel (16-byte
+// aligned), of which dx_lo .. dx_hi + 3 are used; N4 aligned 16-byte LDS reads.  Reading only the used floats of the two
+// end slots (4- and 8-byte reads; a full row over-reads 6 of 28 floats) was measured and is SLOWER (radius 10: +1.2 %
+// launch time, COCO shape +1.4 %): with 4 pixels per lane a 4-byte read of a wave touches every fourth bank only, the four
+// tile rows of a 32-lane group collide 4-way (8 LDS cycles against 4 for the conflict-free 16-byte read), and the LDS row
+// stride that makes the 16-byte reads conflict-free cannot do the same for narrower ones.
 template <int R, int QI, int DY>
 __device__ __forceinline__ void load_window(float (&w)[kMaxWin * 4], const float *xrow) {
     using RW = RowInfo<R, QI, DY>;
     static_assert(RW::N4 <= kMaxWin, "window");
     const float *row = xrow + DY * Geom<R>::LW + RW::c_lo;
-    constexpr int first = kDisc<R>.dx[RW::lo] - RW::c_lo;            // first used float of the window
-    constexpr int last = kDisc<R>.dx[RW::hi] + 3 - RW::c_lo;         // last used float
     static_for<RW::N4>([&](auto ik) __attribute__((always_inline)) {
         constexpr int k = decltype(ik)::value;
-        constexpr int lo = first > 4 * k ? first - 4 * k : 0;         // used range inside slot k
-        constexpr int hi = last < 4 * k + 3 ? last - 4 * k : 3;
-        if constexpr (lo == hi) {
-            w[4 * k + lo] = row[4 * k + lo];
-        } else if constexpr ((lo == 2 && hi == 3) || (lo == 0 && hi == 1)) {
-            const f2a v = *reinterpret_cast<const f2a *>(row + 4 * k + lo);
-            w[4 * k + lo] = v.x;
-            w[4 * k + lo + 1] = v.y;
-        } else {
-            const f4a v = *reinterpret_cast<const f4a *>(row + 4 * k);
-            w[4 * k] = v.x;
-            w[4 * k + 1] = v.y;
-            w[4 * k + 2] = v.z;
-            w[4 * k + 3] = v.w;
-        }
+        const f4a v = *reinterpret_cast<const f4a *>(row + 4 * k);
+        w[4 * k] = v.x;
+        w[4 * k + 1] = v.y;
+        w[4 * k + 2] = v.z;
+        w[4 * k + 3] = v.w;
     });
 }
 
@@ -656,11 +645,21 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     const int py = (s2 / G::C::SL_X) * kSlabH + prow;
                     const int px = (s2 % G::C::SL_X) * kSlabW + x;
                     const float *pr = partf + (k & 1) * (kWaves * 256) + (s2 * Q) * 256 + (prow * 8 + (x >> 2)) * 4 + (x & 3);
-                    double sum = (double)xsb[(py + H) * LW + px + HP];
+                    // the Q fp32 chains of the pixel: pairwise in fp32 (as close to the exact operator as adding them in
+                    // fp64: the model of tests/test_precision_model.py gives the same 1.5e-6 after 256 sweeps), then centre
+                    // term and normalisation in fp64.  A chain of Q dependent fp64 conversions + additions was most of the
+                    // combine's latency.
+                    float ps[Q];
 #pragma unroll
-                    for (int q = 0; q < Q; ++q) sum += (double)pr[q * 256];
+                    for (int q = 0; q < Q; ++q) ps[q] = pr[q * 256];
+#pragma unroll
+                    for (int span = 1; span < Q; span *= 2)
+#pragma unroll
+                        for (int q = 0; q + span < Q; q += 2 * span) ps[q] = ps[q] + ps[q + span];
+                    const double sum = (double)xsb[(py + H) * LW + px + HP] + (double)ps[0];
                     const float res = (float)(sum * invd[i]);
-                    const float other = __shfl_xor(res, 1);
+                    // neighbour lane's result through a DPP quad permute (lanes 2n <-> 2n+1) instead of an LDS round trip
+                    const float other = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(res), 0xB1, 0xF, 0xF, true));
                     const int yy = ty0 + py, xx = tx0 + px;
                     if (yy < h && xx < w) {
                         const unsigned o = (unsigned)(yy * w + xx);
@@ -689,12 +688,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                             const int px = (s2 % G::C::SL_X) * kSlabW + x;
                             const float *pr = partf + (k & 1) * (kWaves * 256) + (s2 * Q) * 256 + (prow * 8 + (x >> 2)) * 4 + (x & 3);
                             const float *xc = xsb + (py + H) * LW + px + HP;
-                            double sum0 = (double)xc[0], sum1 = (double)xc[1];
+                            float ps0 = pr[0], ps1 = pr[1];
 #pragma unroll
-                            for (int q = 0; q < Q; ++q) {
-                                sum0 += (double)pr[q * 256];
-                                sum1 += (double)pr[q * 256 + 1];
+                            for (int q = 1; q < Q; ++q) {
+                                ps0 += pr[q * 256];
+                                ps1 += pr[q * 256 + 1];
                             }
+                            const double sum0 = (double)xc[0] + (double)ps0, sum1 = (double)xc[1] + (double)ps1;
                             const int ii = s2 * 256 + prow * 32 + x;
                             r0v[it] = (float)(sum0 * invd[ii]);
                             r1v[it] = (float)(sum1 * invd[ii + 1]);

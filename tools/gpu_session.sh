@@ -19,7 +19,7 @@ bench)
   timeout 600 python bench.py --steps 10 --warmup 3 --json-out $OUT/bench_default.json > $OUT/bench_default.log 2>&1; echo "bench rc=$?"
   tail -c 6000 $OUT/bench_default.log ;;
 ab)
-  for lib in libirn_hip.so libirn_hip_prev.so; do
+  for lib in ${AB_LIBS:-libirn_hip.so libirn_hip_prev.so}; do
     [ -f irn_amd/lib/$lib ] || continue
     for wl in walk coco walk_r5; do
       IRN_HIP_LIB=$PWD/irn_amd/lib/$lib timeout 300 python bench.py --workload $wl --steps 6 --warmup 2 --no-legs --no-cpu-baseline \
