@@ -87,7 +87,11 @@ template <int R>
 struct Geom {
     using C = RCfg<R>;
     static constexpr int H = R - 1;
-    static constexpr int HP = (H + 3) / 4 * 4;          // LDS column of tile column 0 (16-byte aligned windows)
+    // LDS column of tile column 0.  Windows are read in 16-byte slots aligned in LDS, i.e. starting at offsets c with
+    // (HP + c) % 4 == 0 from the lane's first pixel.  HP = H puts a slot boundary exactly at the leftmost neighbour of a full
+    // disc row (dx = -H): such a row then needs 6 slots instead of 7 (radius 10: 9 of the 19 rows), which is 8 fewer live
+    // VGPRs for the two windows in flight and 6 % fewer LDS reads.
+    static constexpr int HP = H;
     static constexpr int TH = kSlabH * C::SL_Y, TW = kSlabW * C::SL_X;
     // LDS row stride = 32 banks (mod 64): the 16-lane groups of a ds_read_b128 ({0-3,12-15,20-27}, ...)
     // span four tile rows; with this stride their 16-byte chunks fall on distinct banks
@@ -126,7 +130,8 @@ constexpr int row_hi(int dy) {
         if (kDisc<R>.dy[s] == dy) return s;
     return -1;
 }
-constexpr int floor4(int v) { return v >= 0 ? v / 4 * 4 : -((-v + 3) / 4 * 4); }
+// largest c <= v with (c + hp) % 4 == 0: the 16-byte-aligned slot boundary at or left of neighbour offset v
+constexpr int slot_floor(int v, int hp) { return v - (((v + hp) % 4 + 4) % 4); }
 
 // ---- per-job: weights of this lane's 4 pixels for the wave's part of the disc -> registers ----
 template <int R, int QI>
@@ -211,11 +216,11 @@ inline constexpr RowList<R, QI, HALF> kRowList{};
 template <int R, int QI, int DY>
 struct RowInfo {
     static constexpr int lo = row_lo<R, QI>(DY), hi = row_hi<R, QI>(DY);
-    static constexpr int c_lo = floor4(kDisc<R>.dx[lo]), c_hi = kDisc<R>.dx[hi] + 3;
+    static constexpr int c_lo = slot_floor(kDisc<R>.dx[lo], Geom<R>::HP), c_hi = kDisc<R>.dx[hi] + 3;
     static constexpr int N4 = (c_hi - c_lo) / 4 + 1;          // aligned 16-byte reads of the state window
 };
 
-constexpr int kMaxWin = 7;   // a full radius-10 row spans 22 floats = 7 aligned float4 slots
+constexpr int kMaxWin = 6;   // a full radius-10 row spans 22 floats = 6 aligned float4 slots (see Geom::HP)
 
 // The state window of a neighbour row: floats c_lo .. c_lo + 4*N4 - 1 relative to the lane's first pixel (16-byte
 // aligned), of which dx_lo .. dx_hi + 3 are used; N4 aligned 16-byte LDS reads.  Reading only the used floats of the two
