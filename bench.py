@@ -65,7 +65,9 @@ def parse(argv=None):
                     help="extra irn_walk_set_option settings (tuning experiments), e.g. poll_delay=8")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-legs", action="store_true", help="skip the short secondary runs (cam, e2e, steps, walk_r5, ins, coco)")
-    ap.add_argument("--legs", default="cam,e2e,steps,walk_r5,ins,ins_r10,coco")
+    ap.add_argument("--legs", default="walk_r5,ins,ins_r10,coco,cam,e2e,steps")
+    ap.add_argument("--legs-budget-s", type=float, default=240.0,
+                    help="stop starting new legs once the legs have used this much wall time (the rest are recorded as skipped)")
     ap.add_argument("--loader-workers", type=int, default=4, help="DataLoader workers of the `steps` workload")
     ap.add_argument("--cpu-images", type=int, default=0, help="images of the CPU port sample (0 = 2 per host thread, at most 256)")
     ap.add_argument("--json-out", default=None)
@@ -339,6 +341,7 @@ def run_steps(a, rank, world, device, dist, parallel, steps, warmup, batch=0):
     from irn_amd.step import _common, make_cam, make_sem_seg_labels
     os.environ.setdefault("MIOPEN_FIND_MODE", "2")
     batch = batch or 32
+    t_setup = time.perf_counter()
     tmp = tempfile.mkdtemp(prefix="irn_steps_%d_" % rank)
     try:
         root = os.path.join(tmp, "voc")
@@ -401,13 +404,14 @@ def run_steps(a, rank, world, device, dist, parallel, steps, warmup, batch=0):
             finally:
                 sys.stdout = real
 
+        t_setup = time.perf_counter() - t_setup
         elapsed, _ = timed_loop(step, steps, warmup, dist, parallel, device)
         n_png = len([f for f in os.listdir(args.sem_seg_out_dir) if f.endswith(".png")])
         if n_png != batch:
             raise RuntimeError("steps leg: %d label maps written for %d images" % (n_png, batch))
         return {"value": steps * batch * world / elapsed, "ms_per_step": 1e3 * elapsed / steps, "batch": batch,
                 "cam_store_hits": _common.CAM_STORE.hits, "loader_workers": args.num_workers,
-                "last_pass_seconds": dict(pass_s)}
+                "last_pass_seconds": dict(pass_s), "setup_seconds": t_setup}
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
 
@@ -536,9 +540,13 @@ def main(argv=None):
             res["cpu_baseline"] = cpu_baseline(a.workload, a.cpu_images, 1000)
         if world == 1 and not a.no_legs and a.workload == "walk":
             legs = {}
+            legs_t0 = time.perf_counter()
             for name in [n for n in a.legs.split(",") if n]:
                 st, wu, b = LEG_RUNS[name]
                 t0 = time.perf_counter()
+                if t0 - legs_t0 > a.legs_budget_s:
+                    legs[name] = {"skipped": "legs budget of %.0f s used up" % a.legs_budget_s}
+                    continue
                 try:
                     lr = run_workload(a, name, rank, world, device, None, parallel, st, wu, b)
                     legs[name] = {"value": lr["value"], "unit": "images/s", "steps": st, "warmup": wu, "batch": lr["batch"],
@@ -546,7 +554,7 @@ def main(argv=None):
                     if "shapes" in lr:
                         ro = roofline_object(a, name, lr)
                         legs[name]["fp32_vector_frac"] = ro["frac"] if ro.get("bound") == "fp32_vector" else ro["fp32_vector"]["frac"]
-                    for k in ("detections_per_image", "cam_store_hits", "loader_workers", "last_pass_seconds"):
+                    for k in ("detections_per_image", "cam_store_hits", "loader_workers", "last_pass_seconds", "setup_seconds"):
                         if k in lr:
                             legs[name][k] = lr[k]
                 except Exception as e:                      # a leg must never cost the headline line
