@@ -303,7 +303,7 @@ def run_backbone(a, workload, rank, world, device, dist, parallel, steps, warmup
     for i in range(batch):
         lab = torch.zeros(20)
         lab[torch.from_numpy(synth.voc_keys(synth.voc_num_classes(i + 7), i + 7))] = 1
-        labels.append(lab.to(device))
+        labels.append(lab)            # host-side, like the loader hands it over: the merge then never waits for the device
     irn = walker = None
     if workload == "e2e":
         irn = resnet50_irn.EdgeDisplacement()

@@ -75,7 +75,7 @@ def cam_merge(outputs, size, label):
     """Multi-scale CAM merge of reference step/make_cam.py:38-52 (irn_cam_merge).
 
     outputs: list of GPU fp32 [n_classes, hs, ws] (one per scale); size = (H, W) of the image;
-    label: [n_classes] multi-hot image-level label.  Returns (keys int64 [K] on the same device,
+    label: [n_classes] multi-hot image-level label (pass it as a HOST tensor to keep the call asynchronous).  Returns (keys int64 [K] on the same device,
     cam fp32 [K, ceil(H/4), ceil(W/4)], high_res fp32 [K, H, W]), each channel divided by its max + 1e-5."""
     for o in outputs:
         _need_cuda(o, "CAM output")
@@ -83,10 +83,14 @@ def cam_merge(outputs, size, label):
     outs = [o.contiguous().float() for o in outputs]
     n_cls = outs[0].shape[0]
     H, W = int(size[0]), int(size[1])
-    keys = torch.nonzero(torch.as_tensor(label).to(dev))[:, 0].to(torch.int64).contiguous()
+    label = torch.as_tensor(label)
+    if label.is_cuda:
+        keys = torch.nonzero(label.to(dev))[:, 0].to(torch.int64).contiguous()          # synchronises (data-dependent size)
+    else:
+        # the loader hands the image-level label over on the host: the present classes are found there and only the
+        # key list travels, so the call never waits for the device (a device-side nonzero needs its result size)
+        keys = torch.nonzero(label)[:, 0].to(torch.int64).contiguous().to(dev, non_blocking=True)
     k = int(keys.numel())
-    if k == 0:
-        raise ValueError("cam_merge: the image-level label has no positive class")
     cam = torch.empty((k, (H - 1) // 4 + 1, (W - 1) // 4 + 1), dtype=torch.float32, device=dev)
     hi = torch.empty((k, H, W), dtype=torch.float32, device=dev)
     scratch = torch.empty(2 * k, dtype=torch.int32, device=dev)

@@ -135,6 +135,31 @@ def progress(process_id, n_workers, it, n_items):
         print("%d " % ((5 * it + 1) // step), end="", flush=True)
 
 
+class PinnedPool:
+    """Page-locked staging buffers for device-to-host copies that must not stall the step: `take(nbytes)` hands out a
+    uint8 buffer (recycled, rounded up to 1 MiB), `give(buf)` returns it.  Thread-safe (writer threads give back)."""
+
+    def __init__(self):
+        import threading
+        self._free = {}
+        self._lock = threading.Lock()
+
+    def take(self, nbytes):
+        size = max(1 << 20, (int(nbytes) + (1 << 20) - 1) >> 20 << 20)
+        with self._lock:
+            bucket = self._free.get(size)
+            if bucket:
+                return bucket.pop()
+        return torch.empty(size, dtype=torch.uint8, pin_memory=True)
+
+    def give(self, buf):
+        with self._lock:
+            self._free.setdefault(buf.numel(), []).append(buf)
+
+
+PINNED = PinnedPool()
+
+
 class AsyncWriter:
     """Output files (4 MB CAM dictionaries, PNG label maps, detection dictionaries) are encoded and
     written by a small thread pool while the GPU works on the next images; at

@@ -56,19 +56,38 @@ def merge_scales_torch(outputs, size, label):
     return valid_cat, strided_cam, highres
 
 
+def _save_cam(path, keys_cpu, event, staging, cam_view, hi_view):
+    """Writer-thread half of a CAM hand-off: wait for the image's device-to-host copies, write the reference's
+    dictionary (step/make_cam.py:55-56), recycle the staging buffer."""
+    event.synchronize()
+    try:
+        np.save(path, {"keys": keys_cpu, "cam": cam_view.clone(), "high_res": hi_view.numpy()})
+    finally:
+        _common.PINNED.give(staging)
+
+
 def _flush_group(model, group, scales, args, writer, store):
     """One trunk pass per scale for all images of a size group ([image, flip, image, flip, ...]), then the per-image
-    merge (irn_cam_merge) and the asynchronous write of the reference's dictionary."""
+    merge (irn_cam_merge) and the asynchronous write of the reference's dictionary.  Nothing here waits for the device:
+    the present classes come from the host-side label, the results leave through page-locked staging on the stream, and
+    the writer threads wait for each image's copy event — so the next group's passes are queued while this one runs."""
     if not group:
         return
     outs = [model.forward_batch(torch.cat([g["imgs"][si] for g in group])) for si in range(len(scales))]
     for i, g in enumerate(group):
+        keys_cpu = torch.nonzero(g["label"])[:, 0]
         keys, cam, high_res = merge_scales([o[i] for o in outs], g["size"], g["label"])
-        keys_cpu = keys.cpu()
         if store is not None:
             store.put(g["name"], keys_cpu, keys, cam)
-        writer.submit(np.save, os.path.join(args.cam_out_dir, g["name"] + ".npy"),
-                      {"keys": keys_cpu, "cam": cam.cpu(), "high_res": high_res.cpu().numpy()})
+        n_cam, n_hi = cam.numel() * 4, high_res.numel() * 4
+        staging = _common.PINNED.take(n_cam + n_hi)
+        cam_view = staging[:n_cam].view(torch.float32).view(cam.shape)
+        hi_view = staging[n_cam:n_cam + n_hi].view(torch.float32).view(high_res.shape)
+        cam_view.copy_(cam, non_blocking=True)
+        hi_view.copy_(high_res, non_blocking=True)
+        event = torch.cuda.Event()
+        event.record()
+        writer.submit(_save_cam, os.path.join(args.cam_out_dir, g["name"] + ".npy"), keys_cpu, event, staging, cam_view, hi_view)
     group.clear()
 
 
@@ -97,7 +116,7 @@ def _work(process_id, model, dataset, args):
                     warnings.warn("%s: no positive class in the image-level label, skipped" % img_name)
                     continue
                 group = groups.setdefault(size, [])
-                group.append({"name": img_name, "size": size, "label": label.cuda(),
+                group.append({"name": img_name, "size": size, "label": label,
                               "imgs": _common.device_images(pack, scales)})
                 if len(group) == batch:
                     _flush_group(model, group, scales, args, writer, store)
