@@ -349,25 +349,24 @@ def detect_instance_batch(rw_ups, argmaxes, class_ids, n_channels, max_fragment_
             ptr_array([base + o[0] if l else None for o, l in zip(offs, live)]),
             ptr_array([base + o[1] if l else None for o, l in zip(offs, live)]),
             ptr_array([base + o[2] if l else None for o, l in zip(offs, live)]), scratch.data_ptr(), _stream()))
-        host = _cached("det_host_b", "pinned", total, torch.uint8)
-        host[:total].copy_(packed[shift:shift + total], non_blocking=True)
+        # a page-locked buffer of its own for every batch: the detections are handed out as VIEWS of it (no second copy of
+        # 2 MB of masks per image) and it goes back to torch's caching host allocator when the last of them is dropped
+        host = torch.empty(total, dtype=torch.uint8, pin_memory=True)
+        host.copy_(packed[shift:shift + total], non_blocking=True)
         torch.cuda.current_stream().synchronize()                              # host round trip 2
     t_emit = time.perf_counter()
     raw = host.numpy()
-
-    def unpack(i):
+    out = []
+    for i in range(n):
         nd = nds[i]
         if nd == 0:
-            return ValueError("detect_instance: no foreground pixel in any channel")
+            out.append(ValueError("detect_instance: no foreground pixel in any channel"))
+            continue
         o_sc, o_ch, o_mk = offs[i]
-        score = raw[o_sc:o_sc + 4 * nd].view(np.float32).copy()
+        score = raw[o_sc:o_sc + 4 * nd].view(np.float32)
         chan = raw[o_ch:o_ch + 4 * nd].view(np.int32)
-        mask = raw[o_mk:o_mk + nd * hs[i] * ws[i]].view(np.bool_).reshape(nd, hs[i], ws[i]).copy()
-        return {"score": score, "mask": mask, "class": np.asarray(class_ids[i])[chan]}
-
-    # the staging buffer is reused by the next batch, so every image's masks (1-3 MB) are copied out of it: on a few
-    # host threads (numpy releases the GIL for the copy), or this memcpy is as long as the GPU work of the batch
-    out = list(_copy_pool().map(unpack, range(n)))
+        mask = raw[o_mk:o_mk + nd * hs[i] * ws[i]].view(np.bool_).reshape(nd, hs[i], ws[i])
+        out.append({"score": score, "mask": mask, "class": np.asarray(class_ids[i])[chan]})
     if timings is not None:          # seconds: labelling + count transfer, emit + packed transfer, host-side unpacking
         timings["count"] = timings.get("count", 0.0) + t_count - t_start
         timings["emit_d2h"] = timings.get("emit_d2h", 0.0) + t_emit - t_count
@@ -377,15 +376,6 @@ def detect_instance_batch(rw_ups, argmaxes, class_ids, n_channels, max_fragment_
 
 
 _CACHE = {}
-_POOL = []
-
-
-def _copy_pool():
-    if not _POOL:
-        from concurrent.futures import ThreadPoolExecutor
-        _POOL.append(ThreadPoolExecutor(max_workers=8))
-    return _POOL[0]
-
 
 
 def _cached(tag, dev, nbytes, dtype):

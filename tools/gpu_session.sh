@@ -76,6 +76,12 @@ stepsleg)
 profile)
   for c in 1 2 3 4; do timeout 100 python tools/resident_profile.py 10 4 $c 2>&1 | grep "wg 0"; done
   for c in 1 2 3; do timeout 100 python tools/resident_profile.py 5 16 $c 2>&1 | grep "wg 0"; done ;;
+stepsprof)
+  timeout 600 python -m cProfile -s cumtime bench.py --workload steps --steps 2 --warmup 1 --batch 64 > $OUT/steps_cprofile.txt 2>&1
+  grep -v "MIOpen" $OUT/steps_cprofile.txt | grep -E "^\{|cumtime|_work|_flush|edges_for|forward_batch|make_loader|msf_pack|cam_merge|label_epilogue|synchronize|\.cpu|numpy|save|result|acquire|sleep|__call__|sync" | head -50 ;;
+smoke)
+  python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2
+  timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 1 --steps 5 --warmup 2 --no-legs --no-cpu-baseline 2>&1 | grep -E "^\{" | cut -c1-400 ;;
 legs)
   timeout 900 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --json-out $OUT/bench_legs.json > $OUT/bench_legs.log 2>&1; tail -c 4000 $OUT/bench_legs.log ;;
 esac
