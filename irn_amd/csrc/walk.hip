@@ -555,9 +555,6 @@ extern "C" int irn_walk_set_option(irn_walk_ctx *ctx, const char *name, int valu
     } else if (!strcmp(name, "cooperative")) {
         ctx->res_cooperative = value ? 1 : 0;
         ctx->res_coop_refused = false;
-    } else if (!strcmp(name, "mfma_min_c")) {          // images with >= this many channels use the matrix-pipe walk; 0 = never
-        if (value < 0) return fail(IRN_ERR_ARG, "mfma_min_c must be >= 0");
-        ctx->mfma_min_c = value;
     } else if (!strcmp(name, "inject_timeout")) {      // test hook: the next persistent launch gives up at once
         ctx->res_inject_timeout = value ? 1 : 0;
         return IRN_OK;                                  // no re-configure

@@ -113,10 +113,6 @@ struct irn_walk_ctx {
     bool deg_stale = false;    // last run was resident: the inv_deg array of the workspace was not written
     bool res_ok = false;                   // the configured batch fits the resident kernel
     int res_sweeps_per_launch = 0;         // 0 = all sweeps in one launch; k = relaunch every k sweeps (test hook)
-    // many-channel images run on the matrix-pipe form of the persistent walk (walk_mfma.hip, radius 10)
-    int4 *mfma_jobs_dev = nullptr;         // [mfma_rounds][res_nwg]
-    int mfma_cap_jobs = 0, mfma_rounds = 0;
-    int mfma_min_c = 12;                   // images with at least this many channels go there; 0 = never
     int res_cooperative = 1;               // launch with hipLaunchCooperativeKernel (co-residency of the grid is requested,
                                            // not assumed); falls back to a plain launch when the runtime refuses
     bool res_coop_refused = false;         // the runtime refused a cooperative launch once: plain launches from then on
@@ -134,10 +130,6 @@ namespace irn {
 bool resident_supported(const irn_walk_ctx *ctx);
 int resident_configure(irn_walk_ctx *ctx);
 int resident_run(irn_walk_ctx *ctx, int n_sweeps, hipStream_t stream);
-// walk_mfma.hip: the persistent walk on the fp32 matrix pipe for many-channel images (radius 10)
-bool mfma_supported(const irn_walk_ctx *ctx);
-int mfma_capacity(int n_cu, int *capacity);
-int mfma_launch(irn_walk_ctx *ctx, int t_first, int t_count, int t_total, long long ticks, hipStream_t stream);
 // walk.hip: degree + x0 + n_sweeps streaming sweeps of the configured batch (weights already built)
 int streaming_run(irn_walk_ctx *ctx, int n_sweeps, hipStream_t stream, bool timed);
 void resident_destroy(irn_walk_ctx *ctx);

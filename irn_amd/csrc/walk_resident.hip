@@ -756,9 +756,6 @@ static int resident_capacity(int n_cu, int *capacity);
 
 void resident_destroy(irn_walk_ctx *ctx) {
     if (ctx->res_jobs_dev) (void)hipFree(ctx->res_jobs_dev);
-    if (ctx->mfma_jobs_dev) (void)hipFree(ctx->mfma_jobs_dev);
-    ctx->mfma_jobs_dev = nullptr;
-    ctx->mfma_cap_jobs = 0;
     if (ctx->res_err_dev) (void)hipFree(ctx->res_err_dev);
     if (ctx->res_err_host) (void)hipHostFree(ctx->res_err_host);
     if (ctx->res_prof_dev) (void)hipFree(ctx->res_prof_dev);
@@ -804,56 +801,38 @@ int resident_configure(irn_walk_ctx *ctx) {
         if (ctx->c[a] != ctx->c[b]) return ctx->c[a] > ctx->c[b];
         return tiles[a] > tiles[b];
     });
-    // Images with many channels go to the matrix-pipe form of the kernel (walk_mfma.hip: every weight register feeds four
-    // channels per issue); it needs >= 3 groups of 4 channels per sweep to hide the hand-off, and it has its own launch.
-    const bool use_mfma = mfma_supported(ctx) && ctx->mfma_min_c > 0;
-    auto to_mfma = [&](int i) { return use_mfma && ctx->c[i] >= std::max(ctx->mfma_min_c, 9); };
-    auto pack = [&](bool want_mfma, std::vector<int4> &flat, int *n_rounds) {
-        std::vector<std::vector<int4>> rounds;
-        std::vector<int> used;
-        for (int oi = 0; oi < n; ++oi) {
-            const int i = order[oi];
-            if (to_mfma(i) != want_mfma) continue;
-            size_t r = 0;
-            for (; r < rounds.size(); ++r)
-                if (used[r] + tiles[i] <= n_wg) break;
-            if (r == rounds.size()) {
-                rounds.emplace_back(n_wg, make_int4(-1, 0, 0, 0));
-                used.push_back(0);
+    std::vector<std::vector<int4>> rounds;
+    std::vector<int> used;
+    for (int oi = 0; oi < n; ++oi) {
+        const int i = order[oi];
+        size_t r = 0;
+        for (; r < rounds.size(); ++r)
+            if (used[r] + tiles[i] <= n_wg) break;
+        if (r == rounds.size()) {
+            rounds.emplace_back(n_wg, make_int4(-1, 0, 0, 0));
+            used.push_back(0);
+        }
+        for (int ty = 0; ty < ctx->h[i]; ty += th)
+            for (int tx = 0; tx < ctx->w[i]; tx += tw) {
+                const int slot = used[r]++;
+                // consecutive slots share an XCD: block b is dispatched to XCD b % 8 (observed)
+                const int per = (n_wg + 7) / 8;
+                int b = (slot % per) * 8 + slot / per;
+                if (n_wg % 8 != 0 || b >= n_wg) b = slot;
+                rounds[r][b] = make_int4(i, ty, tx, tiles[i]);
             }
-            for (int ty = 0; ty < ctx->h[i]; ty += th)
-                for (int tx = 0; tx < ctx->w[i]; tx += tw) {
-                    const int slot = used[r]++;
-                    // consecutive slots share an XCD: block b is dispatched to XCD b % 8 (observed)
-                    const int per = (n_wg + 7) / 8;
-                    int b = (slot % per) * 8 + slot / per;
-                    if (n_wg % 8 != 0 || b >= n_wg) b = slot;
-                    rounds[r][b] = make_int4(i, ty, tx, tiles[i]);
-                }
-        }
-        flat.clear();
-        for (auto &r : rounds) flat.insert(flat.end(), r.begin(), r.end());
-        *n_rounds = (int)rounds.size();
-    };
-    std::vector<int4> flat, flat_m;
-    int n_rounds = 0, n_rounds_m = 0;
-    pack(false, flat, &n_rounds);
-    pack(true, flat_m, &n_rounds_m);
-    auto upload = [&](const std::vector<int4> &v, int4 **dev, int *cap) -> int {
-        if (v.empty()) return IRN_OK;
-        if ((int)v.size() > *cap) {
-            if (*dev) (void)hipFree(*dev);
-            *dev = nullptr;
-            IRN_HIP_TRY(hipMalloc((void **)dev, sizeof(int4) * v.size()));
-            *cap = (int)v.size();
-        }
-        IRN_HIP_TRY(hipMemcpy(*dev, v.data(), sizeof(int4) * v.size(), hipMemcpyHostToDevice));
-        return IRN_OK;
-    };
-    int rc_up = upload(flat, &ctx->res_jobs_dev, &ctx->res_cap_jobs);
-    if (rc_up) return rc_up;
-    rc_up = upload(flat_m, &ctx->mfma_jobs_dev, &ctx->mfma_cap_jobs);
-    if (rc_up) return rc_up;
+    }
+    const int total = (int)rounds.size() * n_wg;
+    if (total > ctx->res_cap_jobs) {
+        if (ctx->res_jobs_dev) (void)hipFree(ctx->res_jobs_dev);
+        ctx->res_jobs_dev = nullptr;
+        IRN_HIP_TRY(hipMalloc((void **)&ctx->res_jobs_dev, sizeof(int4) * total));
+        ctx->res_cap_jobs = total;
+    }
+    std::vector<int4> flat;
+    flat.reserve(total);
+    for (auto &r : rounds) flat.insert(flat.end(), r.begin(), r.end());
+    IRN_HIP_TRY(hipMemcpy(ctx->res_jobs_dev, flat.data(), sizeof(int4) * total, hipMemcpyHostToDevice));
     if (ctx->res_votes_cap < n) {
         if (ctx->res_votes_dev) (void)hipFree(ctx->res_votes_dev);
         ctx->res_votes_dev = nullptr;
@@ -864,8 +843,7 @@ int resident_configure(irn_walk_ctx *ctx) {
         IRN_HIP_TRY(hipMalloc((void **)&ctx->res_err_dev, 4 * sizeof(unsigned)));
         IRN_HIP_TRY(hipHostMalloc((void **)&ctx->res_err_host, 4 * sizeof(unsigned), hipHostMallocDefault));
     }
-    ctx->res_rounds = n_rounds;
-    ctx->mfma_rounds = n_rounds_m;
+    ctx->res_rounds = (int)rounds.size();
     ctx->res_max_round_channels = 1;
     for (int i = 0; i < n; ++i) ctx->res_max_round_channels = std::max(ctx->res_max_round_channels, ctx->c[i]);
     // the grid must be co-resident: ask the runtime how many workgroups of this kernel fit (a partitioned device or a
@@ -874,12 +852,6 @@ int resident_configure(irn_walk_ctx *ctx) {
     const int rc_cap = ctx->radius == 10 ? resident_capacity<10, false>(n_wg, &capacity) : resident_capacity<5, false>(n_wg, &capacity);
     if (rc_cap) return rc_cap;
     ctx->res_ok = capacity >= n_wg;
-    if (ctx->res_ok && n_rounds_m > 0) {
-        int cap_m = 0;
-        const int rc_m = mfma_capacity(n_wg, &cap_m);
-        if (rc_m) return rc_m;
-        ctx->res_ok = cap_m >= n_wg;
-    }
     return IRN_OK;
 }
 
@@ -906,13 +878,22 @@ static int resident_capacity(int n_cu, int *capacity) {
 }
 
 template <int R, bool PROF>
-static int launch_resident(irn_walk_ctx *ctx, int t_first, int t_count, int t_total, long long ticks, hipStream_t stream) {
+static int launch_resident(irn_walk_ctx *ctx, int t_first, int t_count, int t_total, hipStream_t stream) {
     using G = Geom<R>;
     int capacity = 0;
     int rc = resident_capacity<R, PROF>(ctx->res_nwg, &capacity);
     if (rc) return rc;
     if (capacity < ctx->res_nwg)
         return fail(IRN_ERR_STATE, "resident walk: only %d of %d workgroups can be resident", capacity, ctx->res_nwg);
+    // Bounded waits: a tile that cannot make progress reports instead of hanging.  The bound covers the slowest legal
+    // wait — a workgroup that has moved on to its next round waits for neighbours still busy with a heavy image of the
+    // previous one — so it grows with the work of the launch (3 us per channel-step is twice the measured rate).
+    long long ticks = 200000000LL;                  // 2 s of the 100 MHz wall clock
+    ticks += 4LL * 300LL * (long long)ctx->res_max_round_channels * (long long)t_count * (long long)std::max(ctx->res_rounds, 1);
+    if (ctx->res_inject_timeout) {                  // test hook: every poll that misses once gives up
+        ticks = -1;
+        ctx->res_inject_timeout = 0;
+    }
     unsigned long long *votes = nullptr;
     if (R == 5 && ctx->res_plain_store) {           // one vote word per image, cleared before every launch
         votes = ctx->res_votes_dev;
@@ -947,26 +928,15 @@ int resident_run(irn_walk_ctx *ctx, int n_sweeps, hipStream_t stream) {
     const int step = ctx->res_sweeps_per_launch > 0 ? ctx->res_sweeps_per_launch : n_sweeps;
     for (int t = 0; t < n_sweeps; t += step) {
         const int cnt = std::min(step, n_sweeps - t);
-        // Bounded waits: a tile that cannot make progress reports instead of hanging.  The bound covers the slowest legal
-        // wait — a workgroup that has moved on to its next round waits for neighbours still busy with a heavy image of
-        // the previous one — so it grows with the work of the launch (3 us per channel-step is twice the measured rate).
-        long long ticks = 200000000LL;                  // 2 s of the 100 MHz wall clock
-        ticks += 4LL * 300LL * (long long)ctx->res_max_round_channels * (long long)cnt *
-                 (long long)std::max(ctx->res_rounds + ctx->mfma_rounds, 1);
-        if (ctx->res_inject_timeout) ticks = -1;        // test hook: the launch gives up at its first hand-off
-        int rc = IRN_OK;
-        if (ctx->res_rounds > 0) {
-            if (ctx->res_prof_dev)
-                rc = ctx->radius == 10 ? launch_resident<10, true>(ctx, t, cnt, n_sweeps, ticks, stream)
-                                       : launch_resident<5, true>(ctx, t, cnt, n_sweeps, ticks, stream);
-            else
-                rc = ctx->radius == 10 ? launch_resident<10, false>(ctx, t, cnt, n_sweeps, ticks, stream)
-                                       : launch_resident<5, false>(ctx, t, cnt, n_sweeps, ticks, stream);
-        }
-        if (!rc && ctx->mfma_rounds > 0) rc = mfma_launch(ctx, t, cnt, n_sweeps, ticks, stream);
+        int rc;
+        if (ctx->res_prof_dev)
+            rc = ctx->radius == 10 ? launch_resident<10, true>(ctx, t, cnt, n_sweeps, stream)
+                                   : launch_resident<5, true>(ctx, t, cnt, n_sweeps, stream);
+        else
+            rc = ctx->radius == 10 ? launch_resident<10, false>(ctx, t, cnt, n_sweeps, stream)
+                                   : launch_resident<5, false>(ctx, t, cnt, n_sweeps, stream);
         if (rc) return rc;
     }
-    ctx->res_inject_timeout = 0;
     IRN_HIP_TRY(hipMemcpyAsync(ctx->res_err_host, ctx->res_err_dev, 4 * sizeof(unsigned), hipMemcpyDeviceToHost, stream));
     return IRN_OK;
 }

@@ -245,56 +245,3 @@ def test_instance_split_48_channels(r):
     assert np.abs(a[sel, 0].cpu().numpy() - st[:, 0]).max() <= TOL_F64
     res.close()
     gen.close()
-
-
-# ------------------------------------------------------------------------------------------------
-# the matrix-pipe form of the persistent walk (walk_mfma.hip): many-channel images
-# ------------------------------------------------------------------------------------------------
-
-@pytest.mark.parametrize("n_sweeps", [1, 2, 3, 7, 40])
-def test_mfma_walk_equals_valu_walk_and_generic_kernel(n_sweeps):
-    """Images with >= 12 channels run on the fp32 matrix pipe (option mfma_min_c, default 12).  A ragged batch whose
-    channel counts straddle the threshold and are not multiples of 4 (partial last group), against the VALU kernel
-    (mfma_min_c = 0) and the fp64 generic kernel; the light images of the batch run on the VALU kernel in the same call."""
-    from irn_amd import synth
-    shapes = [(128, 128, 13), (94, 125, 12), (40, 52, 20), (128, 128, 2), (33, 70, 17), (130, 250, 14), (30, 30, 9), (64, 64, 31)]
-    edges = [torch.from_numpy(synth.edge_field(h, w, seed=3100 + i)).to(_dev()) for i, (h, w, c) in enumerate(shapes)]
-    cams = [torch.from_numpy(synth.cam_blobs(c, h, w, seed=3100 + i)).to(_dev()) for i, (h, w, c) in enumerate(shapes)]
-    mf = _walker(10)
-    a = [o.clone() for o in mf(edges, cams, beta=10, n_sweeps=n_sweeps)]
-    assert mf.sync() is False
-    va = _walker(10, mfma_min_c=0)
-    b = va(edges, cams, beta=10, n_sweeps=n_sweeps)
-    assert va.sync() is False
-    gen = _walker(10, variant=0)
-    c = gen(edges, cams, beta=10, n_sweeps=n_sweeps)
-    for i in range(len(shapes)):
-        assert (a[i] - b[i]).abs().max().item() <= 2e-6, (shapes[i], n_sweeps, (a[i] - b[i]).abs().max().item())
-        assert (a[i] - c[i]).abs().max().item() <= 2e-6, (shapes[i], n_sweeps, (a[i] - c[i]).abs().max().item())
-    # a second run on the same workspace (stale tags) is bit-identical
-    a2 = mf(edges, cams, beta=10, n_sweeps=n_sweeps)
-    mf.sync()
-    for i in range(len(shapes)):
-        assert torch.equal(a2[i], a[i]), shapes[i]
-    for wkr in (mf, va, gen):
-        wkr.close()
-
-
-def test_mfma_walk_one_launch_equals_chunked_launches_bitwise():
-    """In-launch hand-offs vs kernel boundaries (sweeps_per_launch 1 and 5) for the matrix-pipe kernel."""
-    from irn_amd import synth
-    shapes = [(128, 128, 16), (125, 94, 12), (60, 200, 21)]
-    edges = [torch.from_numpy(synth.edge_field(h, w, seed=3300 + i)).to(_dev()) for i, (h, w, c) in enumerate(shapes)]
-    cams = [torch.from_numpy(synth.cam_blobs(c, h, w, seed=3300 + i)).to(_dev()) for i, (h, w, c) in enumerate(shapes)]
-    per = _walker(10, sweeps_per_launch=1)
-    ref = [o.clone() for o in per(edges, cams, beta=10, n_sweeps=24)]
-    per.sync()
-    for spl in (0, 5):
-        wk = _walker(10, sweeps_per_launch=spl)
-        for rep in range(2):
-            out = wk(edges, cams, beta=10, n_sweeps=24)
-            assert wk.sync() is False
-            for i in range(len(shapes)):
-                assert torch.equal(out[i], ref[i]), (spl, rep, shapes[i])
-        wk.close()
-    per.close()

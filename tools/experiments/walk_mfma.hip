@@ -303,12 +303,23 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) voi
             f4a acc[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
             {
                 const float *bp = xs + pbase * PLANE + bbase;
+                // B operands through an explicit ring of kAhead registers, loaded kAhead steps before their MFMA: a single
+                // wave per SIMD has nobody else to hide the LDS latency behind (left to itself the compiler waits for
+                // every operand right before its use: 10 us per group instead of ~2)
+                constexpr int kAhead = 8;
+                float bq[kAhead];
+                static_for<kAhead>([&](auto ir) __attribute__((always_inline)) {
+                    constexpr int r = decltype(ir)::value;
+                    bq[r] = bp[kSrc.sy[r] * LWM + kSrc.sx[r]];
+                });
                 static_for<NE>([&](auto ir) __attribute__((always_inline)) {
                     constexpr int r = decltype(ir)::value;
-                    constexpr int off = kSrc.sy[r] * LWM + kSrc.sx[r];
-                    acc[r & 3] = __builtin_amdgcn_mfma_f32_4x4x1f32(A[r], bp[off], acc[r & 3], 0, 0, 0);
-                    // operands are fetched 8 steps ahead at most: the scheduler would otherwise hoist all 362 LDS reads
-                    if constexpr (r % 8 == 7) __builtin_amdgcn_sched_barrier(0);
+                    acc[r & 3] = __builtin_amdgcn_mfma_f32_4x4x1f32(A[r], bq[r % kAhead], acc[r & 3], 0, 0, 0);
+                    if constexpr (r + kAhead < NE) {
+                        constexpr int rn = r + kAhead;
+                        bq[r % kAhead] = bp[kSrc.sy[rn] * LWM + kSrc.sx[rn]];
+                    }
+                    __builtin_amdgcn_sched_barrier(0);          // keep this order: MFMA r, then the load for r + kAhead
                     if constexpr (r == NE / 2) {
                         // half-way: channels 0,1 of the next group have landed; stage them and send the polls of 2,3,
                         // which fly under the second half
