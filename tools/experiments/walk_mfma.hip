@@ -1,3 +1,8 @@
+// EXPERIMENT (round 2, sessions 8-9) — NOT part of libirn_hip.so.  Measured slower than the VALU kernel (DESIGN.md §4 lesson 20,
+// profiles/r02_s8_mfma_experiment.txt) and taken out of the build; kept for the record.  It was wired in by commit 580886e
+// (host hooks mfma_supported / mfma_capacity / mfma_launch in walk_resident.hip, option "mfma_min_c"): check that commit out to
+// build and run it.
+//
 // Weights-stationary persistent random walk for MANY-CHANNEL images on the fp32 matrix pipe (gfx950, radius 10).
 //
 // Same operator, data layout in HBM, tile decomposition (8 x 32 pixels per workgroup) and tile-to-tile exchange (tagged
