@@ -269,3 +269,23 @@ def test_thread_loader_collates_like_dataloader(tmp_path):
                     assert torch.equal(x["img"], y["img"])
                 else:
                     assert all(torch.equal(p, q) for p, q in zip(x["img"], y["img"]))
+
+
+def test_cam_store_hit_and_file_fallback(tmp_path):
+    """step/_common.CamStore: a CAM put by make_cam is handed to the label steps from memory; anything else comes from the
+    `.npy` the reference's make_cam writes (step/make_cam.py:55-56) — same values either way."""
+    from irn_amd.step import _common
+    store = _common.CamStore(max_bytes=1 << 20)
+    dev = torch.device("cpu")
+    keys = torch.tensor([3, 7])
+    cam = torch.rand(2, 8, 9)
+    np.save(tmp_path / "2008_000001.npy", {"keys": keys, "cam": cam, "high_res": np.zeros((2, 32, 36), np.float32)})
+    store.put("2008_000001", keys, keys.clone(), cam.clone())
+    k_cpu, k_dev, c = store.get("2008_000001", str(tmp_path), dev)
+    assert store.hits == 1 and store.misses == 0 and torch.equal(k_cpu, keys) and torch.equal(c, cam)
+    store.clear()
+    k_cpu, k_dev, c = store.get("2008_000001", str(tmp_path), dev)
+    assert store.hits == 1 and store.misses == 1 and torch.equal(k_cpu, keys) and torch.equal(k_dev, keys) and torch.equal(c, cam)
+    big = torch.zeros(1, 1024, 1024)                       # 4 MB > the 1 MB cap: not kept, never an error
+    store.put("big", keys[:1], keys[:1], big)
+    assert "big" not in store._items
