@@ -1,6 +1,6 @@
 #!/bin/bash
 # One gpurun call of round 2 (the script is rewritten per session; results land in gpurun_out/r2_sN/).
-# usage: tools/gpu_session.sh <N> [what...]      what: tests bench ab prof pmc
+# usage: tools/gpu_session.sh <N> [what...]      what: tests bench ab prof pmc pmcsq ...
 set -u
 S=${1:-1}; shift || true
 WHAT=${*:-tests bench ab prof pmc}
@@ -48,6 +48,17 @@ pmc)
   cd $R
   python tools/reduce_prof.py $OUT > $OUT/prof_summary.txt 2>&1; grep -E "resident_k|affinity_k" $OUT/prof_summary.txt | cut -c1-24,96-200 | head -12
   find $OUT -name "walk_kernel_trace.csv" -delete; find $OUT -name "walk_counter_collection.csv" -delete ;;
+pmcsq)
+  # SQ counters of the walk kernels, one rocprofv3 pass per group of four (profiles/r02_s12_sq_counters.txt)
+  R=$PWD; cd /tmp; i=0
+  for set in "SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAVE_CYCLES" "SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_BUSY_CYCLES" \
+             "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS" "SQ_INSTS_VALU_FMA_F32 SQ_INSTS_VALU_ADD_F64 SQ_WAIT_INST_LDS SQ_ACTIVE_INST_MISC"; do
+    i=$((i+1))
+    timeout 200 rocprofv3 --pmc $set -d $R/$OUT/prof_sq$i -o walk -f csv -- python $R/bench.py --steps 1 --warmup 0 --no-legs --no-cpu-baseline ${SQ_BENCH_ARGS:-} > $R/$OUT/prof_sq$i.log 2>&1
+  done
+  cd $R
+  python tools/reduce_prof.py $OUT > $OUT/sq_summary.txt 2>&1; grep -E "resident_kernel" $OUT/sq_summary.txt | cut -c1-30,96-200
+  find $OUT -name "walk_counter_collection.csv" -delete ;;
 ins)
   for r in 5 10; do timeout 200 python tools/ins_step_breakdown.py $r 64 5 > $OUT/ins_breakdown_r$r.txt 2>&1; cat $OUT/ins_breakdown_r$r.txt | grep -v Warning; done
   timeout 300 python tools/ins_step_bench.py 64 > $OUT/ins_step_bench.txt 2>&1; grep walk_batch $OUT/ins_step_bench.txt ;;
