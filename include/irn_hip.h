@@ -209,6 +209,19 @@ int irn_msf_pack(const uint8_t *img_dev, int h, int w, int n_scales, const int32
                  const float *lut_dev, float *const *out_dev, void *scratch_dev, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Trunk epilogue  (replaces the elementwise tail of reference net/resnet50.py:35-55 Bottleneck.forward —
+ * FixedBatchNorm :11-14, `out += residual`, ReLU — and of the stem :87-89, on the inference path)
+ *
+ *   x dev fp32 [n_images, n_channels, plane_elems] (a convolution's output, contiguous NCHW), IN PLACE:
+ *       x[n, c, i] = act(x[n, c, i] * scale[c] + shift[c] (+ res[n, c, i]))      act = ReLU if relu else identity
+ *   scale / shift dev fp32 [n_channels]: weight / sqrt(running_var + eps) and bias - running_mean * scale, folded
+ *   by the caller; res (may be NULL) like x.  One fused multiply-add per element, NaNs propagate.  x and res 16-byte
+ *   aligned; at most 2^31 - 1 elements per call.
+ * ------------------------------------------------------------------------------------------- */
+int irn_bn_act(float *x_dev, const float *res_dev, const float *scale_dev, const float *shift_dev, int64_t n_images,
+               int n_channels, int64_t plane_elems, int relu, void *stream);
+
+/* ---------------------------------------------------------------------------------------------
  * Instance front-end
  *   irn_find_centroids   replaces step/make_ins_seg_labels.py:18-56
  *       dp dev [2,h,w] -> centroids dev int32 [2,h,w]; float32 state, float64 increment in the

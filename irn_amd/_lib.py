@@ -22,7 +22,7 @@ if not os.path.exists(LIB_PATH):
 
 lib = C.CDLL(LIB_PATH)
 
-vp, i32, f32, sz = C.c_void_p, C.c_int, C.c_float, C.c_size_t
+vp, i32, f32, sz, i64 = C.c_void_p, C.c_int, C.c_float, C.c_size_t, C.c_int64
 pi32 = C.POINTER(C.c_int32)
 ppv = C.POINTER(C.c_void_p)
 
@@ -53,6 +53,7 @@ _SIGS = {
     "irn_bicubic_scratch_bytes": (sz, [i32, i32, i32, i32, i32]),
     "irn_bicubic_resize_u8": (i32, [vp, i32, i32, i32, i32, i32, vp, vp, vp]),
     "irn_msf_pack": (i32, [vp, i32, i32, i32, pi32, pi32, vp, ppv, vp, vp]),
+    "irn_bn_act": (i32, [vp, vp, vp, vp, i64, i32, i64, i32, vp]),
     "irn_find_centroids": (i32, [vp, i32, i32, i32, vp, vp]),
     "irn_cluster_scratch_bytes": (sz, [i32, i32]),
     "irn_cluster_centroids": (i32, [vp, vp, i32, i32, f32, vp, C.POINTER(i32), vp, vp]),

@@ -7,8 +7,15 @@ Differences by design:
   * construction never touches the network (the reference downloads ImageNet weights in the
     constructor, net/resnet50.py:111-118); weights are an *input* to the hot path;
   * batch-norm layers always use their running statistics (reference `FixedBatchNorm`,
-    net/resnet50.py:11-14) — here that is simply the module's forward.
+    net/resnet50.py:11-14) — here that is simply the module's forward;
+  * on the inference path (GPU tensor, autograd off) the elementwise tail of every unit — batch norm, the residual add
+    and the ReLU (net/resnet50.py:35-55, :87-89) — is ONE in-place pass of a hand-written kernel over the convolution's
+    output (`ops.bn_act_`, irn_amd/csrc/bn_act.hip) instead of three kernels and seven tensor transfers; the
+    convolutions stay on MIOpen.  With autograd on (the training seam) or on the CPU the composed PyTorch ops run.
 """
+import os
+
+import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
@@ -16,12 +23,60 @@ STAGE_BLOCKS = (3, 4, 6, 3)
 STAGE_PLANES = (64, 128, 256, 512)
 
 
+# IRN_FUSED_EPILOGUE=0 keeps the composed PyTorch ops everywhere (A/B runs)
+FUSED_EPILOGUE = os.environ.get("IRN_FUSED_EPILOGUE", "1") != "0"
+
+
+def _fused(x):
+    return FUSED_EPILOGUE and x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and not torch.is_grad_enabled()
+
+
 class FrozenBatchNorm(nn.BatchNorm2d):
     """Inference-statistics batch norm regardless of train()/eval() (net/resnet50.py:11-14)."""
+
+    _folded = None
 
     def forward(self, x):
         return F.batch_norm(x, self.running_mean, self.running_var, self.weight, self.bias,
                             False, 0.0, self.eps)
+
+    def folded(self):
+        """(scale, shift) fp32 [C] with forward(x) = x * scale + shift, folded in double precision; cached until a
+        parameter or statistic is written or moved."""
+        src = (self.weight, self.bias, self.running_mean, self.running_var)
+        key = tuple((t.data_ptr(), t._version) for t in src)
+        if self._folded is None or self._folded[0] != key:
+            with torch.no_grad():
+                w, b, mean, var = (t.detach().double() for t in src)
+                scale = w / torch.sqrt(var + self.eps)
+                shift = b - mean * scale
+            self._folded = (key, scale.float().contiguous(), shift.float().contiguous())
+        return self._folded[1], self._folded[2]
+
+    def apply_(self, x, residual=None, relu=False):
+        """act(forward(x) (+ residual)), overwriting x on the inference path (x must be a tensor nobody else reads:
+        the output of the convolution in front of this layer)."""
+        if _fused(x) and (residual is None or (residual.is_contiguous() and residual.dtype == x.dtype)):
+            from .. import ops          # the HIP library; raises if it has not been built — there is no other GPU path
+            scale, shift = self.folded()
+            return ops.bn_act_(x, scale, shift, residual, relu)
+        y = self.forward(x)
+        if residual is not None:
+            y = y + residual
+        return F.relu(y) if relu else y
+
+
+class Stem(nn.Sequential):
+    """conv1, bn1, relu, maxpool (+ following stages) as the nets register them (reference net/resnet50_cam.py:14-15,
+    net/resnet50_irn.py:14): the same children and state-dict keys as a plain Sequential, with batch norm + ReLU taken
+    in one pass."""
+
+    def forward(self, x):
+        conv1, bn1, _, maxpool = self[0], self[1], self[2], self[3]
+        x = maxpool(bn1.apply_(conv1(x), relu=True))
+        for m in list(self)[4:]:
+            x = m(x)
+        return x
 
 
 class Bottleneck(nn.Module):
@@ -43,11 +98,10 @@ class Bottleneck(nn.Module):
                                             FrozenBatchNorm(c_out))
 
     def forward(self, x):
-        y = F.relu(self.bn1(self.conv1(x)))
-        y = F.relu(self.bn2(self.conv2(y)))
-        y = self.bn3(self.conv3(y))
-        skip = x if self.downsample is None else self.downsample(x)
-        return F.relu(y + skip)
+        y = self.bn1.apply_(self.conv1(x), relu=True)
+        y = self.bn2.apply_(self.conv2(y), relu=True)
+        skip = x if self.downsample is None else self.downsample[1].apply_(self.downsample[0](x))
+        return self.bn3.apply_(self.conv3(y), residual=skip, relu=True)
 
 
 def _stage(c_in, planes, n_blocks, stride, dilation):
@@ -73,7 +127,7 @@ class ResNet50Trunk(nn.Module):
             c_in = planes * Bottleneck.expansion
 
     def forward(self, x):
-        x = self.maxpool(self.relu(self.bn1(self.conv1(x))))
+        x = self.maxpool(self.bn1.apply_(self.conv1(x), relu=True))
         return self.layer4(self.layer3(self.layer2(self.layer1(x))))
 
 

@@ -19,7 +19,7 @@ class Net(nn.Module):
         super().__init__()
         t = _r50.resnet50(strides=(2, 2, 2, 1))
         self.resnet50 = t
-        self.stage1 = nn.Sequential(t.conv1, t.bn1, t.relu, t.maxpool, t.layer1)
+        self.stage1 = _r50.Stem(t.conv1, t.bn1, t.relu, t.maxpool, t.layer1)
         self.stage2 = nn.Sequential(t.layer2)
         self.stage3 = nn.Sequential(t.layer3)
         self.stage4 = nn.Sequential(t.layer4)

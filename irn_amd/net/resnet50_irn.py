@@ -41,7 +41,7 @@ class Net(nn.Module):
         super().__init__()
         t = _r50.resnet50(strides=(2, 2, 2, 1))
         self.resnet50 = t
-        self.stage1 = nn.Sequential(t.conv1, t.bn1, t.relu, t.maxpool)
+        self.stage1 = _r50.Stem(t.conv1, t.bn1, t.relu, t.maxpool)
         self.stage2 = nn.Sequential(t.layer1)
         self.stage3 = nn.Sequential(t.layer2)
         self.stage4 = nn.Sequential(t.layer3)

@@ -1,0 +1,153 @@
+"""The trunk's fused inference epilogue (irn_bn_act, irn_amd/csrc/bn_act.hip) against the composed operations it
+replaces — FixedBatchNorm -> `out += residual` -> ReLU of reference net/resnet50.py:11-14, :35-55, :87-89.
+
+The kernel does one fused multiply-add per element with constants folded in double precision, so it is compared with
+the exact (fp64) value of the same expression at fp32 rounding accuracy, with PyTorch's own batch_norm / add / relu at
+the accuracy those have among themselves, and through the whole CAM / IRNet forwards with the fusion on and off."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev():
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    return torch.device("cuda", 0)
+
+
+def _case(shape, seed, residual):
+    g = torch.Generator().manual_seed(seed)
+    c = shape[1]
+    x = torch.randn(shape, generator=g)
+    res = torch.randn(shape, generator=g) if residual else None
+    scale = torch.rand(c, generator=g) * 2 - 0.5
+    shift = torch.randn(c, generator=g)
+    return x, res, scale, shift
+
+
+# planes that are / are not a multiple of four long, a piece straddling two planes at every offset, planes shorter than
+# a piece, a flat tail, one channel, one image, many channels
+SHAPES = [(2, 8, 16, 16), (3, 5, 7, 9), (2, 3, 1, 5), (4, 6, 1, 1), (1, 1, 3, 1), (1, 7, 1, 3), (2, 64, 33, 47), (1, 2048, 2, 3),
+          (16, 3, 5, 5), (1, 1, 1, 1027), (2, 1, 31, 2)]
+
+
+@pytest.mark.parametrize("shape", SHAPES)
+@pytest.mark.parametrize("residual", [False, True])
+@pytest.mark.parametrize("relu", [False, True])
+def test_bn_act_equals_the_exact_expression(shape, residual, relu):
+    from irn_amd import ops
+    dev = _dev()
+    x, res, scale, shift = _case(shape, 11 + len(shape) * shape[1], residual)
+    view = (1, -1) + (1,) * (len(shape) - 2)
+    exact = x.double() * scale.double().view(view) + shift.double().view(view)
+    fma32 = exact.float()                                     # the kernel's fmaf: one rounding of the exact value
+    if residual:
+        exact = fma32.double() + res.double()                 # then one fp32 addition
+    want = exact.float()
+    if relu:
+        want = torch.clamp_min(want, 0)
+    xd = x.to(dev)
+    out = ops.bn_act_(xd, scale.to(dev), shift.to(dev), None if res is None else res.to(dev), relu)
+    assert out.data_ptr() == xd.data_ptr()                    # in place
+    assert torch.equal(out.cpu(), want), float((out.cpu() - want).abs().max())
+
+
+def test_bn_act_nan_and_signed_zero():
+    from irn_amd import ops
+    dev = _dev()
+    x = torch.tensor([[[float("nan"), -1.0, 2.0, float("inf"), -float("inf"), 0.0, -0.0, 1.0]]], device=dev).view(1, 1, 8)
+    out = ops.bn_act_(x.clone(), torch.ones(1, device=dev), torch.zeros(1, device=dev), None, True).cpu().view(-1)
+    ref = torch.relu(x.cpu().view(-1))
+    assert torch.isnan(out[0]) and torch.isnan(ref[0])
+    assert torch.equal(out[1:], ref[1:])
+
+
+def test_bn_act_refuses_what_it_cannot_do():
+    from irn_amd import ops
+    dev = _dev()
+    x = torch.zeros(2, 4, 3, 3, device=dev)
+    s = torch.ones(4, device=dev)
+    with pytest.raises(ValueError):
+        ops.bn_act_(x.cpu(), s, s)
+    with pytest.raises(ValueError):
+        ops.bn_act_(x.permute(0, 1, 3, 2)[:, :, :, :2], s, s)                 # not contiguous
+    with pytest.raises(ValueError):
+        ops.bn_act_(x, torch.ones(3, device=dev), s)
+    with pytest.raises(ValueError):
+        ops.bn_act_(x, s, s, residual=torch.zeros(2, 4, 3, 2, device=dev))
+    with pytest.raises(ValueError):
+        ops.bn_act_(x.double(), s, s)
+    assert ops.bn_act_(torch.zeros(0, 4, 3, 3, device=dev), s, s).numel() == 0
+
+
+@pytest.mark.parametrize("shape", [(2, 16, 9, 13), (1, 32, 8, 8)])
+def test_frozen_batch_norm_apply_equals_composed_ops(shape):
+    """FrozenBatchNorm.apply_ on the device (fused) vs F.batch_norm -> + skip -> relu on the device and on the CPU."""
+    from irn_amd.net import resnet50 as R
+    dev = _dev()
+    g = torch.Generator().manual_seed(5)
+    bn = R.FrozenBatchNorm(shape[1])
+    with torch.no_grad():
+        bn.weight.copy_(torch.rand(shape[1], generator=g) + 0.5)
+        bn.bias.copy_(torch.randn(shape[1], generator=g))
+        bn.running_mean.copy_(torch.randn(shape[1], generator=g))
+        bn.running_var.copy_(torch.rand(shape[1], generator=g) + 0.1)
+    x = torch.randn(shape, generator=g)
+    skip = torch.randn(shape, generator=g)
+    with torch.no_grad():
+        want = F.relu(bn(x) + skip)
+        bnd = bn.to(dev)
+        got = bnd.apply_(x.to(dev), residual=skip.to(dev), relu=True)
+        composed = F.relu(bnd(x.to(dev)) + skip.to(dev))
+    assert float((got.cpu() - want).abs().max()) < 2e-6
+    assert float((got - composed).abs().max()) < 2e-6
+    # with autograd on the composed path runs and the input is left alone
+    xg = x.to(dev).requires_grad_(True)
+    y = bnd.apply_(xg, residual=skip.to(dev), relu=True)
+    assert y.requires_grad and y.data_ptr() != xg.data_ptr()
+    assert float((y.detach() - composed).abs().max()) == 0.0
+
+
+def test_folded_constants_follow_the_parameters():
+    from irn_amd.net import resnet50 as R
+    dev = _dev()
+    bn = R.FrozenBatchNorm(4).to(dev)
+    s0, b0 = bn.folded()
+    assert bn.folded()[0] is s0                                                # cached
+    with torch.no_grad():
+        bn.running_var.fill_(4.0)
+        bn.running_mean.fill_(1.0)
+    s1, b1 = bn.folded()
+    assert s1 is not s0
+    np.testing.assert_allclose(s1.cpu().numpy(), 1 / np.sqrt(4.0 + bn.eps), rtol=1e-7)
+    np.testing.assert_allclose(b1.cpu().numpy(), -1 / np.sqrt(4.0 + bn.eps), rtol=1e-7)
+    bn.load_state_dict({"weight": torch.full((4,), 2.0), "bias": torch.zeros(4), "running_mean": torch.zeros(4),
+                        "running_var": torch.ones(4), "num_batches_tracked": torch.tensor(0)})
+    np.testing.assert_allclose(bn.folded()[0].cpu().numpy(), 2 / np.sqrt(1.0 + bn.eps), rtol=1e-7)
+
+
+@pytest.mark.parametrize("size", [(64, 96), (75, 101)])
+def test_backbones_fused_vs_composed(size, monkeypatch):
+    """The whole CAM and IRNet forwards with the fused epilogue on and off (same weights, same MIOpen convolutions):
+    what the fusion changes is one rounding per layer."""
+    from irn_amd.net import resnet50 as R, resnet50_cam, resnet50_irn, weights
+    dev = _dev()
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn((2, 3) + size, generator=g).to(dev)
+    cam = resnet50_cam.CAM()
+    cam.load_state_dict(weights.random_cam_state(seed=1), strict=True)
+    cam = cam.to(dev).eval()
+    irn = resnet50_irn.EdgeDisplacement(crop_size=128)
+    irn.load_state_dict(weights.random_irn_state(seed=2), strict=False)
+    irn = irn.to(dev).eval()
+    outs = {}
+    for fused in (True, False):
+        monkeypatch.setattr(R, "FUSED_EPILOGUE", fused)
+        with torch.no_grad():
+            e, d = irn(x)
+            outs[fused] = (cam(x).cpu(), e.cpu(), d.cpu())
+    for a, b in zip(outs[True], outs[False]):
+        assert a.shape == b.shape
+        assert float((a - b).abs().max()) <= 2e-5 * max(1.0, float(b.abs().max()))

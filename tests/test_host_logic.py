@@ -289,3 +289,36 @@ def test_cam_store_hit_and_file_fallback(tmp_path):
     big = torch.zeros(1, 1024, 1024)                       # 4 MB > the 1 MB cap: not kept, never an error
     store.put("big", keys[:1], keys[:1], big)
     assert "big" not in store._items
+
+
+def test_frozen_batch_norm_folding_and_composed_path():
+    """FrozenBatchNorm.folded() is the batch norm as one multiply-add (the constants irn_bn_act consumes), and apply_ on
+    the CPU (or with autograd on) is the reference's composed tail: FixedBatchNorm -> += residual -> ReLU
+    (net/resnet50.py:11-14, :35-55), leaving its input untouched."""
+    import torch.nn.functional as F
+    from irn_amd.net import resnet50 as R
+    g = torch.Generator().manual_seed(9)
+    bn = R.FrozenBatchNorm(6)
+    with torch.no_grad():
+        bn.weight.copy_(torch.rand(6, generator=g) + 0.5)
+        bn.bias.copy_(torch.randn(6, generator=g))
+        bn.running_mean.copy_(torch.randn(6, generator=g))
+        bn.running_var.copy_(torch.rand(6, generator=g) + 0.05)
+    x = torch.randn(2, 6, 5, 7, generator=g)
+    skip = torch.randn(2, 6, 5, 7, generator=g)
+    scale, shift = bn.folded()
+    with torch.no_grad():
+        want = bn(x)
+    assert float((x * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1) - want).abs().max()) < 2e-6
+    x0 = x.clone()
+    with torch.no_grad():
+        y = bn.apply_(x, residual=skip, relu=True)
+    assert torch.equal(x, x0) and torch.equal(y, F.relu(want + skip))
+    bn.train()                                                   # statistics stay frozen (FixedBatchNorm)
+    with torch.no_grad():
+        assert torch.equal(bn(x), want)
+    key = bn.folded()[0]
+    assert bn.folded()[0] is key
+    with torch.no_grad():
+        bn.weight.mul_(2.0)
+    assert float((bn.folded()[0] - 2 * key).abs().max()) < 1e-6

@@ -90,6 +90,20 @@ profile)
 stepsprof)
   timeout 600 python -m cProfile -s cumtime bench.py --workload steps --steps 2 --warmup 1 --batch 64 > $OUT/steps_cprofile.txt 2>&1
   grep -v "MIOpen" $OUT/steps_cprofile.txt | grep -E "^\{|cumtime|_work|_flush|edges_for|forward_batch|make_loader|msf_pack|cam_merge|label_epilogue|synchronize|\.cpu|numpy|save|result|acquire|sleep|__call__|sync" | head -50 ;;
+camprof)
+  # which MIOpen / PyTorch kernels the CAM backbone leg runs, and their share (profiles/r02_s13_cam_kernel_stats.csv)
+  R=$PWD; cd /tmp
+  timeout 400 rocprofv3 --kernel-trace --stats -d $R/$OUT/prof_cam -o cam -f csv -- python $R/bench.py --workload cam --steps 2 --warmup 1 --no-legs --no-cpu-baseline > $R/$OUT/prof_cam.log 2>&1
+  cd $R
+  find $OUT/prof_cam -name "*kernel_stats*" -exec cp {} $OUT/cam_kernel_stats.csv \;
+  find $OUT/prof_cam -name "cam_kernel_trace.csv" -delete
+  cut -c1-200 $OUT/cam_kernel_stats.csv | head -40 ;;
+fusedab)
+  # trunk epilogue fused (irn_bn_act) vs composed PyTorch ops, same run otherwise
+  for w in cam e2e; do for f in 1 0; do
+    IRN_FUSED_EPILOGUE=$f timeout 300 python bench.py --workload $w --steps 3 --warmup 1 --no-legs --no-cpu-baseline --json-out $OUT/fusedab_${w}_$f.json > /dev/null 2>&1
+    python -c "import json; r=json.load(open('$OUT/fusedab_${w}_$f.json')); print('$w fused=$f: %.1f img/s, %.2f ms/step' % (r['value'], r['ms_per_step']))"
+  done; done ;;
 smoke)
   python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -2
   timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 1 --steps 5 --warmup 2 --no-legs --no-cpu-baseline 2>&1 | grep -E "^\{" | cut -c1-400 ;;
