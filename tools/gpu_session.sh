@@ -90,14 +90,15 @@ profile)
 stepsprof)
   timeout 600 python -m cProfile -s cumtime bench.py --workload steps --steps 2 --warmup 1 --batch 64 > $OUT/steps_cprofile.txt 2>&1
   grep -v "MIOpen" $OUT/steps_cprofile.txt | grep -E "^\{|cumtime|_work|_flush|edges_for|forward_batch|make_loader|msf_pack|cam_merge|label_epilogue|synchronize|\.cpu|numpy|save|result|acquire|sleep|__call__|sync" | head -50 ;;
-camprof)
-  # which MIOpen / PyTorch kernels the CAM backbone leg runs, and their share (profiles/r02_s13_cam_kernel_stats.csv)
+camprof|e2eprof)
+  # which MIOpen / PyTorch / irn kernels a backbone-bound leg runs, and their share (profiles/r02_s14_cam_kernel_stats_fused.csv)
+  leg=${w%prof}
   R=$PWD; cd /tmp
-  timeout 400 rocprofv3 --kernel-trace --stats -d $R/$OUT/prof_cam -o cam -f csv -- python $R/bench.py --workload cam --steps 2 --warmup 1 --no-legs --no-cpu-baseline > $R/$OUT/prof_cam.log 2>&1
+  timeout 400 rocprofv3 --kernel-trace --stats -d $R/$OUT/prof_$leg -o $leg -f csv -- python $R/bench.py --workload $leg --steps 2 --warmup 1 --no-legs --no-cpu-baseline > $R/$OUT/prof_$leg.log 2>&1
   cd $R
-  find $OUT/prof_cam -name "*kernel_stats*" -exec cp {} $OUT/cam_kernel_stats.csv \;
-  find $OUT/prof_cam -name "cam_kernel_trace.csv" -delete
-  cut -c1-200 $OUT/cam_kernel_stats.csv | head -40 ;;
+  find $OUT/prof_$leg -name "*kernel_stats*" -exec cp {} $OUT/${leg}_kernel_stats.csv \;
+  find $OUT/prof_$leg -name "${leg}_kernel_trace.csv" -delete
+  python tools/kernel_classes.py $OUT/${leg}_kernel_stats.csv ;;
 fusedab)
   # trunk epilogue fused (irn_bn_act) vs composed PyTorch ops, same run otherwise
   for w in cam e2e; do for f in 1 0; do
