@@ -221,6 +221,20 @@ int irn_msf_pack(const uint8_t *img_dev, int h, int w, int n_scales, const int32
 int irn_bn_act(float *x_dev, const float *res_dev, const float *scale_dev, const float *shift_dev, int64_t n_images,
                int n_channels, int64_t plane_elems, int relu, void *stream);
 
+/* Stem: batch norm + ReLU + max pool 3x3 / stride 2 / pad 1 in one pass (reference net/resnet50.py:94-97; the nets'
+ * stage1, net/resnet50_cam.py:14, net/resnet50_irn.py:15).
+ *   x dev fp32 [n_images, n_channels, h, w] (conv1's output) -> out dev fp32 [n_images, n_channels, (h-1)/2+1, (w-1)/2+1]
+ *   = max over the window's in-image taps of relu(x * scale[c] + shift[c]); NaNs propagate. */
+int irn_stem_pool(const float *x_dev, const float *scale_dev, const float *shift_dev, int64_t n_images, int n_channels, int h,
+                  int w, float *out_dev, void *stream);
+
+/* IRNet heads: bilinear upsampling by an integer factor, align_corners = False, (+ ReLU) — nn.Upsample(scale_factor = f,
+ * mode = 'bilinear') followed by nn.ReLU, reference net/resnet50_irn.py:36,42,48,72,78,84.  ATen's source index and
+ * weights (src = (dst + 0.5) / f - 0.5 clamped at 0) and its operation order, in fp32 without contraction.
+ *   x dev fp32 [n_planes, h, w] -> out dev fp32 [n_planes, h * f, w * f] (16-byte aligned) */
+int irn_upsample_bilinear(const float *x_dev, int64_t n_planes, int h, int w, int factor, int relu, float *out_dev,
+                          void *stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Instance front-end
  *   irn_find_centroids   replaces step/make_ins_seg_labels.py:18-56

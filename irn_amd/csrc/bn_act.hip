@@ -139,3 +139,135 @@ extern "C" int irn_bn_act(float *x_dev, const float *res_dev, const float *scale
     if (relu) return launch<false, true>(x_dev, res_dev, scale_dev, shift_dev, (unsigned)numel, hw, n_ch, s);
     return launch<false, false>(x_dev, res_dev, scale_dev, shift_dev, (unsigned)numel, hw, n_ch, s);
 }
+
+// ------------------------------------------------------------------------------------------------
+// Stem: batch norm + ReLU + 3x3 / stride 2 / pad 1 max pool of reference net/resnet50.py:94-97 (the nets' stage1,
+// net/resnet50_cam.py:14, net/resnet50_irn.py:15) in one pass: the largest activation of the trunk (64 x H/2 x W/2) is
+// read once and a quarter of it written, instead of read + written by the epilogue and read again by the pool.
+// One output per thread; the nine taps of neighbouring outputs overlap and are served by the vector L1.
+// ------------------------------------------------------------------------------------------------
+namespace irn {
+namespace {
+
+__global__ __launch_bounds__(256) void stem_pool_kernel(const float *__restrict__ x, const float *__restrict__ scale,
+                                                        const float *__restrict__ shift, float *__restrict__ out, int n_ch, int h,
+                                                        int w, int ho, int wo) {
+    const int xo = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int yo = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const unsigned plane = blockIdx.z;
+    if (xo >= wo || yo >= ho) return;
+    const float s = scale[plane % (unsigned)n_ch], b = shift[plane % (unsigned)n_ch];
+    const float *src = x + (size_t)plane * h * w;
+    float m = 0.f;                                   // ReLU's floor: max(0, taps) = relu(max(taps))
+    bool nan = false;
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+        const int y = 2 * yo - 1 + ky;
+        if (y < 0 || y >= h) continue;
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            const int xx = 2 * xo - 1 + kx;
+            if (xx < 0 || xx >= w) continue;
+            const float v = fmaf(src[(size_t)y * w + xx], s, b);
+            nan |= v != v;
+            m = v > m ? v : m;
+        }
+    }
+    out[((size_t)plane * ho + yo) * wo + xo] = nan ? __builtin_nanf("") : m;      // torch's max pool propagates NaN
+}
+
+// Bilinear x`factor` upsampling (align_corners = False, the scale factor handed to the kernel as nn.Upsample does) + ReLU of
+// the IRNet heads, reference net/resnet50_irn.py:36,42,48,72,78,84 followed by nn.ReLU.  Source index and weights as in
+// ATen's upsample_bilinear2d: src = (dst + 0.5) / factor - 0.5 clamped at 0, lambda = src - floor(src), and
+//     out = (1 - ly) * ((1 - lx) * a + lx * b) + ly * ((1 - lx) * c + lx * d)      in fp32, no contraction.
+// Bound by the output write (4 or 16 times the input); V consecutive outputs of a row per thread leave as one store.
+template <int V, bool RELU>
+__global__ __launch_bounds__(256) void upsample_kernel(const float *__restrict__ x, float *__restrict__ out, int h, int w, int ho,
+                                                       int wo, float rscale) {
+    const int xg = blockIdx.x * 64 + (threadIdx.x & 63);         // group of V outputs
+    const int yo = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const unsigned plane = blockIdx.z;
+    if (xg * V >= wo || yo >= ho) return;
+    float sy = rscale * ((float)yo + 0.5f) - 0.5f;
+    sy = sy < 0.f ? 0.f : sy;
+    const int y0 = (int)sy;
+    const int y1 = y0 + (y0 < h - 1 ? 1 : 0);
+    const float ly = sy - (float)y0, ly0 = 1.f - ly;
+    const float *r0 = x + ((size_t)plane * h + y0) * w, *r1 = x + ((size_t)plane * h + y1) * w;
+    float o[V];
+#pragma unroll
+    for (int v = 0; v < V; ++v) {
+        const int xo = xg * V + v;
+        float sx = rscale * ((float)xo + 0.5f) - 0.5f;
+        sx = sx < 0.f ? 0.f : sx;
+        const int x0 = (int)sx;
+        const int x1 = x0 + (x0 < w - 1 ? 1 : 0);
+        const float lx = sx - (float)x0, lx0 = 1.f - lx;
+        float val = ly0 * (lx0 * r0[x0] + lx * r0[x1]) + ly * (lx0 * r1[x0] + lx * r1[x1]);
+        if (RELU) val = val < 0.f ? 0.f : val;
+        o[v] = val;
+    }
+    float *dst = out + ((size_t)plane * ho + yo) * wo + (size_t)xg * V;
+    if constexpr (V == 4) *reinterpret_cast<f4v *>(dst) = f4v{o[0], o[1], o[2], o[3]};
+    else if constexpr (V == 2) *reinterpret_cast<float2 *>(dst) = float2{o[0], o[1]};
+    else dst[0] = o[0];
+}
+
+template <int V>
+int launch_upsample(const float *x, float *out, unsigned n_planes, int h, int w, int ho, int wo, float rscale, int relu,
+                    hipStream_t s) {
+    const dim3 grid((unsigned)cdiv(cdiv(wo, V), 64), (unsigned)cdiv(ho, 4), n_planes);
+    if (relu) hipLaunchKernelGGL((upsample_kernel<V, true>), grid, dim3(256), 0, s, x, out, h, w, ho, wo, rscale);
+    else hipLaunchKernelGGL((upsample_kernel<V, false>), grid, dim3(256), 0, s, x, out, h, w, ho, wo, rscale);
+    IRN_LAUNCH_CHECK("upsample_kernel");
+    return IRN_OK;
+}
+
+}  // namespace
+}  // namespace irn
+
+extern "C" int irn_stem_pool(const float *x_dev, const float *scale_dev, const float *shift_dev, int64_t n_images, int n_channels,
+                             int h, int w, float *out_dev, void *stream) {
+    using namespace irn;
+    if (!x_dev || !scale_dev || !shift_dev || !out_dev) return fail(IRN_ERR_ARG, "irn_stem_pool: null pointer");
+    if (n_images < 0 || n_channels <= 0 || h <= 0 || w <= 0) return fail(IRN_ERR_ARG, "irn_stem_pool: non-positive size");
+    const int64_t n_planes = n_images * n_channels;
+    if (n_planes == 0) return IRN_OK;
+    const int ho = (h - 1) / 2 + 1, wo = (w - 1) / 2 + 1;
+    if (cdiv(ho, 4) > 65535) return fail(IRN_ERR_ARG, "irn_stem_pool: %d rows; at most 524280", h);
+    if (n_channels > 65535) return fail(IRN_ERR_ARG, "irn_stem_pool: %d channels; at most 65535", n_channels);
+    // the plane index rides on grid.z (at most 65535 per launch); launches start at whole images so that plane % n_channels holds
+    const int64_t step = (int64_t)(65535 / n_channels) * n_channels;
+    for (int64_t p0 = 0; p0 < n_planes; p0 += step) {
+        const unsigned np = (unsigned)((n_planes - p0) < step ? (n_planes - p0) : step);
+        hipLaunchKernelGGL(stem_pool_kernel, dim3((unsigned)cdiv(wo, 64), (unsigned)cdiv(ho, 4), np), dim3(256), 0, (hipStream_t)stream,
+                           x_dev + (size_t)p0 * h * w, scale_dev, shift_dev, out_dev + (size_t)p0 * ho * wo, n_channels, h, w, ho, wo);
+        IRN_LAUNCH_CHECK("stem_pool_kernel");
+    }
+    return IRN_OK;
+}
+
+extern "C" int irn_upsample_bilinear(const float *x_dev, int64_t n_planes, int h, int w, int factor, int relu, float *out_dev,
+                                     void *stream) {
+    using namespace irn;
+    if (!x_dev || !out_dev) return fail(IRN_ERR_ARG, "irn_upsample_bilinear: null pointer");
+    if (n_planes < 0 || h <= 0 || w <= 0 || factor < 1 || factor > 64)
+        return fail(IRN_ERR_ARG, "irn_upsample_bilinear: non-positive size or factor outside 1..64");
+    if ((uintptr_t)out_dev & 15u) return fail(IRN_ERR_ARG, "irn_upsample_bilinear: output must be 16-byte aligned");
+    if (n_planes == 0) return IRN_OK;
+    const int ho = h * factor, wo = w * factor;
+    if (cdiv(ho, 4) > 65535) return fail(IRN_ERR_ARG, "irn_upsample_bilinear: %d output rows; at most 262140", ho);
+    const float rscale = (float)(1.0 / (double)factor);
+    for (int64_t p0 = 0; p0 < n_planes; p0 += 65535) {
+        const unsigned np = (unsigned)((n_planes - p0) < 65535 ? (n_planes - p0) : 65535);
+        const float *xs = x_dev + (size_t)p0 * h * w;
+        float *os = out_dev + (size_t)p0 * ho * wo;
+        int rc;
+        // rows start at multiples of wo elements: a 16-byte store needs wo % 4 == 0 (plane and row starts then stay aligned)
+        if (wo % 4 == 0) rc = launch_upsample<4>(xs, os, np, h, w, ho, wo, rscale, relu, (hipStream_t)stream);
+        else if (wo % 2 == 0) rc = launch_upsample<2>(xs, os, np, h, w, ho, wo, rscale, relu, (hipStream_t)stream);
+        else rc = launch_upsample<1>(xs, os, np, h, w, ho, wo, rscale, relu, (hipStream_t)stream);
+        if (rc != IRN_OK) return rc;
+    }
+    return IRN_OK;
+}

@@ -66,14 +66,23 @@ class FrozenBatchNorm(nn.BatchNorm2d):
         return F.relu(y) if relu else y
 
 
+def stem(conv1, bn1, maxpool, x):
+    """conv1 -> bn1 -> ReLU -> maxpool (net/resnet50.py:94-97); on the inference path everything behind the convolution is
+    one pass (`ops.stem_pool`) when the pool is the trunk's 3x3 / stride 2 / pad 1."""
+    y = conv1(x)
+    if _fused(y) and (maxpool.kernel_size, maxpool.stride, maxpool.padding, maxpool.dilation, maxpool.ceil_mode) == (3, 2, 1, 1, False):
+        from .. import ops
+        return ops.stem_pool(y, *bn1.folded())
+    return maxpool(bn1.apply_(y, relu=True))
+
+
 class Stem(nn.Sequential):
     """conv1, bn1, relu, maxpool (+ following stages) as the nets register them (reference net/resnet50_cam.py:14-15,
     net/resnet50_irn.py:14): the same children and state-dict keys as a plain Sequential, with batch norm + ReLU taken
-    in one pass."""
+    and the pool taken in one pass."""
 
     def forward(self, x):
-        conv1, bn1, _, maxpool = self[0], self[1], self[2], self[3]
-        x = maxpool(bn1.apply_(conv1(x), relu=True))
+        x = stem(self[0], self[1], self[3], x)
         for m in list(self)[4:]:
             x = m(x)
         return x
@@ -127,7 +136,7 @@ class ResNet50Trunk(nn.Module):
             c_in = planes * Bottleneck.expansion
 
     def forward(self, x):
-        x = self.maxpool(self.bn1.apply_(self.conv1(x), relu=True))
+        x = stem(self.conv1, self.bn1, self.maxpool, x)
         return self.layer4(self.layer3(self.layer2(self.layer1(x))))
 
 

@@ -128,6 +128,41 @@ def bn_act_(x, scale, shift, residual=None, relu=True):
     return x
 
 
+def _need_f32_contig(t, what, min_dim):
+    _need_cuda(t, what)
+    if t.dtype != torch.float32 or not t.is_contiguous() or t.dim() < min_dim:
+        raise ValueError("%s must be a contiguous fp32 tensor of >= %d dimensions, got %s %s" % (what, min_dim, t.dtype, tuple(t.shape)))
+
+
+def stem_pool(x, scale, shift):
+    """Batch norm + ReLU + 3x3 / stride 2 / pad 1 max pool of the trunk's stem in one pass (irn_stem_pool; reference
+    net/resnet50.py:94-97).  x: GPU fp32 [N, C, H, W] (conv1's output, left untouched) -> [N, C, (H-1)//2+1, (W-1)//2+1]."""
+    _need_f32_contig(x, "stem_pool: x", 4)
+    n, c, h, w = (int(v) for v in x.shape)
+    for name, t in (("scale", scale), ("shift", shift)):
+        if t.device != x.device or t.dtype != torch.float32 or not t.is_contiguous() or t.numel() != c:
+            raise ValueError("stem_pool: %s must be a contiguous fp32 [%d] tensor on %s" % (name, c, x.device))
+    out = torch.empty((n, c, (h - 1) // 2 + 1 if h else 0, (w - 1) // 2 + 1 if w else 0), dtype=torch.float32, device=x.device)
+    if out.numel():
+        with torch.cuda.device(x.device):
+            check(lib.irn_stem_pool(x.data_ptr(), scale.data_ptr(), shift.data_ptr(), n, c, h, w, out.data_ptr(), _stream()))
+    return out
+
+
+def upsample_bilinear(x, factor, relu=False):
+    """nn.Upsample(scale_factor=factor, mode='bilinear', align_corners=False) (+ ReLU) of the IRNet heads in one pass
+    (irn_upsample_bilinear; reference net/resnet50_irn.py:36-48, :72-84).  x: GPU fp32 [..., h, w] -> [..., h*factor, w*factor]."""
+    _need_f32_contig(x, "upsample_bilinear: x", 2)
+    factor = int(factor)
+    h, w = int(x.shape[-2]), int(x.shape[-1])
+    out = torch.empty(tuple(x.shape[:-2]) + (h * factor, w * factor), dtype=torch.float32, device=x.device)
+    if out.numel():
+        with torch.cuda.device(x.device):
+            check(lib.irn_upsample_bilinear(x.data_ptr(), x.numel() // (h * w), h, w, factor, 1 if relu else 0, out.data_ptr(),
+                                            _stream()))
+    return out
+
+
 _LUTS = {}
 
 

@@ -106,6 +106,13 @@ def test_argument_validation_of_the_newer_entry_points():
     assert L.irn_bn_act(C.c_void_p(68), None, one, one, 1, 4, 16, 1, None) == 1    # not 16-byte aligned
     assert L.irn_bn_act(one, None, one, one, 1 << 20, 2048, 4096, 1, None) == 1 and b"2^31" in L.irn_last_error()
     assert L.irn_bn_act(one, None, one, one, 0, 4, 16, 1, None) == 0               # empty batch: nothing to do
+    assert L.irn_stem_pool(None, one, one, 1, 64, 8, 8, one, None) == 1 and b"irn_stem_pool" in L.irn_last_error()
+    assert L.irn_stem_pool(one, one, one, 1, 64, 0, 8, one, None) == 1
+    assert L.irn_stem_pool(one, one, one, 0, 64, 8, 8, one, None) == 0             # empty batch
+    assert L.irn_upsample_bilinear(None, 1, 4, 4, 2, 1, one, None) == 1
+    assert L.irn_upsample_bilinear(one, 1, 4, 4, 0, 1, one, None) == 1 and b"factor" in L.irn_last_error()
+    assert L.irn_upsample_bilinear(one, 1, 4, 4, 2, 1, C.c_void_p(72), None) == 1  # output not 16-byte aligned
+    assert L.irn_upsample_bilinear(one, 0, 4, 4, 2, 1, one, None) == 0
     assert L.irn_pair_displacement(None, 1, 2, 20, 27, 5, None, None) == 1
     assert L.irn_pair_displacement(one, 1, 2, 4, 27, 5, one, None) == 1       # grid smaller than the radius
     assert b"too small" in L.irn_last_error()

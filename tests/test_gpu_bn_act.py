@@ -151,3 +151,110 @@ def test_backbones_fused_vs_composed(size, monkeypatch):
     for a, b in zip(outs[True], outs[False]):
         assert a.shape == b.shape
         assert float((a - b).abs().max()) <= 2e-5 * max(1.0, float(b.abs().max()))
+
+
+# ------------------------------------------------------------------------------------------------
+# stem: batch norm + ReLU + max pool in one pass
+# ------------------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("shape", [(2, 8, 16, 16), (1, 3, 1, 1), (2, 5, 2, 3), (3, 64, 37, 51), (1, 4, 64, 130), (1, 2, 7, 129)])
+def test_stem_pool_equals_the_composed_ops(shape):
+    from irn_amd import ops
+    dev = _dev()
+    x, _, scale, shift = _case(shape, 3 + shape[2], False)
+    fma32 = (x.double() * scale.double().view(1, -1, 1, 1) + shift.double().view(1, -1, 1, 1)).float()
+    want = F.max_pool2d(torch.clamp_min(fma32, 0), 3, 2, 1)
+    xd = x.to(dev)
+    got = ops.stem_pool(xd, scale.to(dev), shift.to(dev))
+    assert torch.equal(xd.cpu(), x)                                             # the input is not written
+    assert got.shape == want.shape and torch.equal(got.cpu(), want)
+
+
+def test_stem_pool_nan_and_refusals():
+    from irn_amd import ops
+    dev = _dev()
+    x = torch.zeros(1, 1, 6, 6)
+    x[0, 0, 3, 3] = float("nan")                                               # a tap of four windows
+    one, zero = torch.ones(1, device=dev), torch.zeros(1, device=dev)
+    got = ops.stem_pool(x.to(dev), one, zero).cpu()
+    want = F.max_pool2d(torch.relu(x), 3, 2, 1)
+    assert torch.equal(torch.isnan(got), torch.isnan(want)) and torch.isnan(got).sum() == 4
+    with pytest.raises(ValueError):
+        ops.stem_pool(x, one, zero)                                             # CPU tensor
+    with pytest.raises(ValueError):
+        ops.stem_pool(x.to(dev), torch.ones(2, device=dev), zero)
+    assert ops.stem_pool(torch.zeros(0, 1, 6, 6, device=dev), one, zero).shape == (0, 1, 3, 3)
+
+
+def test_stem_module_fused_vs_composed(monkeypatch):
+    from irn_amd.net import resnet50 as R
+    dev = _dev()
+    torch.manual_seed(4)
+    trunk = R.ResNet50Trunk(strides=(2, 2, 2, 1)).to(dev).eval()
+    with torch.no_grad():
+        trunk.bn1.running_mean.normal_()
+        trunk.bn1.running_var.uniform_(0.2, 2.0)
+        trunk.bn1.weight.uniform_(-1.0, 1.5)                                    # negative scales too
+    st = R.Stem(trunk.conv1, trunk.bn1, trunk.relu, trunk.maxpool)
+    x = torch.randn(2, 3, 75, 101, device=dev)
+    outs = {}
+    for fused in (True, False):
+        monkeypatch.setattr(R, "FUSED_EPILOGUE", fused)
+        with torch.no_grad():
+            outs[fused] = st(x)
+    assert outs[True].shape == outs[False].shape == (2, 64, 19, 26)
+    assert float((outs[True] - outs[False]).abs().max()) < 1e-5
+    assert list(st.state_dict().keys()) == list(torch.nn.Sequential(trunk.conv1, trunk.bn1, trunk.relu, trunk.maxpool).state_dict().keys())
+
+
+# ------------------------------------------------------------------------------------------------
+# IRNet heads: bilinear upsampling + ReLU
+# ------------------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("shape,factor", [((2, 32, 16, 16), 2), ((2, 32, 8, 8), 4), ((1, 3, 5, 7), 2), ((1, 3, 5, 7), 4), ((2, 2, 1, 1), 4),
+                                          ((1, 4, 9, 5), 3), ((1, 2, 6, 3), 1), ((3, 1, 33, 2), 2), ((1, 1, 2, 129), 4)])
+@pytest.mark.parametrize("relu", [False, True])
+def test_upsample_bilinear_equals_torch(shape, factor, relu):
+    from irn_amd import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(shape[2] * 7 + factor)
+    x = torch.randn(shape, generator=g)
+    up = torch.nn.Upsample(scale_factor=factor, mode="bilinear", align_corners=False)
+    want = up(x)
+    want_dev = up(x.to(dev)).cpu()
+    if relu:
+        want, want_dev = torch.relu(want), torch.relu(want_dev)
+    got = ops.upsample_bilinear(x.to(dev), factor, relu=relu).cpu()
+    assert got.shape == want.shape
+    assert float((got - want).abs().max()) <= 1e-6 * max(1.0, float(want.abs().max()))        # ATen on the CPU (the reference's run)
+    assert float((got - want_dev).abs().max()) <= 1e-6 * max(1.0, float(want.abs().max()))    # ATen on the device
+    # exact statement of the documented expression
+    h, w = shape[2:]
+    r = np.float32(1.0 / factor)
+    def axis(n_out, n_in):
+        src = np.maximum(r * (np.arange(n_out, dtype=np.float32) + np.float32(0.5)) - np.float32(0.5), np.float32(0)).astype(np.float32)
+        i0 = src.astype(np.int64)
+        return i0, i0 + (i0 < n_in - 1), (src - i0.astype(np.float32)).astype(np.float32)
+    y0, y1, ly = axis(h * factor, h)
+    x0, x1, lx = axis(w * factor, w)
+    a = x.numpy()
+    ly, lx = ly[:, None], lx[None, :]
+    one = np.float32(1)
+    top = (one - lx) * a[..., y0[:, None], x0[None, :]] + lx * a[..., y0[:, None], x1[None, :]]
+    bot = (one - lx) * a[..., y1[:, None], x0[None, :]] + lx * a[..., y1[:, None], x1[None, :]]
+    exact = ((one - ly) * top + ly * bot).astype(np.float32)
+    if relu:
+        exact = np.maximum(exact, 0)
+    assert np.array_equal(got.numpy(), exact)
+
+
+def test_upsample_refusals():
+    from irn_amd import ops
+    dev = _dev()
+    with pytest.raises(ValueError):
+        ops.upsample_bilinear(torch.zeros(1, 1, 4, 4), 2)
+    with pytest.raises(ValueError):
+        ops.upsample_bilinear(torch.zeros(1, 1, 4, 4, device=dev).transpose(2, 3)[..., :2], 2)
+    with pytest.raises(RuntimeError):
+        ops.upsample_bilinear(torch.zeros(1, 1, 4, 4, device=dev), 0)
+    assert ops.upsample_bilinear(torch.zeros(0, 3, 4, 4, device=dev), 2).shape == (0, 3, 8, 8)
