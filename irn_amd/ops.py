@@ -153,6 +153,8 @@ def upsample_bilinear(x, factor, relu=False):
     """nn.Upsample(scale_factor=factor, mode='bilinear', align_corners=False) (+ ReLU) of the IRNet heads in one pass
     (irn_upsample_bilinear; reference net/resnet50_irn.py:36-48, :72-84).  x: GPU fp32 [..., h, w] -> [..., h*factor, w*factor]."""
     _need_f32_contig(x, "upsample_bilinear: x", 2)
+    if int(factor) != factor or not 1 <= factor <= 64:
+        raise ValueError("upsample_bilinear: integer factor in 1..64 expected, got %r" % (factor,))
     factor = int(factor)
     h, w = int(x.shape[-2]), int(x.shape[-1])
     out = torch.empty(tuple(x.shape[:-2]) + (h * factor, w * factor), dtype=torch.float32, device=x.device)

@@ -255,6 +255,7 @@ def test_upsample_refusals():
         ops.upsample_bilinear(torch.zeros(1, 1, 4, 4), 2)
     with pytest.raises(ValueError):
         ops.upsample_bilinear(torch.zeros(1, 1, 4, 4, device=dev).transpose(2, 3)[..., :2], 2)
-    with pytest.raises(RuntimeError):
-        ops.upsample_bilinear(torch.zeros(1, 1, 4, 4, device=dev), 0)
+    for bad in (0, 2.5, 65):
+        with pytest.raises(ValueError):
+            ops.upsample_bilinear(torch.zeros(1, 1, 4, 4, device=dev), bad)
     assert ops.upsample_bilinear(torch.zeros(0, 3, 4, 4, device=dev), 2).shape == (0, 3, 8, 8)
