@@ -99,6 +99,8 @@ camprof|e2eprof)
   find $OUT/prof_$leg -name "*kernel_stats*" -exec cp {} $OUT/${leg}_kernel_stats.csv \;
   find $OUT/prof_$leg -name "${leg}_kernel_trace.csv" -delete
   python tools/kernel_classes.py $OUT/${leg}_kernel_stats.csv ;;
+epibench)
+  timeout 300 python tools/epilogue_bench.py 2>&1 | grep -v MIOpen | tee $OUT/epilogue_bench.txt ;;
 fusedab)
   # trunk epilogue fused (irn_bn_act) vs composed PyTorch ops, same run otherwise
   for w in cam e2e; do for f in 1 0; do
