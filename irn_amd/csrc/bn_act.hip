@@ -1,6 +1,8 @@
 // Inference batch norm (+ residual) (+ ReLU) of the ResNet-50 trunk as ONE pass over the convolution's output, in place:
-//     x[n, c, :, :] = act(x[n, c, :, :] * scale[c] + shift[c] (+ res[n, c, :, :]))
-// with scale = weight / sqrt(running_var + eps), shift = bias - running_mean * scale folded by the caller.
+//     x[n, c, :, :] = act(x[n, c, :, :] * scale[c] + shift[c] (+ res[n, c, :, :] (* res_scale[c] + res_shift[c])))
+// with scale = weight / sqrt(running_var + eps), shift = bias - running_mean * scale folded by the caller; the residual may
+// carry a batch norm of its own (the projection shortcut of a stage's first unit, net/resnet50.py:50-51, whose output then
+// never exists as a tensor of its own).
 //
 // Replaces the elementwise tail of reference net/resnet50.py:35-55 (Bottleneck.forward: FixedBatchNorm :11-14 ->
 // `out += residual` -> ReLU) and of the stem (:87-89): three kernels and seven tensor transfers at the end of a
@@ -44,18 +46,26 @@ __device__ __forceinline__ unsigned div_by(unsigned n, const Div dv) {
 
 constexpr int kThreads = 256, kPieces = 4;       // 16-byte pieces per thread, a block-width apart
 
-template <bool HAS_RES, bool RELU>
+// (non-temporal loads of x / res were measured: faster for the one shape that exceeds the caches, 268 MB per tensor — 5.9 vs 5.3
+// TB/s with a residual — and 10-20 % slower for every smaller one, whose lines the convolution has just left in L2 / MALL;
+// profiles/r02_s19_epilogue_bench.txt)
+__device__ __forceinline__ f4v load_piece(const float *p, unsigned i) { return reinterpret_cast<const f4v *>(p)[i]; }
+
+// RES: 0 no residual, 1 residual added as it is, 2 residual through its own scale / shift first
+template <int RES, bool RELU>
 __global__ __launch_bounds__(kThreads) void bn_act_kernel(float *__restrict__ x, const float *__restrict__ res,
                                                           const float *__restrict__ scale, const float *__restrict__ shift,
+                                                          const float *__restrict__ res_scale, const float *__restrict__ res_shift,
                                                           unsigned n_pieces, unsigned hw, unsigned n_ch, Div by_hw, Div by_ch) {
+    constexpr bool HAS_RES = RES != 0;
     const unsigned base = blockIdx.x * (unsigned)(kThreads * kPieces) + threadIdx.x;
     f4v v[kPieces], r[kPieces];
 #pragma unroll
     for (int j = 0; j < kPieces; ++j) {
         const unsigned p = base + j * kThreads;
         if (p < n_pieces) {
-            v[j] = reinterpret_cast<const f4v *>(x)[p];
-            if (HAS_RES) r[j] = reinterpret_cast<const f4v *>(res)[p];
+            v[j] = load_piece(x, p);
+            if (HAS_RES) r[j] = load_piece(res, p);
         }
     }
 #pragma unroll
@@ -74,12 +84,22 @@ __global__ __launch_bounds__(kThreads) void bn_act_kernel(float *__restrict__ x,
             s1 = scale[c1];
             b1 = shift[c1];
         }
+        float rs0 = 1.f, rb0 = 0.f, rs1 = 1.f, rb1 = 0.f;
+        if (RES == 2) {
+            rs0 = rs1 = res_scale[c0];
+            rb0 = rb1 = res_shift[c0];
+            if (left < 4u) {
+                rs1 = res_scale[c1];
+                rb1 = res_shift[c1];
+            }
+        }
         f4v o;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
             const bool upper = (unsigned)k >= left;
             float y = fmaf(v[j][k], upper ? s1 : s0, upper ? b1 : b0);
-            if (HAS_RES) y += r[j][k];
+            if (RES == 1) y += r[j][k];
+            if (RES == 2) y += fmaf(r[j][k], upper ? rs1 : rs0, upper ? rb1 : rb0);
             if (RELU) y = y < 0.f ? 0.f : y;      // NaN stays NaN, like torch.relu
             o[k] = y;
         }
@@ -88,33 +108,35 @@ __global__ __launch_bounds__(kThreads) void bn_act_kernel(float *__restrict__ x,
 }
 
 // one element per thread from `first` on: the last numel % 4 elements, and tensors whose planes are shorter than a piece
-template <bool HAS_RES, bool RELU>
+template <int RES, bool RELU>
 __global__ void bn_act_tail_kernel(float *__restrict__ x, const float *__restrict__ res, const float *__restrict__ scale,
-                                   const float *__restrict__ shift, unsigned first, unsigned numel, unsigned hw, unsigned n_ch) {
+                                   const float *__restrict__ shift, const float *__restrict__ res_scale,
+                                   const float *__restrict__ res_shift, unsigned first, unsigned numel, unsigned hw, unsigned n_ch) {
     const unsigned e = first + blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= numel) return;
     const unsigned c = (e / hw) % n_ch;
     float y = fmaf(x[e], scale[c], shift[c]);
-    if (HAS_RES) y += res[e];
+    if (RES == 1) y += res[e];
+    if (RES == 2) y += fmaf(res[e], res_scale[c], res_shift[c]);
     if (RELU) y = y < 0.f ? 0.f : y;
     x[e] = y;
 }
 
-template <bool HAS_RES, bool RELU>
-int launch(float *x, const float *res, const float *scale, const float *shift, unsigned numel, unsigned hw, unsigned n_ch,
-           hipStream_t stream) {
+template <int RES, bool RELU>
+int launch(float *x, const float *res, const float *scale, const float *shift, const float *res_scale, const float *res_shift,
+           unsigned numel, unsigned hw, unsigned n_ch, hipStream_t stream) {
     // planes shorter than a piece (a piece would span more than two of them) go element by element; such maps carry no time
     const unsigned n_pieces = hw >= 4u ? numel / 4u : 0u;
     if (n_pieces) {
         const unsigned blocks = (n_pieces + kThreads * kPieces - 1) / (kThreads * kPieces);
-        hipLaunchKernelGGL((bn_act_kernel<HAS_RES, RELU>), dim3(blocks), dim3(kThreads), 0, stream, x, res, scale, shift, n_pieces,
-                           hw, n_ch, make_div(hw), make_div(n_ch));
+        hipLaunchKernelGGL((bn_act_kernel<RES, RELU>), dim3(blocks), dim3(kThreads), 0, stream, x, res, scale, shift, res_scale,
+                           res_shift, n_pieces, hw, n_ch, make_div(hw), make_div(n_ch));
         IRN_LAUNCH_CHECK("bn_act_kernel");
     }
     const unsigned rest = numel - n_pieces * 4u;
     if (rest) {
-        hipLaunchKernelGGL((bn_act_tail_kernel<HAS_RES, RELU>), dim3((rest + 63u) / 64u), dim3(64), 0, stream, x, res, scale, shift,
-                           n_pieces * 4u, numel, hw, n_ch);
+        hipLaunchKernelGGL((bn_act_tail_kernel<RES, RELU>), dim3((rest + 63u) / 64u), dim3(64), 0, stream, x, res, scale, shift,
+                           res_scale, res_shift, n_pieces * 4u, numel, hw, n_ch);
         IRN_LAUNCH_CHECK("bn_act_tail_kernel");
     }
     return IRN_OK;
@@ -123,21 +145,28 @@ int launch(float *x, const float *res, const float *scale, const float *shift, u
 }  // namespace
 }  // namespace irn
 
-extern "C" int irn_bn_act(float *x_dev, const float *res_dev, const float *scale_dev, const float *shift_dev, int64_t n_images,
-                          int n_channels, int64_t plane_elems, int relu, void *stream) {
+extern "C" int irn_bn_act(float *x_dev, const float *res_dev, const float *scale_dev, const float *shift_dev,
+                          const float *res_scale_dev, const float *res_shift_dev, int64_t n_images, int n_channels,
+                          int64_t plane_elems, int relu, void *stream) {
     using namespace irn;
     if (!x_dev || !scale_dev || !shift_dev) return fail(IRN_ERR_ARG, "irn_bn_act: null pointer");
+    if ((res_scale_dev != nullptr) != (res_shift_dev != nullptr) || (res_scale_dev && !res_dev))
+        return fail(IRN_ERR_ARG, "irn_bn_act: res_scale and res_shift come together, and only with a residual");
     if (n_images < 0 || n_channels <= 0 || plane_elems < 0) return fail(IRN_ERR_ARG, "irn_bn_act: negative size");
     if (((uintptr_t)x_dev | (uintptr_t)res_dev) & 15u) return fail(IRN_ERR_ARG, "irn_bn_act: tensors must be 16-byte aligned");
     const int64_t numel = n_images * n_channels * plane_elems;
     if (numel == 0) return IRN_OK;
     if (numel >= (1ll << 31)) return fail(IRN_ERR_ARG, "irn_bn_act: %lld elements; at most 2^31 - 1 per call", (long long)numel);
-    const unsigned hw = (unsigned)plane_elems, n_ch = (unsigned)n_channels;
+    const unsigned hw = (unsigned)plane_elems, n_ch = (unsigned)n_channels, n = (unsigned)numel;
     hipStream_t s = (hipStream_t)stream;
-    if (res_dev && relu) return launch<true, true>(x_dev, res_dev, scale_dev, shift_dev, (unsigned)numel, hw, n_ch, s);
-    if (res_dev) return launch<true, false>(x_dev, res_dev, scale_dev, shift_dev, (unsigned)numel, hw, n_ch, s);
-    if (relu) return launch<false, true>(x_dev, res_dev, scale_dev, shift_dev, (unsigned)numel, hw, n_ch, s);
-    return launch<false, false>(x_dev, res_dev, scale_dev, shift_dev, (unsigned)numel, hw, n_ch, s);
+    const int mode = !res_dev ? 0 : (res_scale_dev ? 2 : 1);
+#define IRN_BN_ACT_CASE(RES_MODE)                                                                                                   \
+    return relu ? launch<RES_MODE, true>(x_dev, res_dev, scale_dev, shift_dev, res_scale_dev, res_shift_dev, n, hw, n_ch, s)       \
+                : launch<RES_MODE, false>(x_dev, res_dev, scale_dev, shift_dev, res_scale_dev, res_shift_dev, n, hw, n_ch, s)
+    if (mode == 0) IRN_BN_ACT_CASE(0);
+    if (mode == 1) IRN_BN_ACT_CASE(1);
+    IRN_BN_ACT_CASE(2);
+#undef IRN_BN_ACT_CASE
 }
 
 // ------------------------------------------------------------------------------------------------

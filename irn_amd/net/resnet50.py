@@ -53,16 +53,17 @@ class FrozenBatchNorm(nn.BatchNorm2d):
             self._folded = (key, scale.float().contiguous(), shift.float().contiguous())
         return self._folded[1], self._folded[2]
 
-    def apply_(self, x, residual=None, relu=False):
-        """act(forward(x) (+ residual)), overwriting x on the inference path (x must be a tensor nobody else reads:
-        the output of the convolution in front of this layer)."""
+    def apply_(self, x, residual=None, relu=False, residual_bn=None):
+        """act(forward(x) (+ r)) with r = residual, or residual_bn.forward(residual) when a second layer is given (the
+        projection shortcut's batch norm); overwrites x on the inference path (x must be a tensor nobody else reads: the
+        output of the convolution in front of this layer)."""
         if _fused(x) and (residual is None or (residual.is_contiguous() and residual.dtype == x.dtype)):
             from .. import ops          # the HIP library; raises if it has not been built — there is no other GPU path
             scale, shift = self.folded()
-            return ops.bn_act_(x, scale, shift, residual, relu)
+            return ops.bn_act_(x, scale, shift, residual, relu, None if residual_bn is None else residual_bn.folded())
         y = self.forward(x)
         if residual is not None:
-            y = y + residual
+            y = y + (residual if residual_bn is None else residual_bn.forward(residual))
         return F.relu(y) if relu else y
 
 
@@ -109,8 +110,10 @@ class Bottleneck(nn.Module):
     def forward(self, x):
         y = self.bn1.apply_(self.conv1(x), relu=True)
         y = self.bn2.apply_(self.conv2(y), relu=True)
-        skip = x if self.downsample is None else self.downsample[1].apply_(self.downsample[0](x))
-        return self.bn3.apply_(self.conv3(y), residual=skip, relu=True)
+        if self.downsample is None:
+            return self.bn3.apply_(self.conv3(y), residual=x, relu=True)
+        # the shortcut's batch norm rides in the same pass: its output never exists as a tensor
+        return self.bn3.apply_(self.conv3(y), residual=self.downsample[0](x), relu=True, residual_bn=self.downsample[1])
 
 
 def _stage(c_in, planes, n_blocks, stride, dilation):

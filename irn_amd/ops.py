@@ -101,15 +101,21 @@ def cam_merge(outputs, size, label):
     return keys, cam, hi
 
 
-def bn_act_(x, scale, shift, residual=None, relu=True):
+def bn_act_(x, scale, shift, residual=None, relu=True, residual_affine=None):
     """Inference batch norm (+ residual) (+ ReLU) in one pass, IN PLACE on a convolution's output (irn_bn_act):
-    ``x = act(x * scale[c] + shift[c] (+ residual))`` — the elementwise tail of reference net/resnet50.py:35-55.
-    x, residual: GPU fp32 [N, C, ...] contiguous; scale, shift: GPU fp32 [C].  Returns x."""
+    ``x = act(x * scale[c] + shift[c] (+ r))`` — the elementwise tail of reference net/resnet50.py:35-55.  ``r`` is the
+    residual, or ``residual * rs[c] + rb[c]`` with ``residual_affine = (rs, rb)`` (the projection shortcut's batch norm).
+    x, residual: GPU fp32 [N, C, ...] contiguous; scale, shift, rs, rb: GPU fp32 [C].  Returns x."""
     _need_cuda(x, "x")
     if x.dtype != torch.float32 or not x.is_contiguous() or x.dim() < 2:
         raise ValueError("bn_act_: x must be a contiguous fp32 [N, C, ...] tensor, got %s %s" % (x.dtype, tuple(x.shape)))
     n_ch = int(x.shape[1])
-    for name, t in (("scale", scale), ("shift", shift)):
+    consts = [("scale", scale), ("shift", shift)]
+    if residual_affine is not None:
+        if residual is None:
+            raise ValueError("bn_act_: residual_affine without a residual")
+        consts += [("residual scale", residual_affine[0]), ("residual shift", residual_affine[1])]
+    for name, t in consts:
         if t.device != x.device or t.dtype != torch.float32 or not t.is_contiguous() or t.numel() != n_ch:
             raise ValueError("bn_act_: %s must be a contiguous fp32 [%d] tensor on %s" % (name, n_ch, x.device))
     if residual is not None and (residual.shape != x.shape or residual.dtype != torch.float32 or residual.device != x.device
@@ -117,13 +123,14 @@ def bn_act_(x, scale, shift, residual=None, relu=True):
         raise ValueError("bn_act_: residual must match x (shape %s, fp32, contiguous, same device)" % (tuple(x.shape),))
     n_img = int(x.shape[0])
     plane = x[0, 0].numel() if n_img else 0
+    rs, rb = (None, None) if residual_affine is None else (residual_affine[0].data_ptr(), residual_affine[1].data_ptr())
     # the entry point takes at most 2^31 - 1 elements: larger batches go image group by image group
     per = max(1, (2 ** 31 - 1) // max(1, n_ch * plane))
     with torch.cuda.device(x.device):
         for i in range(0, n_img, per):
             xi = x[i:i + per]
             ri = None if residual is None else residual[i:i + per]
-            check(lib.irn_bn_act(xi.data_ptr(), None if ri is None else ri.data_ptr(), scale.data_ptr(), shift.data_ptr(),
+            check(lib.irn_bn_act(xi.data_ptr(), None if ri is None else ri.data_ptr(), scale.data_ptr(), shift.data_ptr(), rs, rb,
                                  int(xi.shape[0]), n_ch, plane, 1 if relu else 0, _stream()))
     return x
 

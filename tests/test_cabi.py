@@ -101,11 +101,13 @@ def test_argument_validation_of_the_newer_entry_points():
     assert L.irn_bicubic_plan(8, 4, C.byref(ks), None, None, None, 0) == 0 and ks.value == 9   # support 4 -> 2*4+1
     lo = (C.c_int32 * 4)()
     assert L.irn_bicubic_plan(8, 4, C.byref(ks), lo, lo, lo, 3) == 1          # weights array too small
-    assert L.irn_bn_act(None, None, one, one, 1, 4, 16, 1, None) == 1 and b"irn_bn_act" in L.irn_last_error()
-    assert L.irn_bn_act(one, None, one, one, 1, 0, 16, 1, None) == 1               # no channels
-    assert L.irn_bn_act(C.c_void_p(68), None, one, one, 1, 4, 16, 1, None) == 1    # not 16-byte aligned
-    assert L.irn_bn_act(one, None, one, one, 1 << 20, 2048, 4096, 1, None) == 1 and b"2^31" in L.irn_last_error()
-    assert L.irn_bn_act(one, None, one, one, 0, 4, 16, 1, None) == 0               # empty batch: nothing to do
+    assert L.irn_bn_act(None, None, one, one, None, None, 1, 4, 16, 1, None) == 1 and b"irn_bn_act" in L.irn_last_error()
+    assert L.irn_bn_act(one, None, one, one, None, None, 1, 0, 16, 1, None) == 1               # no channels
+    assert L.irn_bn_act(C.c_void_p(68), None, one, one, None, None, 1, 4, 16, 1, None) == 1    # not 16-byte aligned
+    assert L.irn_bn_act(one, None, one, one, None, None, 1 << 20, 2048, 4096, 1, None) == 1 and b"2^31" in L.irn_last_error()
+    assert L.irn_bn_act(one, None, one, one, None, None, 0, 4, 16, 1, None) == 0   # empty batch: nothing to do
+    assert L.irn_bn_act(one, None, one, one, one, one, 1, 4, 16, 1, None) == 1      # residual constants without a residual
+    assert L.irn_bn_act(one, one, one, one, one, None, 1, 4, 16, 1, None) == 1      # only one of the two
     assert L.irn_stem_pool(None, one, one, 1, 64, 8, 8, one, None) == 1 and b"irn_stem_pool" in L.irn_last_error()
     assert L.irn_stem_pool(one, one, one, 1, 64, 0, 8, one, None) == 1
     assert L.irn_stem_pool(one, one, one, 0, 64, 8, 8, one, None) == 0             # empty batch

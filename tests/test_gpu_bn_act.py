@@ -82,6 +82,51 @@ def test_bn_act_refuses_what_it_cannot_do():
     assert ops.bn_act_(torch.zeros(0, 4, 3, 3, device=dev), s, s).numel() == 0
 
 
+@pytest.mark.parametrize("shape", [(2, 8, 16, 16), (3, 5, 7, 9), (2, 3, 1, 5), (4, 6, 1, 1), (2, 64, 33, 47)])
+@pytest.mark.parametrize("relu", [False, True])
+def test_bn_act_with_a_batch_norm_on_the_residual(shape, relu):
+    """The projection shortcut's batch norm in the same pass: fl(fma(x, s, b)) + fl(fma(res, rs, rb)), bit for bit."""
+    from irn_amd import ops
+    dev = _dev()
+    x, res, scale, shift = _case(shape, 31 + shape[1], True)
+    g = torch.Generator().manual_seed(77)
+    rs, rb = torch.rand(shape[1], generator=g) * 2 - 0.5, torch.randn(shape[1], generator=g)
+    view = (1, -1, 1, 1)
+    a = (x.double() * scale.double().view(view) + shift.double().view(view)).float()
+    b = (res.double() * rs.double().view(view) + rb.double().view(view)).float()
+    want = a + b
+    if relu:
+        want = torch.clamp_min(want, 0)
+    got = ops.bn_act_(x.to(dev), scale.to(dev), shift.to(dev), res.to(dev), relu, (rs.to(dev), rb.to(dev)))
+    assert torch.equal(got.cpu(), want), float((got.cpu() - want).abs().max())
+    with pytest.raises(ValueError):
+        ops.bn_act_(x.to(dev), scale.to(dev), shift.to(dev), None, relu, (rs.to(dev), rb.to(dev)))
+
+
+def test_bottleneck_with_projection_fused_vs_composed(monkeypatch):
+    from irn_amd.net import resnet50 as R
+    dev = _dev()
+    torch.manual_seed(8)
+    unit = R.Bottleneck(64, 32, stride=2, project=True).to(dev).eval()
+    with torch.no_grad():
+        for m in unit.modules():
+            if isinstance(m, R.FrozenBatchNorm):
+                m.running_mean.normal_()
+                m.running_var.uniform_(0.3, 2.0)
+                m.weight.uniform_(-1.0, 1.5)
+                m.bias.normal_()
+    x = torch.randn(3, 64, 19, 23, device=dev)
+    outs = {}
+    for fused in (True, False):
+        monkeypatch.setattr(R, "FUSED_EPILOGUE", fused)
+        with torch.no_grad():
+            outs[fused] = unit(x)
+    assert outs[True].shape == (3, 128, 10, 12)
+    assert float((outs[True] - outs[False]).abs().max()) < 1e-5 * max(1.0, float(outs[False].abs().max()))
+    y = unit(x.requires_grad_(True))                                             # autograd on: composed path, differentiable
+    assert y.requires_grad and float((y.detach() - outs[False]).abs().max()) == 0.0
+
+
 @pytest.mark.parametrize("shape", [(2, 16, 9, 13), (1, 32, 8, 8)])
 def test_frozen_batch_norm_apply_equals_composed_ops(shape):
     """FrozenBatchNorm.apply_ on the device (fused) vs F.batch_norm -> + skip -> relu on the device and on the CPU."""

@@ -322,3 +322,23 @@ def test_frozen_batch_norm_folding_and_composed_path():
     with torch.no_grad():
         bn.weight.mul_(2.0)
     assert float((bn.folded()[0] - 2 * key).abs().max()) < 1e-6
+
+
+def test_apply_with_a_batch_norm_on_the_residual_composed_path():
+    """apply_(x, residual, residual_bn=...) off the device = bn(x) + bn_r(residual) -> ReLU: the projection shortcut of
+    net/resnet50.py:50-55."""
+    import torch.nn.functional as F
+    from irn_amd.net import resnet50 as R
+    torch.manual_seed(2)
+    bn, bn_r = R.FrozenBatchNorm(4), R.FrozenBatchNorm(4)
+    with torch.no_grad():
+        for m in (bn, bn_r):
+            m.running_mean.normal_()
+            m.running_var.uniform_(0.2, 2.0)
+            m.weight.normal_()
+            m.bias.normal_()
+        x, r = torch.randn(2, 4, 3, 5), torch.randn(2, 4, 3, 5)
+        assert torch.equal(bn.apply_(x, residual=r, relu=True, residual_bn=bn_r), F.relu(bn(x) + bn_r(r)))
+        unit = R.Bottleneck(8, 4, stride=2, project=True).eval()
+        y = unit(torch.randn(1, 8, 9, 9))
+        assert y.shape == (1, 16, 5, 5) and float(y.min()) >= 0.0

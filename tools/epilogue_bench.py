@@ -43,6 +43,8 @@ for shape in ((16, 256, 128, 128), (16, 512, 64, 64), (16, 2048, 32, 32), (16, 6
              timed(lambda: F.relu(F.batch_norm(x, mean, var, w, b, False, 0.0, 1e-5), inplace=True)))
         line("bn_act + residual %s" % (shape,), timed(lambda: ops.bn_act_(x, scale, shift, res, True)), 3 * nb,
              timed(lambda: F.relu(F.batch_norm(x, mean, var, w, b, False, 0.0, 1e-5) + res, inplace=True)))
+        line("bn_act + bn(residual) %s" % (shape,), timed(lambda: ops.bn_act_(x, scale, shift, res, True, (scale, shift))), 3 * nb,
+             timed(lambda: F.relu(F.batch_norm(x, mean, var, w, b, False, 0.0, 1e-5) + F.batch_norm(res, mean, var, w, b, False, 0.0, 1e-5), inplace=True)))
 for shape in ((16, 64, 256, 256), (16, 64, 512, 512)):
     x = torch.randn(shape, device=dev)
     c = shape[1]

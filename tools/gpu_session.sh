@@ -100,7 +100,10 @@ camprof|e2eprof)
   find $OUT/prof_$leg -name "${leg}_kernel_trace.csv" -delete
   python tools/kernel_classes.py $OUT/${leg}_kernel_stats.csv ;;
 epibench)
-  timeout 300 python tools/epilogue_bench.py 2>&1 | grep -v MIOpen | tee $OUT/epilogue_bench.txt ;;
+  for lib in ${AB_LIBS:-libirn_hip.so}; do
+    [ -f irn_amd/lib/$lib ] || continue
+    echo "== $lib"; IRN_HIP_LIB=$PWD/irn_amd/lib/$lib timeout 300 python tools/epilogue_bench.py 2>&1 | grep -v MIOpen | tee $OUT/epilogue_bench_${lib%.so}.txt
+  done ;;
 fusedab)
   # trunk epilogue fused (irn_bn_act) vs composed PyTorch ops, same run otherwise
   for w in cam e2e; do for f in 1 0; do
