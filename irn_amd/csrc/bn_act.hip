@@ -173,34 +173,53 @@ extern "C" int irn_bn_act(float *x_dev, const float *res_dev, const float *scale
 // Stem: batch norm + ReLU + 3x3 / stride 2 / pad 1 max pool of reference net/resnet50.py:94-97 (the nets' stage1,
 // net/resnet50_cam.py:14, net/resnet50_irn.py:15) in one pass: the largest activation of the trunk (64 x H/2 x W/2) is
 // read once and a quarter of it written, instead of read + written by the epilogue and read again by the pool.
-// One output per thread; the nine taps of neighbouring outputs overlap and are served by the vector L1.
 // ------------------------------------------------------------------------------------------------
 namespace irn {
 namespace {
 
+// A workgroup produces a 4 x 64 tile of outputs from a 9 x 129 tile of inputs: the inputs are read once, row-contiguous
+// (consecutive lanes = consecutive floats), pass through batch norm + ReLU on their way into LDS (out-of-image taps
+// become 0, the ReLU's floor), and every thread takes its 3 x 3 window from there as 8-byte reads (one output = columns
+// 2x-1 .. 2x+1 of the tile; lanes a pair of columns apart never share a bank).
+constexpr int kPoolW = 64, kPoolH = 4, kPoolInW = 2 * kPoolW + 1, kPoolInH = 2 * kPoolH + 1, kPoolLdsW = 132;
+
 __global__ __launch_bounds__(256) void stem_pool_kernel(const float *__restrict__ x, const float *__restrict__ scale,
                                                         const float *__restrict__ shift, float *__restrict__ out, int n_ch, int h,
                                                         int w, int ho, int wo) {
-    const int xo = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int yo = blockIdx.y * 4 + (threadIdx.x >> 6);
+    __shared__ __attribute__((aligned(16))) float tile[kPoolInH][kPoolLdsW];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int xo0 = blockIdx.x * kPoolW, yo0 = blockIdx.y * kPoolH;
     const unsigned plane = blockIdx.z;
-    if (xo >= wo || yo >= ho) return;
     const float s = scale[plane % (unsigned)n_ch], b = shift[plane % (unsigned)n_ch];
     const float *src = x + (size_t)plane * h * w;
-    float m = 0.f;                                   // ReLU's floor: max(0, taps) = relu(max(taps))
+    const int x_in0 = 2 * xo0 - 1, y_in0 = 2 * yo0 - 1;
+    // tile[r][c + 1] holds input (y_in0 + r, x_in0 + c); column 0 is padding so that a thread's window starts 8-byte aligned
+#pragma unroll
+    for (int i = threadIdx.x; i < kPoolInH * kPoolInW; i += 256) {
+        const int r = i / kPoolInW, c = i - r * kPoolInW;
+        const int yy = y_in0 + r, xx = x_in0 + c;
+        float v = 0.f;
+        if (yy >= 0 && yy < h && xx >= 0 && xx < w) {
+            v = fmaf(src[(size_t)yy * w + xx], s, b);
+            v = v < 0.f ? 0.f : v;                                    // NaN stays NaN
+        }
+        tile[r][c + 1] = v;
+    }
+    __syncthreads();
+    const int xo = xo0 + tx, yo = yo0 + ty;
+    if (xo >= wo || yo >= ho) return;
+    float m = 0.f;
     bool nan = false;
 #pragma unroll
     for (int ky = 0; ky < 3; ++ky) {
-        const int y = 2 * yo - 1 + ky;
-        if (y < 0 || y >= h) continue;
-#pragma unroll
-        for (int kx = 0; kx < 3; ++kx) {
-            const int xx = 2 * xo - 1 + kx;
-            if (xx < 0 || xx >= w) continue;
-            const float v = fmaf(src[(size_t)y * w + xx], s, b);
-            nan |= v != v;
-            m = v > m ? v : m;
-        }
+        // columns 2tx .. 2tx+3 of the LDS row = inputs x_in0 + 2tx - 1 .. + 2: the window is the last three
+        const float2 lo = *reinterpret_cast<const float2 *>(&tile[2 * ty + ky][2 * tx]);
+        const float2 hi = *reinterpret_cast<const float2 *>(&tile[2 * ty + ky][2 * tx + 2]);
+        const float v0 = lo.y, v1 = hi.x, v2 = hi.y;
+        nan |= (v0 != v0) | (v1 != v1) | (v2 != v2);
+        m = v0 > m ? v0 : m;
+        m = v1 > m ? v1 : m;
+        m = v2 > m ? v2 : m;
     }
     out[((size_t)plane * ho + yo) * wo + xo] = nan ? __builtin_nanf("") : m;      // torch's max pool propagates NaN
 }
