@@ -452,6 +452,59 @@ def instance_labels(cams, keys, edge, dp, out_hw, beta=10, exp_times=8, radius=5
 
 
 # ------------------------------------------------------------------------------------------
+# Elementwise tails of the trunk and the heads  (reference net/resnet50.py:11-14, :35-55, :94-97;
+# net/resnet50_irn.py:36-48, :72-84) — what irn_bn_act / irn_stem_pool / irn_upsample_bilinear compute.
+# Pinned on tests/golden/trunk_ops.npz, written by the reference's own FixedBatchNorm and the torch
+# modules it instantiates.
+# ------------------------------------------------------------------------------------------
+
+def fold_batch_norm(weight, bias, mean, var, eps=1e-5):
+    """FixedBatchNorm (net/resnet50.py:11-14: F.batch_norm with the running statistics) as y = x * scale + shift:
+    scale = w / sqrt(var + eps), shift = b - mean * scale, in fp64, rounded to fp32 once."""
+    w, b, mean, var = (np.asarray(t, np.float64) for t in (weight, bias, mean, var))
+    scale = w / np.sqrt(var + eps)
+    return scale.astype(np.float32), (b - mean * scale).astype(np.float32)
+
+
+def bn_act(x, scale, shift, res=None, relu=True, res_affine=None):
+    """Bottleneck.forward's tail (net/resnet50.py:35-55): bn -> (+ residual | + bn_d(residual)) -> ReLU with the batch
+    norms folded: one fp32 fused multiply-add per operand, one fp32 addition."""
+    x = np.asarray(x, np.float32)
+    bc = (1, -1) + (1,) * (x.ndim - 2)
+    y = _fma32(x, np.asarray(scale, np.float32).reshape(bc), np.asarray(shift, np.float32).reshape(bc))
+    if res is not None:
+        r = np.asarray(res, np.float32)
+        if res_affine is not None:
+            r = _fma32(r, np.asarray(res_affine[0], np.float32).reshape(bc), np.asarray(res_affine[1], np.float32).reshape(bc))
+        y = (y + r).astype(np.float32)
+    return np.maximum(y, np.float32(0)) if relu else y
+
+
+def stem_pool(x, scale, shift):
+    """conv1's tail (net/resnet50.py:94-97): bn1 -> ReLU -> MaxPool2d(3, stride 2, padding 1) (:66); padding taps never win."""
+    y = bn_act(x, scale, shift, relu=True)
+    n, c, h, w = y.shape
+    ho, wo = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+    pad = np.full((n, c, 2 * ho + 1, 2 * wo + 1), -np.inf, np.float32)
+    pad[:, :, 1:h + 1, 1:w + 1] = y
+    out = np.full((n, c, ho, wo), -np.inf, np.float32)
+    for ky in range(3):
+        for kx in range(3):
+            out = np.maximum(out, pad[:, :, ky:ky + 2 * ho:2, kx:kx + 2 * wo:2])
+    return out
+
+
+def head_upsample_relu(x, factor):
+    """nn.Upsample(scale_factor, 'bilinear', align_corners=False) -> ReLU of the IRNet heads (net/resnet50_irn.py:36-48,
+    :72-84) with the multiply-add pattern of `_bilinear_taps`; ATen's own pattern varies with the loop specialisation it
+    picks for a shape, so this is within 2 ulp of it, not bit-equal (tests/golden/trunk_ops.npz)."""
+    x = np.asarray(x, np.float32)
+    lead, (h, w) = x.shape[:-2], x.shape[-2:]
+    up = upsample_bilinear(x.reshape((-1, 1, h, w)), scale=int(factor))
+    return np.maximum(up.reshape(lead + (h * factor, w * factor)), np.float32(0))
+
+
+# ------------------------------------------------------------------------------------------
 # CAM merge  (reference step/make_cam.py:32-52)
 # ------------------------------------------------------------------------------------------
 

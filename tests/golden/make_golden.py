@@ -421,10 +421,66 @@ def gen_msf():
     np.savez_compressed(os.path.join(OUT, "msf.npz"), **out)
 
 
+def gen_trunk_ops():
+    """The elementwise tails of the reference's trunk and heads, run by the reference's own modules on seeded tensors
+    standing in for the convolutions' outputs: FixedBatchNorm -> += residual -> ReLU (net/resnet50.py:11-14, :35-55, with
+    and without the projection shortcut's batch norm :50-51), conv1's tail bn1 -> relu -> maxpool (:94-97), and the heads'
+    Upsample -> ReLU (net/resnet50_irn.py:36-48, :72-84)."""
+    import net.resnet50 as r50
+    g = torch.Generator().manual_seed(21)
+
+    def bn(c):
+        m = r50.FixedBatchNorm(c)
+        with torch.no_grad():
+            m.weight.copy_(torch.rand(c, generator=g) * 2 - 0.5)
+            m.bias.copy_(torch.randn(c, generator=g))
+            m.running_mean.copy_(torch.randn(c, generator=g))
+            m.running_var.copy_(torch.rand(c, generator=g) + 0.05)
+        return m
+
+    def params(prefix, m):
+        return {prefix + "_w": m.weight.detach().numpy(), prefix + "_b": m.bias.detach().numpy(),
+                prefix + "_mean": m.running_mean.numpy(), prefix + "_var": m.running_var.numpy(),
+                prefix + "_eps": np.float64(m.eps)}
+
+    out = {}
+    relu = torch.nn.ReLU(inplace=True)
+    with torch.no_grad():
+        for tag, shape in (("a", (2, 6, 9, 13)), ("b", (1, 5, 1, 3)), ("c", (3, 4, 8, 8))):
+            x = torch.randn(shape, generator=g)
+            res = torch.randn(shape, generator=g)
+            m, md = bn(shape[1]), bn(shape[1])
+            out.update(params("bn_" + tag, m))
+            out.update(params("bnd_" + tag, md))
+            out["x_" + tag], out["res_" + tag] = x.numpy().copy(), res.numpy().copy()
+            out["bn_relu_" + tag] = relu(m(x)).numpy().copy()                    # Bottleneck.forward :37-43
+            y = m(x)
+            y += res                                                             # :52
+            out["bn_add_relu_" + tag] = relu(y).numpy().copy()                   # :53
+            y = m(x)
+            y += md(res)                                                         # :49-52 (downsample = conv, FixedBatchNorm)
+            out["bn_addbn_relu_" + tag] = relu(y).numpy().copy()
+            out["bn_plain_" + tag] = m(x).numpy().copy()
+        pool = torch.nn.MaxPool2d(kernel_size=3, stride=2, padding=1)            # net/resnet50.py:66
+        for tag, shape in (("s1", (2, 4, 12, 17)), ("s2", (1, 3, 7, 8)), ("s3", (1, 2, 1, 1))):
+            x = torch.randn(shape, generator=g)
+            m = bn(shape[1])
+            out.update(params("stem_" + tag, m))
+            out["stem_x_" + tag] = x.numpy().copy()
+            out["stem_out_" + tag] = pool(relu(m(x))).numpy().copy()             # :94-97
+        for tag, shape, f in (("u2", (2, 3, 7, 5), 2), ("u4", (1, 4, 6, 9), 4), ("u2b", (1, 2, 1, 1), 2)):
+            x = torch.randn(shape, generator=g)
+            up = torch.nn.Upsample(scale_factor=f, mode="bilinear", align_corners=False)   # net/resnet50_irn.py:36
+            out["up_x_" + tag] = x.numpy().copy()
+            out["up_f_" + tag] = np.int64(f)
+            out["up_out_" + tag] = relu(up(x)).numpy().copy()
+    np.savez_compressed(os.path.join(OUT, "trunk_ops.npz"), **out)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", nargs="*", default=None,
-                    help="subset of: path affinity affinity_grad walk walk128 semseg instance cam_merge nets nets512 msf pair_disp; or walk case names")
+                    help="subset of: path affinity affinity_grad walk walk128 semseg instance cam_merge nets nets512 msf pair_disp trunk_ops; or walk case names")
     a = ap.parse_args()
     _install_reference()
     torch.set_num_threads(os.cpu_count())
@@ -458,6 +514,8 @@ def main():
         gen_msf()
     if want("pair_disp"):
         gen_pair_disp()
+    if want("trunk_ops"):
+        gen_trunk_ops()
 
 
 if __name__ == "__main__":

@@ -304,3 +304,62 @@ def test_upsample_refusals():
         with pytest.raises(ValueError):
             ops.upsample_bilinear(torch.zeros(1, 1, 4, 4, device=dev), bad)
     assert ops.upsample_bilinear(torch.zeros(0, 3, 4, 4, device=dev), 2).shape == (0, 3, 8, 8)
+
+
+# ------------------------------------------------------------------------------------------------
+# against the oracle and the reference's own modules (tests/golden/trunk_ops.npz)
+# ------------------------------------------------------------------------------------------------
+
+def test_trunk_tails_hip_vs_oracle_and_reference_golden(golden):
+    """irn_bn_act / irn_stem_pool / irn_upsample_bilinear through the C ABI on the reference's fixtures: bit-identical to
+    the oracle's folded restatement (bn, residual, pool) and within fp32 rounding of the outputs of the reference's
+    FixedBatchNorm / MaxPool2d / Upsample modules."""
+    from oracle import irn_oracle as O
+    from irn_amd import ops
+    dev = _dev()
+    g = golden("trunk_ops")
+    T = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+
+    def fold(prefix):
+        return O.fold_batch_norm(g[prefix + "_w"], g[prefix + "_b"], g[prefix + "_mean"], g[prefix + "_var"], float(g[prefix + "_eps"]))
+
+    def close(a, ref, tol=2e-6):
+        assert float(np.abs(a - ref).max()) <= tol * max(1.0, float(np.abs(ref).max()))
+
+    for tag in "abc":
+        x, res = g["x_" + tag], g["res_" + tag]
+        s, b = fold("bn_" + tag)
+        sd, bd = fold("bnd_" + tag)
+        cases = (("bn_plain_", None, False, None), ("bn_relu_", None, True, None), ("bn_add_relu_", res, True, None),
+                 ("bn_addbn_relu_", res, True, (sd, bd)))
+        for key, r, relu, aff in cases:
+            got = ops.bn_act_(T(x), T(s), T(b), None if r is None else T(r), relu,
+                              None if aff is None else (T(aff[0]), T(aff[1]))).cpu().numpy()
+            assert np.array_equal(got, O.bn_act(x, s, b, res=r, relu=relu, res_affine=aff)), key + tag
+            close(got, g[key + tag], 4e-6)
+    for tag in ("s1", "s2", "s3"):
+        s, b = fold("stem_" + tag)
+        got = ops.stem_pool(T(g["stem_x_" + tag]), T(s), T(b)).cpu().numpy()
+        assert np.array_equal(got, O.stem_pool(g["stem_x_" + tag], s, b))
+        close(got, g["stem_out_" + tag])
+    for tag in ("u2", "u4", "u2b"):
+        f = int(g["up_f_" + tag])
+        got = ops.upsample_bilinear(T(g["up_x_" + tag]), f, relu=True).cpu().numpy()
+        close(got, O.head_upsample_relu(g["up_x_" + tag], f), 3e-7)
+        close(got, g["up_out_" + tag], 3e-7)
+
+
+def test_module_folding_equals_the_oracle_folding():
+    from oracle import irn_oracle as O
+    from irn_amd.net import resnet50 as R
+    dev = _dev()
+    torch.manual_seed(12)
+    bn = R.FrozenBatchNorm(37)
+    with torch.no_grad():
+        bn.weight.normal_()
+        bn.bias.normal_()
+        bn.running_mean.normal_()
+        bn.running_var.uniform_(0.01, 3.0)
+    s, b = O.fold_batch_norm(bn.weight.detach().numpy(), bn.bias.detach().numpy(), bn.running_mean.numpy(), bn.running_var.numpy(), bn.eps)
+    sd, bd = bn.to(dev).folded()
+    assert np.array_equal(sd.cpu().numpy(), s) and np.array_equal(bd.cpu().numpy(), b)
