@@ -69,6 +69,8 @@ def parse(argv=None):
     ap.add_argument("--legs-budget-s", type=float, default=240.0,
                     help="stop starting new legs once the legs have used this much wall time (the rest are recorded as skipped)")
     ap.add_argument("--loader-workers", type=int, default=4, help="DataLoader workers of the `steps` workload")
+    ap.add_argument("--ins-blocking", action="store_true",
+                    help="ins / ins_r10: wait for every batch's detections before the next batch is enqueued (no PCIe overlap)")
     ap.add_argument("--cpu-images", type=int, default=0, help="images of the CPU port sample (0 = 2 per host thread, at most 256)")
     ap.add_argument("--json-out", default=None)
     return ap.parse_args(argv)
@@ -175,8 +177,9 @@ def reference_algorithm_baseline(radius, beta, exp_times, n_target, seed0, budge
 # workloads
 # ------------------------------------------------------------------------------------------------
 
-def timed_loop(step, steps, warmup, dist, parallel, device, after_warmup=None):
-    """The contract: W untimed steps, then exactly K steps bracketed by barrier + synchronize, MAX over ranks."""
+def timed_loop(step, steps, warmup, dist, parallel, device, after_warmup=None, before_stop=None):
+    """The contract: W untimed steps, then exactly K steps bracketed by barrier + synchronize, MAX over ranks.
+    `before_stop` runs inside the timed region behind the last step (a pipelined step collects its last batch there)."""
     for _ in range(warmup):
         step()
     torch.cuda.synchronize()
@@ -189,6 +192,8 @@ def timed_loop(step, steps, warmup, dist, parallel, device, after_warmup=None):
     out = None
     for _ in range(steps):
         out = step()
+    if before_stop:
+        out = before_stop()
     torch.cuda.synchronize()
     if dist:
         dist.barrier()
@@ -267,10 +272,26 @@ def run_ins(a, workload, rank, world, device, dist, parallel, steps, warmup, bat
         name, value = kv.split("=")
         walker.set_option(name, int(value))
 
-    def step():
-        return mis.instance_labels_batch(walker, items, beta, exp_times, 0.25)
+    # as the step's loop does it (make_ins_seg_labels._flush): a batch is enqueued, then the batch before it is collected —
+    # its masks cross PCIe under this batch's kernels.  Every batch enqueued inside the timed region is collected inside it.
+    in_flight = [None]
 
-    elapsed, dets = timed_loop(step, steps, warmup, dist, parallel, device)
+    def step():
+        cur = mis.instance_labels_batch(walker, items, beta, exp_times, 0.25, deferred=not a.ins_blocking)
+        if a.ins_blocking:
+            return cur
+        prev, in_flight[0] = in_flight[0], cur
+        return prev.result() if prev is not None else None
+
+    def collect_last():
+        prev, in_flight[0] = in_flight[0], None
+        return prev.result() if prev is not None else None
+
+    def after_warmup():
+        collect_last()
+
+    elapsed, dets = timed_loop(step, steps, warmup, dist, parallel, device, after_warmup=after_warmup,
+                               before_stop=None if a.ins_blocking else collect_last)
     n_det = sum(0 if isinstance(d, Exception) else len(d["score"]) for d in dets)
     n_fallback = walker.fallback_runs
     walker.close()

@@ -374,12 +374,62 @@ def detect_instance(rw_up, argmax, class_ids, n_channels, max_fragment_size=0):
     return {"score": score, "mask": mask, "class": class_ids[chan]}
 
 
-def detect_instance_batch(rw_ups, argmaxes, class_ids, n_channels, max_fragment_sizes, timings=None):
+class PendingDetections:
+    """Detections of a batch whose packed transfer to the host may still be in flight (`detect_instance_batch(...,
+    deferred=True)`): `result()` waits for it and returns the list `detect_instance_batch` returns.  The transfer runs on
+    a copy stream of its own, so the caller can enqueue the next batch's kernels before collecting this one."""
+
+    def __init__(self, n, host, done, nds, offs, hs, ws, class_ids, timings, t_emit):
+        self._n, self._host, self._done, self._nds, self._offs = n, host, done, nds, offs
+        self._hs, self._ws, self._class_ids, self._timings, self._t_emit = hs, ws, class_ids, timings, t_emit
+        self._out = None
+
+    def result(self):
+        if self._out is not None:
+            return self._out
+        import time
+        out = []
+        if self._host is None:                      # no foreground pixel in any image of the batch
+            out = [ValueError("detect_instance: no foreground pixel in any channel") for _ in range(self._n)]
+        else:
+            self._done.synchronize()                                               # host round trip 2
+            t_done = time.perf_counter()
+            raw = self._host.numpy()
+            for i in range(self._n):
+                nd = self._nds[i]
+                if nd == 0:
+                    out.append(ValueError("detect_instance: no foreground pixel in any channel"))
+                    continue
+                o_sc, o_ch, o_mk = self._offs[i]
+                score = raw[o_sc:o_sc + 4 * nd].view(np.float32)
+                chan = raw[o_ch:o_ch + 4 * nd].view(np.int32)
+                mask = raw[o_mk:o_mk + nd * self._hs[i] * self._ws[i]].view(np.bool_).reshape(nd, self._hs[i], self._ws[i])
+                out.append({"score": score, "mask": mask, "class": np.asarray(self._class_ids[i])[chan]})
+            if self._timings is not None:            # seconds: emit + packed transfer (as far as the caller waited for it), unpacking
+                self._timings["emit_d2h"] = self._timings.get("emit_d2h", 0.0) + t_done - self._t_emit
+                self._timings["unpack"] = self._timings.get("unpack", 0.0) + time.perf_counter() - t_done
+        self._out = out
+        return out
+
+
+_COPY_STREAMS = {}
+
+
+def _copy_stream(dev):
+    key = (dev.type, dev.index if dev.index is not None else torch.cuda.current_device())
+    if key not in _COPY_STREAMS:
+        _COPY_STREAMS[key] = torch.cuda.Stream(device=dev)
+    return _COPY_STREAMS[key]
+
+
+def detect_instance_batch(rw_ups, argmaxes, class_ids, n_channels, max_fragment_sizes, timings=None, deferred=False):
     """detect_instance for a batch of images with two host round trips in total (the per-image form has three per
     image): one 4-byte-per-image transfer of the detection counts, one packed transfer of every image's
     {score, channel, masks} (irn_detect_instance_batch_count / _emit).  Arguments are lists (one entry per image) of
     what `detect_instance` takes.  Returns a list with, per image, the reference's numpy dict or — for an image without
-    any foreground pixel — the ValueError `detect_instance` would raise."""
+    any foreground pixel — the ValueError `detect_instance` would raise.  With `deferred=True` the packed transfer is
+    left in flight on a copy stream and a `PendingDetections` is returned: call its `result()` after the next batch has
+    been enqueued and the 2 MB of masks per image cross PCIe under that batch's kernels."""
     import time
     t_start = time.perf_counter()
     n = len(rw_ups)
@@ -403,6 +453,8 @@ def detect_instance_batch(rw_ups, argmaxes, class_ids, n_channels, max_fragment_
                                                   scratch.data_ptr(), _stream()))
         nds = [int(v) for v in n_det_dev.cpu().tolist()]                       # host round trip 1
         t_count = time.perf_counter()
+        if timings is not None:          # seconds: labelling + count transfer
+            timings["count"] = timings.get("count", 0.0) + t_count - t_start
         # packed output: per image [score fp32 x nd | channel int32 x nd | pad to 16 | masks uint8 nd x h x w | pad to 16]
         offs, total = [], 0
         for i in range(n):
@@ -410,8 +462,12 @@ def detect_instance_batch(rw_ups, argmaxes, class_ids, n_channels, max_fragment_
             offs.append((total, total + 4 * nds[i], total + head))
             total += head + (nds[i] * hs[i] * ws[i] + 15) // 16 * 16
         if total == 0:
-            return [ValueError("detect_instance: no foreground pixel in any channel") for _ in range(n)]
-        packed = _cached("det_out_b", dev, total + 16, torch.uint8)
+            pending = PendingDetections(n, None, None, nds, offs, hs, ws, class_ids, timings, t_count)
+            return pending if deferred else pending.result()
+        # the device-side staging buffer: the cached one when the call waits for its transfer, one of the batch's own
+        # when the transfer is left in flight (the next batch must not write into it)
+        packed = (torch.empty(total + 16, dtype=torch.uint8, device=dev) if deferred
+                  else _cached("det_out_b", dev, total + 16, torch.uint8))
         base = (packed.data_ptr() + 15) // 16 * 16
         shift = base - packed.data_ptr()
         live = [nd > 0 for nd in nds]
@@ -423,27 +479,23 @@ def detect_instance_batch(rw_ups, argmaxes, class_ids, n_channels, max_fragment_
         # a page-locked buffer of its own for every batch: the detections are handed out as VIEWS of it (no second copy of
         # 2 MB of masks per image) and it goes back to torch's caching host allocator when the last of them is dropped
         host = torch.empty(total, dtype=torch.uint8, pin_memory=True)
-        host.copy_(packed[shift:shift + total], non_blocking=True)
-        torch.cuda.current_stream().synchronize()                              # host round trip 2
-    t_emit = time.perf_counter()
-    raw = host.numpy()
-    out = []
-    for i in range(n):
-        nd = nds[i]
-        if nd == 0:
-            out.append(ValueError("detect_instance: no foreground pixel in any channel"))
-            continue
-        o_sc, o_ch, o_mk = offs[i]
-        score = raw[o_sc:o_sc + 4 * nd].view(np.float32)
-        chan = raw[o_ch:o_ch + 4 * nd].view(np.int32)
-        mask = raw[o_mk:o_mk + nd * hs[i] * ws[i]].view(np.bool_).reshape(nd, hs[i], ws[i])
-        out.append({"score": score, "mask": mask, "class": np.asarray(class_ids[i])[chan]})
-    if timings is not None:          # seconds: labelling + count transfer, emit + packed transfer, host-side unpacking
-        timings["count"] = timings.get("count", 0.0) + t_count - t_start
-        timings["emit_d2h"] = timings.get("emit_d2h", 0.0) + t_emit - t_count
-        timings["unpack"] = timings.get("unpack", 0.0) + time.perf_counter() - t_emit
+        done = torch.cuda.Event()
+        if deferred:
+            side, cur = _copy_stream(dev), torch.cuda.current_stream()
+            emitted = torch.cuda.Event()
+            emitted.record(cur)
+            side.wait_event(emitted)
+            with torch.cuda.stream(side):
+                host.copy_(packed[shift:shift + total], non_blocking=True)
+                done.record(side)
+            packed.record_stream(side)               # the allocator may hand the block out again only behind the copy
+        else:
+            host.copy_(packed[shift:shift + total], non_blocking=True)
+            done.record(torch.cuda.current_stream())
+    if timings is not None:
         timings["bytes"] = timings.get("bytes", 0) + total
-    return out
+    pending = PendingDetections(n, host, done, nds, offs, hs, ws, class_ids, timings, t_count)
+    return pending if deferred else pending.result()
 
 
 _CACHE = {}

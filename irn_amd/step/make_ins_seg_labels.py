@@ -28,13 +28,14 @@ cluster_centroids = ops.cluster_centroids
 detect_instance = ops.detect_instance
 
 
-def instance_labels_batch(walker, items, beta, exp_times, bg_thres):
+def instance_labels_batch(walker, items, beta, exp_times, bg_thres, deferred=False):
     """step/make_ins_seg_labels.py:131-150 for a batch of images.  items: dicts with GPU tensors
     `edge` [1,h,w], `dp` [2,h,w], `cam` [C,h,w], CPU/GPU `keys` [C] and `size` (H, W).  Every stage runs ONCE for the
     whole batch — centroid refinement, clustering, random walk (a 128x128 grid is 16 tiles at radius 5: one image uses
     1/16 of the GPU), label epilogue, detection — with three host round trips per BATCH: the instance counts K (they
     size the walk's channels), the detection counts, and the packed detections.  Returns a list of detection dicts
-    (or the ValueError of an image without detections, in its slot)."""
+    (or the ValueError of an image without detections, in its slot); with `deferred=True` an `ops.PendingDetections`
+    whose `result()` is that list — the packed transfer then runs under whatever the caller enqueues next."""
     dps = [it["dp"] for it in items]
     cmaps, ks = ops.cluster_centroids_batch(ops.find_centroids_batch(dps), dps)
     rws = walker([it["edge"] for it in items], [it["cam"] for it in items], beta=beta, exp_times=exp_times,
@@ -47,7 +48,7 @@ def instance_labels_batch(walker, items, beta, exp_times, bg_thres):
     n_ch = [it["cam"].shape[0] * k for it, k in zip(items, ks)]
     class_ids = [np.repeat(np.asarray(torch.as_tensor(it["keys"]).cpu()), k) for it, k in zip(items, ks)]
     return ops.detect_instance_batch(ep["rw_up"], ep["argmax"], class_ids, n_ch,
-                                     [it["size"][0] * it["size"][1] * 0.01 for it in items])
+                                     [it["size"][0] * it["size"][1] * 0.01 for it in items], deferred=deferred)
 
 
 def instance_labels(walker, edge, dp, cams, keys, size, beta, exp_times, bg_thres):
@@ -59,17 +60,28 @@ def instance_labels(walker, edge, dp, cams, keys, size, beta, exp_times, bg_thre
     return det
 
 
-def _flush(model, walker, pend, args, writer):
-    if not pend:
-        return
-    make_sem_seg_labels.edges_for(model, pend, int(getattr(args, "irn_batch", 0) or 8))
-    dets = instance_labels_batch(walker, pend, float(args.beta), int(args.exp_times), float(args.ins_seg_bg_thres))
-    for it, det in zip(pend, dets):
+def _write(names, pending, args, writer):
+    for name, det in zip(names, pending.result()):
         if isinstance(det, Exception):
-            warnings.warn("%s: %s — no file written" % (it["name"], det))
+            warnings.warn("%s: %s — no file written" % (name, det))
             continue
-        writer.submit(np.save, os.path.join(args.ins_seg_out_dir, it["name"] + ".npy"), det)
-    pend.clear()
+        writer.submit(np.save, os.path.join(args.ins_seg_out_dir, name + ".npy"), det)
+
+
+def _flush(model, walker, pend, args, writer, in_flight):
+    """Enqueue the batch in `pend`, then collect and write the batch before it (`in_flight`, a one-element list): its
+    detections crossed PCIe while this batch's kernels were being enqueued and run."""
+    if pend:
+        make_sem_seg_labels.edges_for(model, pend, int(getattr(args, "irn_batch", 0) or 8))
+        cur = ([it["name"] for it in pend],
+               instance_labels_batch(walker, pend, float(args.beta), int(args.exp_times), float(args.ins_seg_bg_thres),
+                                     deferred=True))
+        pend.clear()
+    else:
+        cur = None
+    if in_flight[0] is not None:
+        _write(*in_flight[0], args, writer)
+    in_flight[0] = cur
 
 
 def _work(process_id, model, dataset, args):
@@ -83,7 +95,7 @@ def _work(process_id, model, dataset, args):
             model.cuda()
             dev = torch.device("cuda", process_id)
             walker = indexing.RandomWalk(_common.walk_radius(args, RADIUS))
-            pend = []
+            pend, in_flight = [], [None]
             for it, pack in enumerate(loader):
                 name = pack["name"][0]
                 if not isinstance(name, str):
@@ -93,9 +105,10 @@ def _work(process_id, model, dataset, args):
                 pend.append({"name": name, "size": size, "img": _common.device_images(pack, (1.0,))[0],
                              "cam": cam, "keys": keys})
                 if len(pend) == batch:
-                    _flush(model, walker, pend, args, writer)
+                    _flush(model, walker, pend, args, writer, in_flight)
                 _common.progress(process_id, n_gpus, it, len(databin))
-            _flush(model, walker, pend, args, writer)
+            _flush(model, walker, pend, args, writer, in_flight)      # the last batch ...
+            _flush(model, walker, pend, args, writer, in_flight)      # ... and its collection
             walker.close()
     finally:
         writer.close()

@@ -225,3 +225,59 @@ def test_detect_instance_batch_vs_oracle_incl_empty_and_fragmented():
     one = ops.detect_instance(torch.from_numpy(scores[2]).to(_dev()), torch.from_numpy(clss[2]).to(_dev()), cids[2],
                               specs[2][2], max_fragment_size=0.0)
     assert np.array_equal(one["mask"], got[2]["mask"]) and np.array_equal(one["score"], got[2]["score"])
+
+
+def test_deferred_detections_equal_blocking_and_survive_the_next_batch():
+    """detect_instance_batch(deferred=True): the packed transfer of batch A is still in flight on the copy stream while
+    batch B (different sizes, so different offsets in its own staging buffer) is counted, emitted and collected; A's
+    result, collected last, equals the blocking call's.  An all-background batch gives the per-image ValueErrors."""
+    from irn_amd import ops
+    rng = np.random.RandomState(5)
+
+    def batch(specs):
+        sc, cl, cid = [], [], []
+        for (h, w, c) in specs:
+            cls = np.kron(rng.randint(0, c + 1, size=((h + 3) // 4, (w + 3) // 4)), np.ones((4, 4), int))[:h, :w]
+            sc.append(torch.from_numpy(rng.rand(c, h, w).astype(np.float32)).to(_dev()))
+            cl.append(torch.from_numpy(cls.astype(np.int32)).to(_dev()))
+            cid.append(np.arange(7, 7 + c))
+        return sc, cl, cid, [s[2] for s in specs], [0.0] * len(specs)
+
+    A = batch([(64, 80, 3), (33, 47, 5), (128, 128, 2)])
+    B = batch([(96, 96, 4), (16, 24, 1)])
+    want_a, want_b = ops.detect_instance_batch(*A), ops.detect_instance_batch(*B)
+    pa = ops.detect_instance_batch(*A, deferred=True)
+    pb = ops.detect_instance_batch(*B, deferred=True)
+    assert isinstance(pa, ops.PendingDetections)
+    got_b, got_a = pb.result(), pa.result()
+    assert pa.result() is got_a                                                  # collected once
+    for got, want in ((got_a, want_a), (got_b, want_b)):
+        assert len(got) == len(want)
+        for g, w in zip(got, want):
+            assert np.array_equal(g["mask"], w["mask"]) and np.array_equal(g["score"], w["score"])
+            assert np.array_equal(g["class"], w["class"])
+    empty = ops.detect_instance_batch([torch.zeros(2, 8, 8, device=_dev())], [torch.zeros(8, 8, dtype=torch.int32, device=_dev())],
+                                      [np.arange(2)], [2], [0.0], deferred=True).result()
+    assert len(empty) == 1 and isinstance(empty[0], ValueError)
+
+
+def test_instance_labels_batch_deferred_equals_blocking(golden):
+    from irn_amd.misc import indexing
+    from irn_amd.step import make_ins_seg_labels as mis
+    ins = golden("instance")
+    items = []
+    for name in "abc":
+        H, W = (int(v) for v in ins[name + "_size"])
+        items.append({"edge": torch.from_numpy(ins[name + "_edge"])[None].to(_dev()),
+                      "dp": torch.from_numpy(ins[name + "_dp"]).to(_dev()),
+                      "cam": torch.from_numpy(ins[name + "_cam"]).to(_dev()),
+                      "keys": torch.from_numpy(ins[name + "_keys"]), "size": (H, W)})
+    walker = indexing.RandomWalk(5, _dev())
+    want = mis.instance_labels_batch(walker, items, 10.0, 8, 0.25)
+    p1 = mis.instance_labels_batch(walker, items, 10.0, 8, 0.25, deferred=True)
+    p2 = mis.instance_labels_batch(walker, items[::-1], 10.0, 8, 0.25, deferred=True)   # enqueued before p1 is collected
+    got, got_rev = p1.result(), p2.result()
+    walker.close()
+    for g1, g2, w in zip(got, got_rev[::-1], want):
+        for d in (g1, g2):
+            assert np.array_equal(d["mask"], w["mask"]) and np.array_equal(d["score"], w["score"]) and np.array_equal(d["class"], w["class"])

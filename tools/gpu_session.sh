@@ -99,6 +99,11 @@ camprof|e2eprof)
   find $OUT/prof_$leg -name "*kernel_stats*" -exec cp {} $OUT/${leg}_kernel_stats.csv \;
   find $OUT/prof_$leg -name "${leg}_kernel_trace.csv" -delete
   python tools/kernel_classes.py $OUT/${leg}_kernel_stats.csv ;;
+insab)
+  for r in ins ins_r10; do for b in "" --ins-blocking; do
+    timeout 300 python bench.py --workload $r --steps 6 --warmup 2 --no-legs --no-cpu-baseline $b --json-out $OUT/insab_${r}_${b:-pipelined}.json > /dev/null 2>&1
+    python -c "import json; r=json.load(open('$OUT/insab_${r}_${b:-pipelined}.json')); print('$r ${b:-pipelined}: %.1f img/s, %.2f ms/step' % (r['value'], r['ms_per_step']))"
+  done; done ;;
 epibench)
   for lib in ${AB_LIBS:-libirn_hip.so}; do
     [ -f irn_amd/lib/$lib ] || continue
