@@ -38,20 +38,33 @@ def edges_for(model, pend, irn_batch):
             p["edge"], p["dp"] = edge, dp
 
 
-def _flush(model, walker, pend, args, writer):
-    if not pend:
-        return
+def _enqueue(model, walker, pend, args):
+    """IRNet forward, walk and label epilogue of the images in `pend`, enqueued only; returns what `_collect` needs."""
     edges_for(model, pend, int(getattr(args, "irn_batch", 0) or 8))
     rws = walker([p["edge"] for p in pend], [p["cam"] for p in pend],
                  beta=float(args.beta), exp_times=int(args.exp_times))
     sizes, keys = [p["size"] for p in pend], [p["keys_dev"] for p in pend]
     out = ops.label_epilogue(rws, sizes, float(args.sem_seg_bg_thres), keys=keys)
-    if walker.sync():                       # the persistent walk gave up and the batch was re-run on the streaming sweeps
-        out = ops.label_epilogue(rws, sizes, float(args.sem_seg_bg_thres), keys=keys)
-    labels = [lab.cpu().numpy() for lab in out["labels"]]
-    for p, lab in zip(pend, labels):
-        writer.submit(_save_png, os.path.join(args.sem_seg_out_dir, p["name"] + ".png"), lab)
+    batch = {"names": [p["name"] for p in pend], "rws": rws, "sizes": sizes, "keys": keys, "labels": out["labels"]}
     pend.clear()
+    return batch
+
+
+def _collect(walker, batch, args, writer):
+    """Wait for the batch enqueued last, bring its label maps to the host and hand them to the writer threads."""
+    if batch is None:
+        return
+    if walker.sync():                       # the persistent walk gave up and the batch was re-run on the streaming sweeps
+        batch["labels"] = ops.label_epilogue(batch["rws"], batch["sizes"], float(args.sem_seg_bg_thres),
+                                             keys=batch["keys"])["labels"]
+    for name, lab in zip(batch["names"], batch["labels"]):
+        writer.submit(_save_png, os.path.join(args.sem_seg_out_dir, name + ".png"), lab.cpu().numpy())
+
+
+def _flush(model, walker, pend, args, writer):
+    """One batch start to finish (kept for callers that want the blocking form)."""
+    if pend:
+        _collect(walker, _enqueue(model, walker, pend, args), args, writer)
 
 
 def _work(process_id, model, dataset, args):
@@ -65,7 +78,9 @@ def _work(process_id, model, dataset, args):
             model.cuda()
             dev = torch.device("cuda", process_id)
             walker = indexing.RandomWalk(_common.walk_radius(args, RADIUS))
-            pend = []
+            # a batch is enqueued and left running while the loop gathers the next one (decoded images from the loader
+            # threads, their uploads, the CAMs); it is collected just before the next batch is enqueued
+            pend, running = [], None
             for it, pack in enumerate(loader):
                 name = pack["name"][0]
                 if not isinstance(name, str):
@@ -76,8 +91,10 @@ def _work(process_id, model, dataset, args):
                 pend.append({"name": name, "size": size, "img": _common.device_images(pack, (1.0,))[0],
                              "cam": cam, "keys_dev": keys_dev})
                 if len(pend) == batch:
-                    _flush(model, walker, pend, args, writer)
+                    _collect(walker, running, args, writer)
+                    running = _enqueue(model, walker, pend, args)
                 _common.progress(process_id, n_gpus, it, len(databin))
+            _collect(walker, running, args, writer)
             _flush(model, walker, pend, args, writer)
             walker.close()
     finally:

@@ -80,9 +80,9 @@ abalt)
     done
   done ;;
 stepsleg)
-  for nw in 0 4; do
-    timeout 600 python bench.py --workload steps --steps 1 --warmup 1 --batch 32 --loader-workers $nw --json-out $OUT/steps_w$nw.json > $OUT/steps_w$nw.log 2>&1
-    python -c "import json; r=json.load(open('$OUT/steps_w$nw.json')); print('steps workers $nw: %.1f img/s' % r['value'], r['config'].get('last_pass_seconds'))" || tail -5 $OUT/steps_w$nw.log
+  for b in 64 128; do
+    timeout 600 python bench.py --workload steps --steps 2 --warmup 1 --batch $b --json-out $OUT/steps_b$b.json > $OUT/steps_b$b.log 2>&1
+    python -c "import json; r=json.load(open('$OUT/steps_b$b.json')); print('steps, $b images per pass: %.1f img/s' % r['value'], r['config'].get('last_pass_seconds'))" || tail -5 $OUT/steps_b$b.log
   done ;;
 profile)
   for c in 1 2 3 4; do timeout 100 python tools/resident_profile.py 10 4 $c 2>&1 | grep "wg 0"; done
