@@ -210,7 +210,7 @@ int irn_msf_pack(const uint8_t *img_dev, int h, int w, int n_scales, const int32
 
 /* ---------------------------------------------------------------------------------------------
  * Trunk epilogue  (replaces the elementwise tail of reference net/resnet50.py:35-55 Bottleneck.forward —
- * FixedBatchNorm :11-14, `out += residual`, ReLU — and of the stem :87-89, on the inference path)
+ * FixedBatchNorm :11-14, `out += residual`, ReLU — and of the stem :93-96, on the inference path)
  *
  *   x dev fp32 [n_images, n_channels, plane_elems] (a convolution's output, contiguous NCHW), IN PLACE:
  *       x[n, c, i] = act(x[n, c, i] * scale[c] + shift[c] (+ r[n, c, i]))      act = ReLU if relu else identity
@@ -223,7 +223,7 @@ int irn_msf_pack(const uint8_t *img_dev, int h, int w, int n_scales, const int32
 int irn_bn_act(float *x_dev, const float *res_dev, const float *scale_dev, const float *shift_dev, const float *res_scale_dev,
                const float *res_shift_dev, int64_t n_images, int n_channels, int64_t plane_elems, int relu, void *stream);
 
-/* Stem: batch norm + ReLU + max pool 3x3 / stride 2 / pad 1 in one pass (reference net/resnet50.py:94-97; the nets'
+/* Stem: batch norm + ReLU + max pool 3x3 / stride 2 / pad 1 in one pass (reference net/resnet50.py:93-96; the nets'
  * stage1, net/resnet50_cam.py:14, net/resnet50_irn.py:15).
  *   x dev fp32 [n_images, n_channels, h, w] (conv1's output) -> out dev fp32 [n_images, n_channels, (h-1)/2+1, (w-1)/2+1]
  *   = max over the window's in-image taps of relu(x * scale[c] + shift[c]); NaNs propagate. */

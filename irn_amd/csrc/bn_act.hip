@@ -5,10 +5,10 @@
 // never exists as a tensor of its own).
 //
 // Replaces the elementwise tail of reference net/resnet50.py:35-55 (Bottleneck.forward: FixedBatchNorm :11-14 ->
-// `out += residual` -> ReLU) and of the stem (:87-89): three kernels and seven tensor transfers at the end of a
+// `out += residual` -> ReLU) and of the stem (:93-96): three kernels and seven tensor transfers at the end of a
 // bottleneck (batch norm read + write, add two reads + write, ReLU read + write) become one kernel and three; after a
 // plain convolution four transfers become two.  The convolutions stay on MIOpen / rocBLAS; measured on the CAM leg
-// (profiles/r02_s13_cam_kernel_stats.csv) the elementwise kernels were 28 % of the backbone's time.
+// (profiles/r02_s13_cam_kernel_stats_composed.csv) the elementwise kernels were 28 % of the backbone's time.
 //
 // HBM-bound (12 or 8 bytes per element).  The tensor is walked flat in 16-byte pieces, so every load and store is a
 // full-width coalesced access whatever H x W is (VOC planes are rarely a multiple of 4 wide); a piece that straddles
@@ -170,7 +170,7 @@ extern "C" int irn_bn_act(float *x_dev, const float *res_dev, const float *scale
 }
 
 // ------------------------------------------------------------------------------------------------
-// Stem: batch norm + ReLU + 3x3 / stride 2 / pad 1 max pool of reference net/resnet50.py:94-97 (the nets' stage1,
+// Stem: batch norm + ReLU + 3x3 / stride 2 / pad 1 max pool of reference net/resnet50.py:93-96 (the nets' stage1,
 // net/resnet50_cam.py:14, net/resnet50_irn.py:15) in one pass: the largest activation of the trunk (64 x H/2 x W/2) is
 // read once and a quarter of it written, instead of read + written by the epilogue and read again by the pool.
 // ------------------------------------------------------------------------------------------------

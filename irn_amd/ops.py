@@ -143,7 +143,7 @@ def _need_f32_contig(t, what, min_dim):
 
 def stem_pool(x, scale, shift):
     """Batch norm + ReLU + 3x3 / stride 2 / pad 1 max pool of the trunk's stem in one pass (irn_stem_pool; reference
-    net/resnet50.py:94-97).  x: GPU fp32 [N, C, H, W] (conv1's output, left untouched) -> [N, C, (H-1)//2+1, (W-1)//2+1]."""
+    net/resnet50.py:93-96).  x: GPU fp32 [N, C, H, W] (conv1's output, left untouched) -> [N, C, (H-1)//2+1, (W-1)//2+1]."""
     _need_f32_contig(x, "stem_pool: x", 4)
     n, c, h, w = (int(v) for v in x.shape)
     for name, t in (("scale", scale), ("shift", shift)):

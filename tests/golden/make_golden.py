@@ -424,7 +424,7 @@ def gen_msf():
 def gen_trunk_ops():
     """The elementwise tails of the reference's trunk and heads, run by the reference's own modules on seeded tensors
     standing in for the convolutions' outputs: FixedBatchNorm -> += residual -> ReLU (net/resnet50.py:11-14, :35-55, with
-    and without the projection shortcut's batch norm :50-51), conv1's tail bn1 -> relu -> maxpool (:94-97), and the heads'
+    and without the projection shortcut's batch norm :50-51), conv1's tail bn1 -> relu -> maxpool (:93-96), and the heads'
     Upsample -> ReLU (net/resnet50_irn.py:36-48, :72-84)."""
     import net.resnet50 as r50
     g = torch.Generator().manual_seed(21)
