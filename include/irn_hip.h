@@ -209,13 +209,13 @@ int irn_msf_pack(const uint8_t *img_dev, int h, int w, int n_scales, const int32
                  const float *lut_dev, float *const *out_dev, void *scratch_dev, void *stream);
 
 /* ---------------------------------------------------------------------------------------------
- * Trunk epilogue  (replaces the elementwise tail of reference net/resnet50.py:35-55 Bottleneck.forward —
- * FixedBatchNorm :11-14, `out += residual`, ReLU — and of the stem :93-96, on the inference path)
+ * Trunk epilogue  (replaces the elementwise tail of reference net/resnet50.py:34-54 Bottleneck.forward —
+ * FixedBatchNorm :11-14, `out += residual`, ReLU — and of the stem :94-97, on the inference path)
  *
  *   x dev fp32 [n_images, n_channels, plane_elems] (a convolution's output, contiguous NCHW), IN PLACE:
  *       x[n, c, i] = act(x[n, c, i] * scale[c] + shift[c] (+ r[n, c, i]))      act = ReLU if relu else identity
  *       r = res, or res * res_scale[c] + res_shift[c] when res_scale / res_shift are given (the projection shortcut's own
- *       batch norm, net/resnet50.py:50-51, folded into the same pass)
+ *       batch norm, net/resnet50.py:48-49, folded into the same pass)
  *   scale / shift (/ res_scale / res_shift) dev fp32 [n_channels]: weight / sqrt(running_var + eps) and
  *   bias - running_mean * scale, folded by the caller; res (may be NULL) like x.  One fused multiply-add per element and
  *   operand, then one addition; NaNs propagate.  x and res 16-byte aligned; at most 2^31 - 1 elements per call.
@@ -223,7 +223,7 @@ int irn_msf_pack(const uint8_t *img_dev, int h, int w, int n_scales, const int32
 int irn_bn_act(float *x_dev, const float *res_dev, const float *scale_dev, const float *shift_dev, const float *res_scale_dev,
                const float *res_shift_dev, int64_t n_images, int n_channels, int64_t plane_elems, int relu, void *stream);
 
-/* Stem: batch norm + ReLU + max pool 3x3 / stride 2 / pad 1 in one pass (reference net/resnet50.py:93-96; the nets'
+/* Stem: batch norm + ReLU + max pool 3x3 / stride 2 / pad 1 in one pass (reference net/resnet50.py:94-97; the nets'
  * stage1, net/resnet50_cam.py:14, net/resnet50_irn.py:15).
  *   x dev fp32 [n_images, n_channels, h, w] (conv1's output) -> out dev fp32 [n_images, n_channels, (h-1)/2+1, (w-1)/2+1]
  *   = max over the window's in-image taps of relu(x * scale[c] + shift[c]); NaNs propagate. */

@@ -1,11 +1,11 @@
 // Inference batch norm (+ residual) (+ ReLU) of the ResNet-50 trunk as ONE pass over the convolution's output, in place:
 //     x[n, c, :, :] = act(x[n, c, :, :] * scale[c] + shift[c] (+ res[n, c, :, :] (* res_scale[c] + res_shift[c])))
 // with scale = weight / sqrt(running_var + eps), shift = bias - running_mean * scale folded by the caller; the residual may
-// carry a batch norm of its own (the projection shortcut of a stage's first unit, net/resnet50.py:50-51, whose output then
+// carry a batch norm of its own (the projection shortcut of a stage's first unit, net/resnet50.py:48-49, whose output then
 // never exists as a tensor of its own).
 //
-// Replaces the elementwise tail of reference net/resnet50.py:35-55 (Bottleneck.forward: FixedBatchNorm :11-14 ->
-// `out += residual` -> ReLU) and of the stem (:93-96): three kernels and seven tensor transfers at the end of a
+// Replaces the elementwise tail of reference net/resnet50.py:34-54 (Bottleneck.forward: FixedBatchNorm :11-14 ->
+// `out += residual` -> ReLU) and of the stem (:94-97): three kernels and seven tensor transfers at the end of a
 // bottleneck (batch norm read + write, add two reads + write, ReLU read + write) become one kernel and three; after a
 // plain convolution four transfers become two.  The convolutions stay on MIOpen / rocBLAS; measured on the CAM leg
 // (profiles/r02_s13_cam_kernel_stats_composed.csv) the elementwise kernels were 28 % of the backbone's time.
@@ -170,7 +170,7 @@ extern "C" int irn_bn_act(float *x_dev, const float *res_dev, const float *scale
 }
 
 // ------------------------------------------------------------------------------------------------
-// Stem: batch norm + ReLU + 3x3 / stride 2 / pad 1 max pool of reference net/resnet50.py:93-96 (the nets' stage1,
+// Stem: batch norm + ReLU + 3x3 / stride 2 / pad 1 max pool of reference net/resnet50.py:94-97 (the nets' stage1,
 // net/resnet50_cam.py:14, net/resnet50_irn.py:15) in one pass: the largest activation of the trunk (64 x H/2 x W/2) is
 // read once and a quarter of it written, instead of read + written by the epilogue and read again by the pool.
 // ------------------------------------------------------------------------------------------------

@@ -9,7 +9,7 @@ Differences by design:
   * batch-norm layers always use their running statistics (reference `FixedBatchNorm`,
     net/resnet50.py:11-14) — here that is simply the module's forward;
   * on the inference path (GPU tensor, autograd off) the elementwise tail of every unit — batch norm, the residual add
-    and the ReLU (net/resnet50.py:35-55, :93-96) — is ONE in-place pass of a hand-written kernel over the convolution's
+    and the ReLU (net/resnet50.py:34-54, :94-97) — is ONE in-place pass of a hand-written kernel over the convolution's
     output (`ops.bn_act_`, irn_amd/csrc/bn_act.hip) instead of three kernels and seven tensor transfers; the
     convolutions stay on MIOpen.  With autograd on (the training seam) or on the CPU the composed PyTorch ops run.
 """
@@ -68,7 +68,7 @@ class FrozenBatchNorm(nn.BatchNorm2d):
 
 
 def stem(conv1, bn1, maxpool, x):
-    """conv1 -> bn1 -> ReLU -> maxpool (net/resnet50.py:93-96); on the inference path everything behind the convolution is
+    """conv1 -> bn1 -> ReLU -> maxpool (net/resnet50.py:94-97); on the inference path everything behind the convolution is
     one pass (`ops.stem_pool`) when the pool is the trunk's 3x3 / stride 2 / pad 1."""
     y = conv1(x)
     if _fused(y) and (maxpool.kernel_size, maxpool.stride, maxpool.padding, maxpool.dilation, maxpool.ceil_mode) == (3, 2, 1, 1, False):

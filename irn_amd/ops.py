@@ -103,7 +103,7 @@ def cam_merge(outputs, size, label):
 
 def bn_act_(x, scale, shift, residual=None, relu=True, residual_affine=None):
     """Inference batch norm (+ residual) (+ ReLU) in one pass, IN PLACE on a convolution's output (irn_bn_act):
-    ``x = act(x * scale[c] + shift[c] (+ r))`` — the elementwise tail of reference net/resnet50.py:35-55.  ``r`` is the
+    ``x = act(x * scale[c] + shift[c] (+ r))`` — the elementwise tail of reference net/resnet50.py:34-54.  ``r`` is the
     residual, or ``residual * rs[c] + rb[c]`` with ``residual_affine = (rs, rb)`` (the projection shortcut's batch norm).
     x, residual: GPU fp32 [N, C, ...] contiguous; scale, shift, rs, rb: GPU fp32 [C].  Returns x."""
     _need_cuda(x, "x")
@@ -143,7 +143,7 @@ def _need_f32_contig(t, what, min_dim):
 
 def stem_pool(x, scale, shift):
     """Batch norm + ReLU + 3x3 / stride 2 / pad 1 max pool of the trunk's stem in one pass (irn_stem_pool; reference
-    net/resnet50.py:93-96).  x: GPU fp32 [N, C, H, W] (conv1's output, left untouched) -> [N, C, (H-1)//2+1, (W-1)//2+1]."""
+    net/resnet50.py:94-97).  x: GPU fp32 [N, C, H, W] (conv1's output, left untouched) -> [N, C, (H-1)//2+1, (W-1)//2+1]."""
     _need_f32_contig(x, "stem_pool: x", 4)
     n, c, h, w = (int(v) for v in x.shape)
     for name, t in (("scale", scale), ("shift", shift)):

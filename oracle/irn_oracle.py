@@ -452,7 +452,7 @@ def instance_labels(cams, keys, edge, dp, out_hw, beta=10, exp_times=8, radius=5
 
 
 # ------------------------------------------------------------------------------------------
-# Elementwise tails of the trunk and the heads  (reference net/resnet50.py:11-14, :35-55, :93-96;
+# Elementwise tails of the trunk and the heads  (reference net/resnet50.py:11-14, :34-54, :94-97;
 # net/resnet50_irn.py:36-48, :72-84) — what irn_bn_act / irn_stem_pool / irn_upsample_bilinear compute.
 # Pinned on tests/golden/trunk_ops.npz, written by the reference's own FixedBatchNorm and the torch
 # modules it instantiates.
@@ -467,7 +467,7 @@ def fold_batch_norm(weight, bias, mean, var, eps=1e-5):
 
 
 def bn_act(x, scale, shift, res=None, relu=True, res_affine=None):
-    """Bottleneck.forward's tail (net/resnet50.py:35-55): bn -> (+ residual | + bn_d(residual)) -> ReLU with the batch
+    """Bottleneck.forward's tail (net/resnet50.py:34-54): bn -> (+ residual | + bn_d(residual)) -> ReLU with the batch
     norms folded: one fp32 fused multiply-add per operand, one fp32 addition."""
     x = np.asarray(x, np.float32)
     bc = (1, -1) + (1,) * (x.ndim - 2)
@@ -481,7 +481,7 @@ def bn_act(x, scale, shift, res=None, relu=True, res_affine=None):
 
 
 def stem_pool(x, scale, shift):
-    """conv1's tail (net/resnet50.py:93-96): bn1 -> ReLU -> MaxPool2d(3, stride 2, padding 1) (:66); padding taps never win."""
+    """conv1's tail (net/resnet50.py:94-97): bn1 -> ReLU -> MaxPool2d(3, stride 2, padding 1) (:66); padding taps never win."""
     y = bn_act(x, scale, shift, relu=True)
     n, c, h, w = y.shape
     ho, wo = (h - 1) // 2 + 1, (w - 1) // 2 + 1

@@ -423,8 +423,8 @@ def gen_msf():
 
 def gen_trunk_ops():
     """The elementwise tails of the reference's trunk and heads, run by the reference's own modules on seeded tensors
-    standing in for the convolutions' outputs: FixedBatchNorm -> += residual -> ReLU (net/resnet50.py:11-14, :35-55, with
-    and without the projection shortcut's batch norm :50-51), conv1's tail bn1 -> relu -> maxpool (:93-96), and the heads'
+    standing in for the convolutions' outputs: FixedBatchNorm -> += residual -> ReLU (net/resnet50.py:11-14, :34-54, with
+    and without the projection shortcut's batch norm :48-49), conv1's tail bn1 -> relu -> maxpool (:94-97), and the heads'
     Upsample -> ReLU (net/resnet50_irn.py:36-48, :72-84)."""
     import net.resnet50 as r50
     g = torch.Generator().manual_seed(21)
@@ -455,10 +455,10 @@ def gen_trunk_ops():
             out["x_" + tag], out["res_" + tag] = x.numpy().copy(), res.numpy().copy()
             out["bn_relu_" + tag] = relu(m(x)).numpy().copy()                    # Bottleneck.forward :37-43
             y = m(x)
-            y += res                                                             # :52
-            out["bn_add_relu_" + tag] = relu(y).numpy().copy()                   # :53
+            y += res                                                             # :51
+            out["bn_add_relu_" + tag] = relu(y).numpy().copy()                   # :52
             y = m(x)
-            y += md(res)                                                         # :49-52 (downsample = conv, FixedBatchNorm)
+            y += md(res)                                                         # :48-51 (downsample = conv, FixedBatchNorm)
             out["bn_addbn_relu_" + tag] = relu(y).numpy().copy()
             out["bn_plain_" + tag] = m(x).numpy().copy()
         pool = torch.nn.MaxPool2d(kernel_size=3, stride=2, padding=1)            # net/resnet50.py:66

@@ -1,5 +1,5 @@
 """The trunk's fused inference epilogue (irn_bn_act, irn_amd/csrc/bn_act.hip) against the composed operations it
-replaces — FixedBatchNorm -> `out += residual` -> ReLU of reference net/resnet50.py:11-14, :35-55, :87-89.
+replaces — FixedBatchNorm -> `out += residual` -> ReLU of reference net/resnet50.py:11-14, :34-54, :87-89.
 
 The kernel does one fused multiply-add per element with constants folded in double precision, so it is compared with
 the exact (fp64) value of the same expression at fp32 rounding accuracy, with PyTorch's own batch_norm / add / relu at

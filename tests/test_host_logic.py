@@ -294,7 +294,7 @@ def test_cam_store_hit_and_file_fallback(tmp_path):
 def test_frozen_batch_norm_folding_and_composed_path():
     """FrozenBatchNorm.folded() is the batch norm as one multiply-add (the constants irn_bn_act consumes), and apply_ on
     the CPU (or with autograd on) is the reference's composed tail: FixedBatchNorm -> += residual -> ReLU
-    (net/resnet50.py:11-14, :35-55), leaving its input untouched."""
+    (net/resnet50.py:11-14, :34-54), leaving its input untouched."""
     import torch.nn.functional as F
     from irn_amd.net import resnet50 as R
     g = torch.Generator().manual_seed(9)
@@ -326,7 +326,7 @@ def test_frozen_batch_norm_folding_and_composed_path():
 
 def test_apply_with_a_batch_norm_on_the_residual_composed_path():
     """apply_(x, residual, residual_bn=...) off the device = bn(x) + bn_r(residual) -> ReLU: the projection shortcut of
-    net/resnet50.py:50-55."""
+    net/resnet50.py:48-52."""
     import torch.nn.functional as F
     from irn_amd.net import resnet50 as R
     torch.manual_seed(2)
