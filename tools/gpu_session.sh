@@ -57,7 +57,7 @@ pmcsq)
     timeout 200 rocprofv3 --pmc $set -d $R/$OUT/prof_sq$i -o walk -f csv -- python $R/bench.py --steps 1 --warmup 0 --no-legs --no-cpu-baseline ${SQ_BENCH_ARGS:-} > $R/$OUT/prof_sq$i.log 2>&1
   done
   cd $R
-  python tools/reduce_prof.py $OUT > $OUT/sq_summary.txt 2>&1; grep -E "resident_kernel" $OUT/sq_summary.txt | cut -c1-30,96-200
+  python tools/reduce_prof.py $OUT > $OUT/sq_summary.txt 2>&1; grep -E "resident_kernel|affinity_kernel" $OUT/sq_summary.txt | cut -c1-40,96-200
   find $OUT -name "walk_counter_collection.csv" -delete ;;
 ins)
   for r in 5 10; do timeout 200 python tools/ins_step_breakdown.py $r 64 5 > $OUT/ins_breakdown_r$r.txt 2>&1; cat $OUT/ins_breakdown_r$r.txt | grep -v Warning; done
@@ -99,6 +99,19 @@ camprof|e2eprof)
   find $OUT/prof_$leg -name "*kernel_stats*" -exec cp {} $OUT/${leg}_kernel_stats.csv \;
   find $OUT/prof_$leg -name "${leg}_kernel_trace.csv" -delete
   python tools/kernel_classes.py $OUT/${leg}_kernel_stats.csv ;;
+affab)
+  R=$PWD
+  for lib in ${AB_LIBS:-libirn_hip.so}; do
+    [ -f irn_amd/lib/$lib ] || continue
+    echo "== $lib"
+    IRN_HIP_LIB=$R/irn_amd/lib/$lib timeout 300 python -m pytest tests/test_gpu_walk.py -q -m gpu -x -k "affinity" 2>&1 | tail -1
+    for wl in walk walk_r5; do
+      cd /tmp; IRN_HIP_LIB=$R/irn_amd/lib/$lib timeout 300 rocprofv3 --kernel-trace --stats -d $R/$OUT/aff_${lib%.so}_$wl -o t -f csv -- python $R/bench.py --workload $wl --steps 4 --warmup 1 --no-legs --no-cpu-baseline > $R/$OUT/aff_${lib%.so}_$wl.log 2>&1; cd $R
+      f=$(find $OUT/aff_${lib%.so}_$wl -name '*kernel_stats*' | head -1)
+      grep -E 'affinity_kernel|resident_kernel' $f | awk -F'",' '{print substr($1,2,60), $2, $4}' | sed "s/^/$wl /"
+      find $OUT/aff_${lib%.so}_$wl -name 't_kernel_trace.csv' -delete
+    done
+  done ;;
 insab)
   for r in ins ins_r10; do for b in "" --ins-blocking; do
     timeout 300 python bench.py --workload $r --steps 6 --warmup 2 --no-legs --no-cpu-baseline $b --json-out $OUT/insab_${r}_${b:-pipelined}.json > /dev/null 2>&1
