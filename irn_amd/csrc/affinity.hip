@@ -10,6 +10,8 @@
 // Roofline: per source pixel the kernel reads n_cells LDS words (242 at r=5, 2134 at r=10) and writes
 // n_dirs floats (34 / 152) — one pass, LDS-issue bound; it runs once per image against 2^exp_times
 // sweeps of the walk, so it is <2 % of the path.
+#include <utility>
+
 #include "kernels.hpp"
 
 namespace irn {
@@ -34,6 +36,12 @@ __device__ __forceinline__ float pow_beta(float a, float beta, int beta_int) {
         return (float)r;
     }
     return (float)pow(b, (double)beta);
+}
+
+__device__ __forceinline__ float max3(float a, float b, float c) {
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
 }
 
 template <bool POW>
@@ -83,14 +91,124 @@ __global__ __launch_bounds__(256) void affinity_kernel(const AffJob *__restrict_
             const int4 ob = *reinterpret_cast<const int4 *>(cell_off8 + k + 4);
             const float a0 = tb[oa.x], a1 = tb[oa.y], a2 = tb[oa.z], a3 = tb[oa.w];
             const float b0 = tb[ob.x], b1 = tb[ob.y], b2 = tb[ob.z], b3 = tb[ob.w];
-            m0 = fmaxf(m0, fmaxf(fmaxf(a0, a1), fmaxf(a2, a3)));
-            m1 = fmaxf(m1, fmaxf(fmaxf(b0, b1), fmaxf(b2, b3)));
+            // v_max3_f32 directly: fmaxf() on values fresh from memory is preceded by a canonicalising v_max_f32 v, v, v
+            // each (8 extra vector instructions per 8 cells in a loop the vector pipe bounds)
+            m0 = max3(max3(m0, a0, a1), a2, a3);
+            m1 = max3(max3(m1, b0, b1), b2, b3);
         }
-        const float m = fmaxf(m0, m1);
+        const float m = max3(m0, m1, m1);
         float a = 1.0f - m;
         if (POW) a = pow_beta(a, beta, beta_int);
         if (valid) out[(long)d * J.plane_stride] = a;
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// The same kernel with the path table as a compile-time constant (radius 5 and 10, raster plane order: the walk's
+// weight table).  In the table-driven loop above every LDS read costs a vector add for its address (the cell's offset
+// arrives in a scalar register) and the loop is bound by the vector pipe (profiles/r02_s27_affinity_counters.txt: 11.5 k
+// vector instructions per wave for 2.6 k LDS reads).  Unrolled, the cell offsets are the immediate offsets of the
+// ds_read instructions: 2134 reads + 1067 v_max3 + 152 powers and stores of straight-line code at radius 10 (~40 KB,
+// inside the instruction cache, every wave running the same stream).
+// ------------------------------------------------------------------------------------------------
+template <int R>
+struct Paths {
+    static constexpr int kMaxDirs = 2 * R * R, kMaxCells = 32 * R * R;
+    int n_dirs = 0, n_cells = 0;
+    signed char dy[kMaxDirs] = {}, dx[kMaxDirs] = {};
+    short start[kMaxDirs + 1] = {};
+    signed char cy[kMaxCells] = {}, cx[kMaxCells] = {};
+    constexpr void add(int y, int x) {
+        // thick segment (0,0) -> (y,x): lattice points of the bounding box with (y*px - x*py)^2 < y^2 + x^2
+        // (misc/indexing.py:37-46); the max over a path does not depend on the order of its cells
+        dy[n_dirs] = (signed char)y;
+        dx[n_dirs] = (signed char)x;
+        const int lsq = y * y + x * x;
+        const int x_lo = x < 0 ? x : 0, x_hi = x < 0 ? 0 : x;
+        for (int py = 0; py <= y; ++py)
+            for (int px = x_lo; px <= x_hi; ++px) {
+                const int cross = y * px - x * py;
+                if (cross * cross < lsq) {
+                    cy[n_cells] = (signed char)py;
+                    cx[n_cells] = (signed char)px;
+                    ++n_cells;
+                }
+            }
+        start[++n_dirs] = (short)n_cells;
+    }
+    constexpr Paths() {
+        // raster order of the directions = discovery order of misc/indexing.py:24-30 (path table order 1)
+        for (int x = 1; x < R; ++x) add(0, x);
+        for (int y = 1; y < R; ++y)
+            for (int x = -R + 1; x < R; ++x)
+                if (x * x + y * y < R * R) add(y, x);
+    }
+};
+template <int R>
+inline constexpr Paths<R> kPaths{};
+
+template <int... Is, typename F>
+__device__ __forceinline__ void static_for_impl(std::integer_sequence<int, Is...>, F &&f) {
+    (f(std::integral_constant<int, Is>{}), ...);
+}
+template <int N, typename F>
+__device__ __forceinline__ void static_for(F &&f) {
+    static_for_impl(std::make_integer_sequence<int, N>{}, f);
+}
+
+template <int R, int D>
+__device__ __forceinline__ float path_max(const float *tb) {
+    constexpr int LW = AFF_TW + 2 * (R - 1), HALO = R - 1;
+    constexpr int k0 = kPaths<R>.start[D], n = kPaths<R>.start[D + 1] - k0;
+    constexpr auto off = [](int k) constexpr { return kPaths<R>.cy[k] * LW + kPaths<R>.cx[k] + HALO; };
+    float m = tb[off(k0)];
+    static_for<(n - 1) / 2>([&](auto ik) __attribute__((always_inline)) {
+        constexpr int k = k0 + 1 + 2 * decltype(ik)::value;
+        m = max3(m, tb[off(k)], tb[off(k + 1)]);
+    });
+    if constexpr ((n - 1) % 2 == 1) {
+        const float v = tb[off(k0 + n - 1)];
+        m = max3(m, v, v);
+    }
+    return m;
+}
+
+template <int R>
+__global__ __launch_bounds__(256) void affinity_unrolled_kernel(const AffJob *__restrict__ jobs, int beta_int) {
+    constexpr int HALO = R - 1, LW = AFF_TW + 2 * HALO, LH = AFF_TH + HALO, ND = kPaths<R>.n_dirs;
+    __shared__ float tile[LH * LW];
+    const AffJob J = jobs[blockIdx.y];
+    const int tiles_x = (J.sw + AFF_TW - 1) / AFF_TW;
+    const int tiles_y = (J.sh + AFF_TH - 1) / AFF_TH;
+    if ((int)blockIdx.x >= tiles_x * tiles_y) return;
+    const int ty0 = ((int)blockIdx.x / tiles_x) * AFF_TH;
+    const int tx0 = ((int)blockIdx.x % tiles_x) * AFF_TW;
+    for (int i = threadIdx.x; i < LH * LW; i += 256) {          // staging as in affinity_kernel
+        const int ly = i / LW, lx = i - ly * LW;
+        const int gy = J.oy + ty0 + ly;
+        const int gx = J.ox + tx0 + lx - HALO;
+        float v = 1.0f;
+        if (gy < J.gh && gx >= 0 && gx < J.gw) v = J.edge[(long)gy * J.gw + gx];
+        tile[i] = v;
+    }
+    __syncthreads();
+    const int ly = threadIdx.x / AFF_TW, lx = threadIdx.x % AFF_TW;
+    const int sy = ty0 + ly, sx = tx0 + lx;
+    const bool valid = sy < J.sh && sx < J.sw;
+    const float *tb = tile + ly * LW + lx;              // cell (cy, cx) of this pixel sits at tb[cy * LW + cx + HALO]
+    float *out = J.out + (long)sy * J.sw + sx;
+    static_for<ND>([&](auto id) __attribute__((always_inline)) {
+        constexpr int d = decltype(id)::value;
+        // integer beta only (the launch sends any other beta to the table-driven kernel): the general fp64 pow() inlined
+        // once per direction would be 300 KB of code
+        double b = (double)(1.0f - path_max<R, d>(tb)), r = 1.0;
+        for (int e = beta_int; e; e >>= 1) {
+            if (e & 1) r *= b;
+            b *= b;
+        }
+        if (valid) *out = (float)r;
+        out += J.plane_stride;
+    });
 }
 
 // Backward of edge_to_affinity for the training seam (reference net/resnet50_irn.py:162-175: index_select
@@ -169,7 +287,11 @@ int launch_affinity(const AffJob *jobs_dev, int n_jobs, int max_sh, int max_sw, 
     dim3 grid(tiles, n_jobs);
     int beta_int = 0;
     if (with_pow && beta == (float)(int)beta && beta >= 1.0f && beta <= 64.0f) beta_int = (int)beta;
-    if (with_pow)
+    if (with_pow && beta_int > 0 && tab.order == 1 && tab.radius == 10)
+        hipLaunchKernelGGL(affinity_unrolled_kernel<10>, grid, dim3(256), 0, stream, jobs_dev, beta_int);
+    else if (with_pow && beta_int > 0 && tab.order == 1 && tab.radius == 5)
+        hipLaunchKernelGGL(affinity_unrolled_kernel<5>, grid, dim3(256), 0, stream, jobs_dev, beta_int);
+    else if (with_pow)
         hipLaunchKernelGGL(affinity_kernel<true>, grid, dim3(256), lds, stream, jobs_dev, tab.dir_start8,
                            tab.cell_off8, tab.n_dirs, tab.radius, beta, beta_int);
     else
