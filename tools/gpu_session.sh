@@ -63,11 +63,11 @@ ins)
   for r in 5 10; do timeout 200 python tools/ins_step_breakdown.py $r 64 5 > $OUT/ins_breakdown_r$r.txt 2>&1; cat $OUT/ins_breakdown_r$r.txt | grep -v Warning; done
   timeout 300 python tools/ins_step_bench.py 64 > $OUT/ins_step_bench.txt 2>&1; grep walk_batch $OUT/ins_step_bench.txt ;;
 sweep)
-  for d in 6 8 12 14; do
-    timeout 200 python bench.py --steps 5 --warmup 2 --no-legs --no-cpu-baseline --walk-option poll_delay=$d --json-out $OUT/sweep_pd$d.json > /dev/null 2>&1
+  for d in ${SWEEP_PD:-6 8 12 14}; do
+    timeout 200 python bench.py --steps ${SWEEP_STEPS:-5} --warmup 2 --no-legs --no-cpu-baseline --walk-option poll_delay=$d --json-out $OUT/sweep_pd$d.json > /dev/null 2>&1
     python -c "import json; r=json.load(open('$OUT/sweep_pd$d.json')); print('poll_delay $d: %.1f img/s launch %.3f ms' % (r['value'], r['roofline']['avg_launch_ms']))"
   done
-  for d in 1 3 4; do
+  for d in ${SWEEP_PDP:-1 3 4}; do
     timeout 200 python bench.py --workload walk_r5 --steps 5 --warmup 2 --no-legs --no-cpu-baseline --walk-option poll_delay_plain=$d --json-out $OUT/sweep_r5_pdp$d.json > /dev/null 2>&1
     python -c "import json; r=json.load(open('$OUT/sweep_r5_pdp$d.json')); print('r5 poll_delay_plain $d: %.1f img/s launch %.3f ms' % (r['value'], r['roofline']['avg_launch_ms']))"
   done ;;
