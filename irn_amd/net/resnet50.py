@@ -31,6 +31,13 @@ def _fused(x):
     return FUSED_EPILOGUE and x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and not torch.is_grad_enabled()
 
 
+def _version(t):
+    try:
+        return t._version
+    except RuntimeError:          # tensors created under torch.inference_mode() carry no version counter
+        return -1
+
+
 class FrozenBatchNorm(nn.BatchNorm2d):
     """Inference-statistics batch norm regardless of train()/eval() (net/resnet50.py:11-14)."""
 
@@ -44,7 +51,7 @@ class FrozenBatchNorm(nn.BatchNorm2d):
         """(scale, shift) fp32 [C] with forward(x) = x * scale + shift, folded in double precision; cached until a
         parameter or statistic is written or moved."""
         src = (self.weight, self.bias, self.running_mean, self.running_var)
-        key = tuple((t.data_ptr(), t._version) for t in src)
+        key = tuple((t.data_ptr(), _version(t)) for t in src)
         if self._folded is None or self._folded[0] != key:
             with torch.no_grad():
                 w, b, mean, var = (t.detach().double() for t in src)

@@ -342,3 +342,15 @@ def test_apply_with_a_batch_norm_on_the_residual_composed_path():
         unit = R.Bottleneck(8, 4, stride=2, project=True).eval()
         y = unit(torch.randn(1, 8, 9, 9))
         assert y.shape == (1, 16, 5, 5) and float(y.min()) >= 0.0
+
+
+def test_folding_under_inference_mode():
+    """Tensors made under torch.inference_mode() have no version counter; the folded constants are then cached by
+    storage only."""
+    from irn_amd.net import resnet50 as R
+    with torch.inference_mode():
+        bn = R.FrozenBatchNorm(3)
+        scale, shift = bn.folded()
+        assert bn.folded()[0] is scale
+        x = torch.randn(2, 3, 4, 4)
+        assert float((bn.apply_(x, relu=False) - (x * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1))).abs().max()) < 1e-6
