@@ -1,0 +1,1096 @@
+// NOT BUILT.  Round-2 experiment (session 35/36): resident_kernel with a PIPE instantiation — the combine of step k-1
+// runs in front of the arithmetic of step k (one barrier per step, three state buffers) for batches whose images all have
+// >= 3 channels.  Bit-identical (96 GPU tests), but the combine's latency chain still runs before the wave's FMAs (its
+// stores sit behind exec-mask branches, so nothing interleaves): COCO shape 43.08 vs 43.68 ms per launch (+1.4 %).
+// As a run-time switch inside the one kernel it was 30 % SLOWER: the register allocator gave the two-channel schedule's
+// in-flight poll other registers and the compiler then waited for every outstanding memory operation in the middle of
+// the pipelined arithmetic.  DESIGN.md section 4, lesson 22.
+// Weights-stationary persistent random walk (gfx950) — "variant 2" of irn_walk_run.
+//
+// The transition operator of an image is the same in every one of the 2^exp_times sweeps
+// (reference misc/indexing.py:136-137 squares ONE matrix).  The streaming sweeps of walk.hip re-read
+// its |S| weight planes from HBM every sweep (4*|S|*N bytes: the HBM roofline of SURVEY.md §8d).
+// This kernel reads them ONCE per image: every workgroup keeps the 2|S| directed weights of its
+// pixels in VGPRs for the whole walk, so a sweep moves only the state (8*C*N bytes per image, all of
+// it L2/fabric traffic between neighbouring workgroups) and the chip's 128 MB of register file is the
+// cache the weights live in.
+//
+// Decomposition (radius 10: 304 directed neighbours per pixel)
+//   * one workgroup = 512 threads = 8 waves, one per CU (256 VGPRs per lane), resident for the launch;
+//   * a "slab" is 8 rows x 32 columns of pixels = 64 lanes x 4 consecutive pixels; Q waves share a
+//     slab and split the neighbour disc between them in raster order (radius 10: Q = 8 waves x 38
+//     neighbours x 4 px = 152 weight registers per lane; radius 5: Q = 2 x 34, four slabs per
+//     workgroup).  Each wave's part of the disc is a different, fully expanded instruction stream
+//     (wave-uniform switch), so every weight has a fixed register;
+//   * a step = (sweep t, channel c), c fastest.  Waves 4-7 poll and stage x_t[c] of the tile + halo into
+//     LDS (double-buffered); every wave forms, per neighbour row, an fp32 FMA chain (<= 19 terms) over
+//     a register window of the staged state and folds it into fp64; the Q partial sums of a pixel meet
+//     in LDS; waves 0-3 add the centre term, multiply by 1/deg in fp64 and store x_{t+1}[c] (same
+//     numerics contract as walk.hip).  Channels are independent chains: with C >= 2 the poll of the
+//     next step flies during the arithmetic of this one.
+//
+// Exchange between workgroups (tiles of one image; no kernel boundary between sweeps)
+//   state buffers hold one 8-byte granule {tag = sweep + 1, fp32 value} per pixel and channel, written
+//   by ONE agent-scope (sc1, write-through) store and polled with agent-scope loads until the tag
+//   matches: the data is its own flag (MI355X guide, Guideline 16 form R2), so a sweep costs one
+//   store->load hop and no fence.  Ping-pong buffers are WAR-safe: a workgroup overwrites x_t of its
+//   tile (while producing x_{t+2}) only after it has seen x_{t+1} of every tile within the halo, i.e.
+//   after every reader of its x_t has finished reading.  Polls are bounded (wall clock): a
+//   workgroup that cannot make progress reports through `err` and the launch fails loudly.
+//
+// Scheduling: grid = one workgroup per CU.  The host packs images into rounds of <= #CU tiles in
+// descending cost order (tile = 8x32 px at radius 10, 16x64 at radius 5); workgroup b runs
+// job[round][b] for every round.
+// Tiles of an image sit on consecutive slots of one XCD (slot -> block id b = idx*8 + xcd; observed
+// placement, speed only).  No grid-wide barrier exists, so rounds pipeline.
+#include <algorithm>
+
+#include "walk_ctx.hpp"
+
+namespace irn {
+namespace {
+
+typedef unsigned long long u64;
+typedef const double IRN_GLOBAL *gcd_t;
+typedef float IRN_GLOBAL *gf_t;
+typedef float f4a __attribute__((ext_vector_type(4)));
+
+constexpr int kSlabH = 8, kSlabW = 32;     // 64 lanes x 4 px
+constexpr int kWaves = 8;                  // 512 threads
+
+template <int R>
+struct RCfg;
+template <>
+struct RCfg<10> {
+    static constexpr int Q = 8, SL_Y = 1, SL_X = 1;
+    static constexpr bool PREFETCH_ROWS = true;     // read the next neighbour row's window ahead of this row's FMAs
+};
+template <>
+struct RCfg<5> {
+    static constexpr int Q = 2, SL_Y = 2, SL_X = 2;
+    static constexpr bool PREFETCH_ROWS = true;     // fits since the fp32 chains freed the fp64 accumulators (250 VGPRs)
+};
+
+// The neighbour disc (dy,dx) != (0,0), dx^2 + dy^2 < R^2, in raster order: the union of the
+// reference's half-plane direction set S (misc/indexing.py:18-56) and its mirror image.
+template <int R>
+struct Disc {
+    int n = 0;
+    signed char dy[4 * R * R] = {}, dx[4 * R * R] = {};
+    constexpr Disc() {
+        for (int y = -(R - 1); y <= R - 1; ++y)
+            for (int x = -(R - 1); x <= R - 1; ++x)
+                if ((y != 0 || x != 0) && x * x + y * y < R * R) {
+                    dy[n] = (signed char)y;
+                    dx[n] = (signed char)x;
+                    ++n;
+                }
+    }
+};
+template <int R>
+inline constexpr Disc<R> kDisc{};
+
+template <int R>
+struct Geom {
+    using C = RCfg<R>;
+    static constexpr int H = R - 1;
+    // LDS column of tile column 0.  Windows are read in 16-byte slots aligned in LDS, i.e. starting at offsets c with
+    // (HP + c) % 4 == 0 from the lane's first pixel.  HP = H puts a slot boundary exactly at the leftmost neighbour of a full
+    // disc row (dx = -H): such a row then needs 6 slots instead of 7 (radius 10: 9 of the 19 rows), which is 8 fewer live
+    // VGPRs for the two windows in flight and 6 % fewer LDS reads.
+    static constexpr int HP = H;
+    static constexpr int TH = kSlabH * C::SL_Y, TW = kSlabW * C::SL_X;
+    // LDS row stride = 32 banks (mod 64): the 16-lane groups of a ds_read_b128 ({0-3,12-15,20-27}, ...)
+    // span four tile rows; with this stride their 16-byte chunks fall on distinct banks
+    // (56 floats, the tight fit, was 2-3-way conflicted: 0.95 us of a 3.1 us sweep).
+    static constexpr int LH = TH + 2 * H, LW = 96;
+    static_assert(LW >= TW + 2 * HP && LW % 64 == 32, "LDS row stride");
+    static_assert((TW + 2 * H) % 2 == 0, "staged rows are polled in pixel pairs");
+    static constexpr int NK = (LH * ((TW + 2 * H) / 2) + 255) / 256;   // staged pixel PAIRS per polling lane (waves 4-7)
+    static constexpr int LWU = TW + 2 * H;               // columns actually staged
+    static constexpr int RG = LH * LWU;                  // staged pixels per channel
+    static constexpr int D = kDisc<R>.n;
+    static constexpr int Q = C::Q;
+    static constexpr int NS = D / Q;                     // neighbours per wave
+    static constexpr int SLABS = C::SL_Y * C::SL_X;
+    static_assert(D % Q == 0, "disc must split evenly over the waves of a slab");
+    static_assert(SLABS * Q == kWaves, "8 waves per workgroup");
+    // LDS carve (bytes)
+    // state buffers of the steps: two (step k stages while step k-1 is combined), three at radius 10 where the combine of
+    // step k-1 runs INSIDE the arithmetic of step k for jobs with >= 3 channels (it still reads the centre term of k-1
+    // while the polling waves already stage k+1)
+    static constexpr int NXS = R == 10 ? 3 : 2;
+    static constexpr int XS_BYTES = NXS * LH * LW * 4;             // [NXS][LH][LW] fp32
+    static constexpr int PART_BYTES = 2 * kWaves * 4 * 64 * 8;      // [2][wave][lane][j]: fp64 for the degree (prologue), fp32 chains in the steps
+    static constexpr int INVD_BYTES = SLABS * 4 * 64 * 8;           // [slab][row][column] fp64
+    static constexpr int LDS_BYTES = XS_BYTES + PART_BYTES + INVD_BYTES + 16;
+};
+
+// first / last neighbour of row dy inside wave part QI (raster order => contiguous), or lo > hi
+template <int R, int QI>
+constexpr int row_lo(int dy) {
+    constexpr int NS = Geom<R>::NS;
+    for (int s = QI * NS; s < (QI + 1) * NS; ++s)
+        if (kDisc<R>.dy[s] == dy) return s;
+    return 1 << 20;
+}
+template <int R, int QI>
+constexpr int row_hi(int dy) {
+    constexpr int NS = Geom<R>::NS;
+    for (int s = (QI + 1) * NS - 1; s >= QI * NS; --s)
+        if (kDisc<R>.dy[s] == dy) return s;
+    return -1;
+}
+// largest c <= v with (c + hp) % 4 == 0: the 16-byte-aligned slot boundary at or left of neighbour offset v
+constexpr int slot_floor(int v, int hp) { return v - (((v + hp) % 4 + 4) % 4); }
+
+// ---- per-job: weights of this lane's 4 pixels for the wave's part of the disc -> registers ----
+template <int R, int QI>
+__device__ __forceinline__ void load_weights(float (&wr)[Geom<R>::NS][4], const WalkImg &I, int gy, int gx) {
+    using G = Geom<R>;
+    const bool row_ok = gy < I.h && gx < I.w;
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        (void *)(I.wts - I.front_pad), 0, (int)(I.n_dirs * I.plane_stride * 4), 0x00020000);
+    // out-of-image lanes read beyond num_records: the buffer load returns 0.  The front pad goes into
+    // the scalar offset so that it stays >= 0 for backward reads of plane 0 (the hardware adds it
+    // as an unsigned 32-bit number).
+    const int p4 = row_ok ? (gy * I.w + gx) * 4 : 0x7ffffff0;
+    const int ps4 = (int)(I.plane_stride * 4);
+    const int fp4 = I.front_pad * 4;
+    static_for<G::NS>([&](auto is) __attribute__((always_inline)) {
+        constexpr int s = QI * G::NS + decltype(is)::value;
+        constexpr int dy = kDisc<R>.dy[s], dx = kDisc<R>.dx[s];
+        constexpr bool fwd = dy > 0 || (dy == 0 && dx > 0);
+        // forward neighbour p+d uses w_d(p); backward neighbour p-d' (d' = -d in S) uses w_d'(p-d')
+        constexpr int plane = fwd ? plane_of<R>(dy, dx) : plane_of<R>(-dy, -dx);
+        const int soff = fp4 + plane * ps4 + (fwd ? 0 : (dy * I.w + dx) * 4);
+        const f4a v = __builtin_bit_cast(f4a, __builtin_amdgcn_raw_buffer_load_b128(rsrc, p4, soff, 0));
+        wr[decltype(is)::value][0] = v.x;
+        wr[decltype(is)::value][1] = gx + 1 < I.w ? v.y : 0.f;
+        wr[decltype(is)::value][2] = gx + 2 < I.w ? v.z : 0.f;
+        wr[decltype(is)::value][3] = gx + 3 < I.w ? v.w : 0.f;
+    });
+}
+
+// deg(p) - 1 = sum of the 2|S| directed weights of p (column sum of misc/indexing.py:135): this wave's part of it,
+// from the registers load_weights just filled, in fp64.  A backward weight whose source pixel lies outside
+// the image reads a stored zero by construction of the planes (walk.hip, layout); it is masked out here all
+// the same, like degree_kernel does, so that the degree never depends on that property.
+template <int R, int QI>
+__device__ __forceinline__ void degree_partial(const float (&wr)[Geom<R>::NS][4], const WalkImg &I, int gy, int gx,
+                                               double (&ds)[4]) {
+    using G = Geom<R>;
+    ds[0] = ds[1] = ds[2] = ds[3] = 0.0;
+    // validity of a backward source as 0/1 FACTORS in VGPRs, one per column offset (dx + j) and per row: kept as
+    // per-neighbour lane masks the conditions needed ~150 SGPR pairs at once and spilled
+    float fx[2 * R + 2];
+#pragma unroll
+    for (int e = 0; e < 2 * R + 2; ++e) fx[e] = (unsigned)(gx + e - (R - 1)) < (unsigned)I.w ? 1.f : 0.f;
+    static_for<G::NS>([&](auto is) __attribute__((always_inline)) {
+        constexpr int s = QI * G::NS + decltype(is)::value;
+        constexpr int dy = kDisc<R>.dy[s], dx = kDisc<R>.dx[s];
+        constexpr bool fwd = dy > 0 || (dy == 0 && dx > 0);
+        if constexpr (fwd) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) ds[j] += (double)wr[decltype(is)::value][j];
+        } else {
+            const float fy = gy + dy >= 0 ? 1.f : 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) ds[j] += (double)(wr[decltype(is)::value][j] * (fx[dx + j + R - 1] * fy));
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    });
+}
+
+// ---- per sweep and channel: this wave's partial sums for its 4 pixels ----
+// Neighbour rows of wave part QI that belong to HALF (0: the rows up to and including the one that
+// crosses the half-way point of the part, 1: the rest; radius 5 keeps everything in half 0 — the split
+// pushed that instantiation into scratch; HALF 2 = all rows in one piece).  The C = 2 schedule issues a
+// poll between the halves; the other schedules run the whole part as one pipeline.
+template <int R, int QI, int HALF>
+struct RowList {
+    int n = 0;
+    int dy[2 * R] = {};
+    constexpr RowList() {
+        constexpr int NS = Geom<R>::NS;
+        for (int y = -(R - 1); y <= R - 1; ++y) {
+            const int lo = row_lo<R, QI>(y), hi = row_hi<R, QI>(y);
+            if (lo > hi) continue;
+            const bool first_half = R == 5 || lo - QI * NS < NS / 2;
+            if (HALF == 2 || first_half == (HALF == 0)) dy[n++] = y;
+        }
+    }
+};
+template <int R, int QI, int HALF>
+inline constexpr RowList<R, QI, HALF> kRowList{};
+
+template <int R, int QI, int DY>
+struct RowInfo {
+    static constexpr int lo = row_lo<R, QI>(DY), hi = row_hi<R, QI>(DY);
+    static constexpr int c_lo = slot_floor(kDisc<R>.dx[lo], Geom<R>::HP), c_hi = kDisc<R>.dx[hi] + 3;
+    static constexpr int N4 = (c_hi - c_lo) / 4 + 1;          // aligned 16-byte reads of the state window
+};
+
+constexpr int kMaxWin = 6;   // a full radius-10 row spans 22 floats = 6 aligned float4 slots (see Geom::HP)
+
+// The state window of a neighbour row: floats c_lo .. c_lo + 4*N4 - 1 relative to the lane's first pixel (16-byte
+// aligned), of which dx_lo .. dx_hi + 3 are used; N4 aligned 16-byte LDS reads.  Reading only the used floats of the two
+// end slots (4- and 8-byte reads; a full row over-reads 6 of 28 floats) was measured and is SLOWER (radius 10: +1.2 %
+// launch time, COCO shape +1.4 %): with 4 pixels per lane a 4-byte read of a wave touches every fourth bank only, the four
+// tile rows of a 32-lane group collide 4-way (8 LDS cycles against 4 for the conflict-free 16-byte read), and the LDS row
+// stride that makes the 16-byte reads conflict-free cannot do the same for narrower ones.
+template <int R, int QI, int DY>
+__device__ __forceinline__ void load_window(float (&w)[kMaxWin * 4], const float *xrow) {
+    using RW = RowInfo<R, QI, DY>;
+    static_assert(RW::N4 <= kMaxWin, "window");
+    const float *row = xrow + DY * Geom<R>::LW + RW::c_lo;
+    static_for<RW::N4>([&](auto ik) __attribute__((always_inline)) {
+        constexpr int k = decltype(ik)::value;
+        const f4a v = *reinterpret_cast<const f4a *>(row + 4 * k);
+        w[4 * k] = v.x;
+        w[4 * k + 1] = v.y;
+        w[4 * k + 2] = v.z;
+        w[4 * k + 3] = v.w;
+    });
+}
+
+// ONE fp32 chain per pixel over all neighbours of the wave's part (<= 38 terms at radius 10, 34 at radius 5); the Q
+// chains of a pixel are combined in fp64 together with the centre term and the normalisation.  A numpy model of this
+// scheme (tests/test_precision_model.py) is as close to the exact operator as folding every neighbour row into fp64
+// separately (1.5e-6 after 256 sweeps: the floor set by storing the state in fp32), and it saves 2 x 4 conversions /
+// fp64 additions per row segment and wave.  (More chains for ILP and packed FMAs were both measured: slower / no gain.)
+template <int R, int QI, int DY>
+__device__ __forceinline__ void fma_window(const float (&wr)[Geom<R>::NS][4], const float (&w)[kMaxWin * 4], float (&pf)[4]) {
+    using RW = RowInfo<R, QI, DY>;
+    static_for<RW::hi - RW::lo + 1>([&](auto is) __attribute__((always_inline)) {
+        constexpr int s = RW::lo + decltype(is)::value;
+        constexpr int dx = kDisc<R>.dx[s];
+        constexpr int k = s - QI * Geom<R>::NS;
+        static_for<4>([&](auto ij) __attribute__((always_inline)) {
+            constexpr int j = decltype(ij)::value;
+            constexpr int e = dx + j - RW::c_lo;
+            pf[j] = fmaf(wr[k][j], w[e], pf[j]);
+        });
+    });
+}
+
+// The window of row r+1 is read BEFORE the FMAs of row r (two windows live).  Isolated in
+// tools/arith_probe.hip the phase is LDS-bound: the window reads alone take 0.44 us per step, reads
+// then FMAs row after row 0.78 us (no overlap at all: every wave of the CU is in the same phase), this
+// order 0.62 us; reading every window of the part first 0.70 us.
+template <int R, int QI, int HALF>
+__device__ __forceinline__ void partial_sums(const float (&wr)[Geom<R>::NS][4], const float *xrow, float (&pf)[4]) {
+    constexpr int NR = kRowList<R, QI, HALF>.n;
+    if constexpr (HALF != 1) pf[0] = pf[1] = pf[2] = pf[3] = 0.f;
+    if constexpr (NR > 0 && !RCfg<R>::PREFETCH_ROWS) {
+        // row after row
+        static_for<NR>([&](auto ir) __attribute__((always_inline)) {
+            float w1[kMaxWin * 4];
+            load_window<R, QI, kRowList<R, QI, HALF>.dy[decltype(ir)::value]>(w1, xrow);
+            fma_window<R, QI, kRowList<R, QI, HALF>.dy[decltype(ir)::value]>(wr, w1, pf);
+        });
+    } else if constexpr (NR > 0) {
+        float w[2][kMaxWin * 4];
+        load_window<R, QI, kRowList<R, QI, HALF>.dy[0]>(w[0], xrow);
+        static_for<NR>([&](auto ir) __attribute__((always_inline)) {
+            constexpr int r = decltype(ir)::value;
+            if constexpr (r + 1 < NR) load_window<R, QI, kRowList<R, QI, HALF>.dy[r + 1 < NR ? r + 1 : r]>(w[(r + 1) & 1], xrow);
+            __builtin_amdgcn_sched_barrier(0);
+            fma_window<R, QI, kRowList<R, QI, HALF>.dy[r]>(wr, w[r & 1], pf);
+            __builtin_amdgcn_sched_barrier(0);
+        });
+    }
+}
+
+// The whole part with a hook behind the request of its first window: the pipelined steps (>= 3 channels, radius 10) run
+// the combine of the PREVIOUS step there — its LDS reads were issued before the window's, its arithmetic and stores fall
+// into the shadow of the window's latency.
+template <int R, int QI, typename Mid>
+__device__ __forceinline__ void partial_sums_piped(const float (&wr)[Geom<R>::NS][4], const float *xrow, float (&pf)[4], Mid &&mid) {
+    constexpr int NR = kRowList<R, QI, 2>.n;
+    pf[0] = pf[1] = pf[2] = pf[3] = 0.f;
+    float w[2][kMaxWin * 4];
+    load_window<R, QI, kRowList<R, QI, 2>.dy[0]>(w[0], xrow);
+    __builtin_amdgcn_sched_barrier(0);
+    mid();          // under the latency of the first window; its registers are free again before the second is requested
+    __builtin_amdgcn_sched_barrier(0);
+    static_for<NR>([&](auto ir) __attribute__((always_inline)) {
+        constexpr int r = decltype(ir)::value;
+        if constexpr (r + 1 < NR) load_window<R, QI, kRowList<R, QI, 2>.dy[r + 1 < NR ? r + 1 : r]>(w[(r + 1) & 1], xrow);
+        __builtin_amdgcn_sched_barrier(0);
+        fma_window<R, QI, kRowList<R, QI, 2>.dy[r]>(wr, w[r & 1], pf);
+        __builtin_amdgcn_sched_barrier(0);
+    });
+}
+
+// Granule = {fp32 value, tag} in one naturally aligned 8-byte word, moved by ONE agent-scope access:
+// buffer_load/store_dwordx2 with sc1 (aux 16) — the store writes through to memory, the load
+// bypasses this CU's L1 (MI355X guide, Guideline 16 R1/R2).  Buffer addressing keeps the base in
+// SGPRs and needs one 32-bit VGPR per item (64-bit flat addresses cost 2 and pushed the kernel
+// into scratch).
+typedef unsigned u2v __attribute__((ext_vector_type(2)));
+typedef unsigned u4v __attribute__((ext_vector_type(4)));
+constexpr int kSc1 = 16;
+__device__ __forceinline__ u2v ld_granule(__amdgpu_buffer_rsrc_t rsrc, int voff, int soff) {
+    return __builtin_bit_cast(u2v, __builtin_amdgcn_raw_buffer_load_b64(rsrc, voff, soff, kSc1));
+}
+template <int AUX = kSc1>
+__device__ __forceinline__ void st_granule(__amdgpu_buffer_rsrc_t rsrc, int voff, int soff, unsigned tag, float v) {
+    u2v g;
+    g.x = __float_as_uint(v);
+    g.y = tag;
+    __builtin_amdgcn_raw_buffer_store_b64(g, rsrc, voff, soff, AUX);
+}
+
+// two adjacent pixels' granules in ONE 16-byte write-through store (8-byte sc1 stores are one fabric write
+// each and cost ~2.7x per byte: MI355X guide, stores table); each 8-byte half is still written whole
+template <int AUX = kSc1>
+__device__ __forceinline__ void st_granule2(__amdgpu_buffer_rsrc_t rsrc, int voff, int soff, unsigned tag, float v0, float v1) {
+    u4v g;
+    g.x = __float_as_uint(v0);
+    g.y = tag;
+    g.z = __float_as_uint(v1);
+    g.w = tag;
+    __builtin_amdgcn_raw_buffer_store_b128(g, rsrc, voff, soff, AUX);
+}
+
+#ifndef IRN_PIPELINED_STEPS
+#define IRN_PIPELINED_STEPS 1
+#endif
+
+// One pixel of a step's combine at radius 10 (the arithmetic and order of the in-step combine of resident_kernel, shared
+// by the pipelined steps): the Q fp32 chains pairwise, centre term and normalisation in fp64, the neighbour lane's result
+// through a DPP quad permute, then the even lane stores both granules — or the last sweep's value goes to the output.
+template <int R, int Q>
+__device__ __forceinline__ void resident_store_px(float (&ps)[Q], float centre, double inv_deg, const WalkImg &I,
+                                                  __amdgpu_buffer_rsrc_t dst, int t, int c, int t_total, int yy, int xx, int x,
+                                                  int h, int w, unsigned n, int ch_bytes, bool plain_st) {
+#pragma unroll
+    for (int span = 1; span < Q; span *= 2)
+#pragma unroll
+        for (int q = 0; q + span < Q; q += 2 * span) ps[q] = ps[q] + ps[q + span];
+    const double sum = (double)centre + (double)ps[0];
+    const float res = (float)(sum * inv_deg);
+    const float other = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(res), 0xB1, 0xF, 0xF, true));
+    if (yy < h && xx < w) {
+        const unsigned o = (unsigned)(yy * w + xx);
+        const unsigned tag = (unsigned)(t + 2);
+        if (t + 1 == t_total) ((gf_t)I.out)[(unsigned)c * n + o] = res;
+        else if ((x & 1) == 0 && xx + 1 < w) {
+            if (plain_st) st_granule2<0>(dst, (int)o * 8, c * ch_bytes, tag, res, other);
+            else st_granule2(dst, (int)o * 8, c * ch_bytes, tag, res, other);
+        } else if ((x & 1) == 0) {
+            if (plain_st) st_granule<0>(dst, (int)o * 8, c * ch_bytes, tag, res);
+            else st_granule(dst, (int)o * 8, c * ch_bytes, tag, res);
+        }
+    }
+}
+
+// x_0 = cam * (1 - edge) (misc/indexing.py:162; instance split step/make_ins_seg_labels.py:77-80) as
+// granules with tag 1 into xa; xb's tags are cleared so that no stale tag of an earlier run matches.
+__global__ __launch_bounds__(256) void x0_granule_kernel(const WalkImg *__restrict__ imgs) {
+    const WalkImg I = imgs[blockIdx.y];
+    const long n = (long)I.h * I.w;
+    const long p = (long)blockIdx.x * 256 + threadIdx.x;
+    if (p >= n) return;
+    const float one_minus = 1.0f - I.edge[p];
+    const int k = I.inst ? I.k_inst : 1;
+    const int id = I.inst ? I.inst[p] : 0;
+    u64 *xa = (u64 *)I.xa, *xb = (u64 *)I.xb;
+    for (int c = 0; c < I.C; ++c) {
+        const int cls = c / k, kk = c - cls * k;
+        float v = I.cam[(long)cls * n + p];
+        if (I.inst) v = v * (id == kk ? 1.0f : 0.0f);
+        xa[(long)c * n + p] = ((u64)1 << 32) | (u64)__float_as_uint(v * one_minus);
+        xb[(long)c * n + p] = 0;
+    }
+}
+
+// PROF: per-step time stamps for tools/resident_profile.py (its own instantiation: the stamp pointer would
+// cost the production kernel two live VGPRs per lane, and it sits exactly at the 256-register limit)
+template <int R, bool PROF, bool PIPE = false>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void resident_kernel(
+    const WalkImg *__restrict__ imgs, const int4 *__restrict__ jobs, int n_rounds, int t_first, int t_count,
+    int t_total, unsigned *err, long long timeout_ticks, long long *prof, int poll_delay, unsigned long long *votes) {
+    using G = Geom<R>;
+    constexpr int H = G::H, HP = G::HP, LH = G::LH, LW = G::LW, LWU = G::LWU, RG = G::RG, Q = G::Q, NK = G::NK;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float *xs = reinterpret_cast<float *>(smem);
+    double *part = reinterpret_cast<double *>(smem + G::XS_BYTES);
+    double *invd = reinterpret_cast<double *>(smem + G::XS_BYTES + G::PART_BYTES);
+    int *abort_flag = reinterpret_cast<int *>(smem + G::XS_BYTES + G::PART_BYTES + G::INVD_BYTES);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int slab = wv / Q, qi = wv % Q;
+    const int ly = (slab / G::C::SL_X) * kSlabH + (lane >> 3);
+    const int lx = (slab % G::C::SL_X) * kSlabW + (lane & 7) * 4;
+    if (tid == 0) *abort_flag = 0;
+    // Option "plain_store" (radius 5 only; `votes` non-null): state stores without sc1 when every tile of the image
+    // has been SEEN to run on this XCD.  Such a store keeps the line in the XCD's L2, which then serves a same-XCD
+    // neighbour's sc1 poll without the trip through the fabric (C = 1 sweep 2.61 -> 2.23 us).  A reader on another XCD
+    // never sees it in time (radius 10, 64 tiles = 2 XCDs per image: every launch ran into the bounded wait), and HIP
+    // promises nothing about block -> XCD placement, so each job votes: every tile adds 1 to the byte of its XCC id
+    // in the image's 64-bit word and waits until all tiles have voted; one byte holding them all = same XCD.
+    int *plain_flag = abort_flag + 1;
+    const int delay_plain = (poll_delay >> 16) & 0xffff;
+    poll_delay &= 0xffff;
+
+    float wr[G::NS][4];
+    // poll_delay: units of s_sleep(1) = 64 clocks.  Fixed on purpose: steering the delay
+    // from hits and misses was tried twice and lost both times — a miss usually means a neighbour
+    // was late, not that this workgroup polled early, so every tile backs off together (symmetric
+    // steering: 3.6 us per sweep, late-only steering: 3.5 us and drifting, fixed: 2.7-3.0 us).
+
+#pragma unroll 1
+    for (int round = 0; round < n_rounds; ++round) {
+        const int4 je = jobs[round * gridDim.x + blockIdx.x];
+        if (je.x < 0) continue;
+        const WalkImg I = imgs[je.x];
+        const int ty0 = je.y, tx0 = je.z;
+        const int h = I.h, w = I.w;
+        const unsigned n = (unsigned)(h * w);
+        const int gy = ty0 + ly, gx = tx0 + lx;
+        if constexpr (R == 5) {
+            if (votes && tid == 0) {
+                const unsigned xcc = (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 20) & 7u;   // HW_REG_XCC_ID
+                unsigned long long *v = votes + je.x;
+                __hip_atomic_fetch_add(v, 1ull << (8 * xcc), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const long long t0 = wall_clock64();
+                int same = 0;
+                for (;;) {
+                    const unsigned long long word = __hip_atomic_load(v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    unsigned total = 0;
+                    bool single = false;
+                    for (int f = 0; f < 8; ++f) {
+                        const unsigned cnt = (unsigned)(word >> (8 * f)) & 0xffu;
+                        total += cnt;
+                        single |= cnt == (unsigned)je.w;
+                    }
+                    if (total >= (unsigned)je.w) {
+                        same = single ? 1 : 0;
+                        break;
+                    }
+                    if (wall_clock64() - t0 > timeout_ticks) break;      // sc1 stores are always safe
+                    __builtin_amdgcn_s_sleep(16);
+                }
+                *plain_flag = same;
+            }
+        }
+
+        double dsum[4];
+#define IRN_LOAD_PART(QI)                          \
+    load_weights<R, (QI) % Q>(wr, I, gy, gx);      \
+    degree_partial<R, (QI) % Q>(wr, I, gy, gx, dsum)
+        switch (qi) {
+            case 0: IRN_LOAD_PART(0); break;
+            case 1: IRN_LOAD_PART(1); break;
+            case 2: IRN_LOAD_PART(2); break;
+            case 3: IRN_LOAD_PART(3); break;
+            case 4: IRN_LOAD_PART(4); break;
+            case 5: IRN_LOAD_PART(5); break;
+            case 6: IRN_LOAD_PART(6); break;
+            default: IRN_LOAD_PART(7); break;
+        }
+#undef IRN_LOAD_PART
+        // 1/deg of the tile: the waves' parts meet in LDS (the combine's partial-sum buffer), fp64 throughout
+        __syncthreads();   // previous job's readers of part / invd / xs are done
+        {
+            double *pw = part + wv * 256 + lane * 4;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) pw[j] = dsum[j];
+        }
+        __syncthreads();
+        const bool plain_st = R == 5 && votes && *plain_flag != 0;
+        const int job_delay = plain_st ? delay_plain : poll_delay;
+#pragma unroll
+        for (int i = tid; i < G::SLABS * 256; i += 512) {     // [slab][row][column] like the combine's thread order
+            const int s2 = i >> 8, prow = (i >> 5) & 7, x = i & 31;
+            const int yy = ty0 + (s2 / G::C::SL_X) * kSlabH + prow;
+            const int xx = tx0 + (s2 % G::C::SL_X) * kSlabW + x;
+            const double *pr = part + (s2 * Q) * 256 + (prow * 8 + (x >> 2)) * 4 + (x & 3);
+            double deg = 1.0;
+#pragma unroll
+            for (int q = 0; q < Q; ++q) deg += pr[q * 256];
+            invd[i] = (yy < h && xx < w) ? 1.0 / deg : 0.0;
+        }
+        // Wave roles: waves 4-7 poll and stage the state, waves 0-3 combine and store it.  A wave
+        // that issued divergent stores after its prefetched poll loads can only wait for those loads
+        // with vmcnt(0), i.e. for the write-through acknowledge of the stores as well (that put the
+        // whole store latency, ~0.5 us, into every step); a polling wave never stores.
+        const bool poller = wv >= 4;
+        // Staged pixel PAIRS of a polling lane (the same for every channel and sweep of the job): two adjacent
+        // granules come with ONE 16-byte load (half as many poll requests as one load per granule; each
+        // 8-byte half is read whole).  Per pair: granule index of its first pixel inside one channel (high
+        // bits) | LDS index (low 12 bits); vmask has one bit per HALF.  Positions outside the image are
+        // zeroed once here and never examined (their half of the load reads a neighbouring granule or, out
+        // of range, 0 from the bounds-checked buffer).
+        unsigned btab[NK];
+        unsigned vmask = 0;
+#pragma unroll
+        for (int k = 0; k < NK; ++k) {
+            const int i = (tid - 256) + k * 256;
+            const int ry = i / (LWU / 2);
+            int rx = (i - ry * (LWU / 2)) * 2;
+            const int yy = ty0 - H + ry;
+            int xx = tx0 - H + rx;
+            bool second = true;
+            if (xx == -1) {          // pair straddling the left image edge: load (0, 1) instead and use its first half only
+                xx = 0;
+                rx += 1;
+                second = false;
+            }
+            const bool row_ok = poller && i < RG / 2 && yy >= 0 && yy < h;
+            const bool ok0 = row_ok && xx >= 0 && xx < w, ok1 = row_ok && second && xx >= 0 && xx + 1 < w;
+            // pairs without a valid half read granule 0 (in range, never examined)
+            btab[k] = ((ok0 ? (unsigned)(yy * w + xx) : 0u) << 15) | (unsigned)(ry * LW + rx + (HP - H));
+            if (ok0) vmask |= 1u << (2 * k);
+            if (ok1) vmask |= 2u << (2 * k);
+        }
+        for (int i = tid; i < G::NXS * LH * LW; i += 512) xs[i] = 0.f;
+        __syncthreads();
+
+        // ---- the walk of this tile: a pipeline of steps (sweep t, channel c), c fastest ----
+        // Step k stages x_t[c] into xs[k & 1], forms the partial sums into part[k & 1], combines and
+        // stores x_{t+1}[c].  Channels are independent chains, so with C >= 2 the poll of step k+1
+        // is issued before the arithmetic of step k and its round trip through the fabric is hidden;
+        // with C = 1 the next step's input does not exist before this step's stores have landed in
+        // the neighbouring tiles, and the poll waits `poll_delay` behind our own stores instead.
+        const int C = I.C;
+        const int ch_bytes = (int)(8u * n);
+        const int state_bytes = (int)(8u * n * (unsigned)C);
+        const int n_steps = t_count * C;
+        // delays are counted in s_sleep(1) = 64 clocks; reading a clock instead (s_memrealtime in
+        // every wave, several times per step) cost more than 1 us per step
+        auto nap = [&](int units) {
+            for (int d = 0; d < units; ++d) __builtin_amdgcn_s_sleep(1);
+        };
+        auto state_rsrc = [&](int tt) {
+            // + 16: the 16-byte poll of the last granule reaches one granule past the state (the workspace keeps
+            // >= 64 bytes of slack behind every state buffer)
+            return __builtin_amdgcn_make_buffer_rsrc((void *)((tt & 1) ? I.xb : I.xa), 0, state_bytes + 16, 0x00020000);
+        };
+        // One poll slot of NK granule pairs per polling lane.  Loads are unconditional (straight-line code).
+        u4v va[NK];
+        auto issue = [&](__amdgpu_buffer_rsrc_t rs, int soff) __attribute__((always_inline)) {
+#pragma unroll
+            for (int kk = 0; kk < NK; ++kk)
+                va[kk] = __builtin_bit_cast(u4v, __builtin_amdgcn_raw_buffer_load_b128(rs, (int)((btab[kk] >> 15) << 3), soff, kSc1));
+        };
+        int t = t_first, c = 0;
+        bool fresh = true;             // first step of the job: its input has been there since before the launch
+        bool polled = false;           // the poll of the current step is already in flight
+        // Pipelined steps (radius 10, >= 3 channels): the combine of step k-1 runs inside the arithmetic of step k — its
+        // latency chain (LDS partial sums -> fp64 -> store, 0.25 us of a 1.05 us step with every vector pipe idle) and the
+        // barrier in front of it leave the critical path.  Its stores go out ~0.2 us into step k instead of at the end
+        // of step k-1; the tiles that need them poll one step later still (>= 0.6 us behind them), which needs the
+        // third channel.  One barrier per step; a third state buffer, because the centre term of k-1 is read while the
+        // polling waves stage k+1.
+        // The pipelined schedule is a separate instantiation of the kernel (PIPE), launched for batches whose images all
+        // have >= 3 channels: inside one kernel the register allocation of the two schedules interfered (the in-flight
+        // poll of the two-channel schedule, requested half-way through its arithmetic into other registers, made the
+        // compiler wait for every outstanding memory operation in the middle of the pipelined arithmetic), and the kernel
+        // has no registers to spare for keeping them apart.
+        static_assert(!PIPE || (R == 10 && !PROF), "pipelined steps exist at radius 10 only");
+        const bool pipe = PIPE;
+        int xb = 0;                    // state buffer of this step (pipelined: k mod 3)
+        int pt = t_first, pc = 0;      // (sweep, channel) of the previous step
+        const float *xs_prev = xs;
+#pragma unroll 1
+        for (int k = 0; k < n_steps; ++k) {
+            const __amdgpu_buffer_rsrc_t src = state_rsrc(t), dst = state_rsrc(t + 1);
+            const bool last = (t + 1 == t_total);
+            const unsigned want = (unsigned)(t + 1);
+            float *xsb = xs + (pipe ? xb : (k & 1)) * (LH * LW);
+            long long *pslot = nullptr;   // diagnostic time stamps of round 0 for two workgroups
+            if (PROF && prof && round == 0 && tid == 0 && (blockIdx.x == 0 || blockIdx.x == gridDim.x / 2) && k < 256)
+                pslot = prof + ((blockIdx.x == 0 ? 0 : 256) + k) * 4;
+            if (PROF && pslot) pslot[0] = wall_clock64();
+
+            // ---- [A] poll + stage x_t[c] of the tile and its halo (polling waves) ----
+            // All tiles of an image run in lock step, so nothing is ready right after our own stores:
+            // an unprefetched poll (C = 1) goes out `poll_delay` behind them so that it samples memory
+            // just after the neighbours' stores have landed.  Polling early is worse than useless
+            // (delay 0: 4.3 us per sweep, delay 20: 2.6 — early loads pull stale lines that the
+            // stores must then displace, and a miss costs a whole ~0.85 us round trip).
+            if (poller) {
+                unsigned pend = vmask;
+                if (!polled) {
+                    if (!fresh) nap(job_delay);
+                    issue(src, c * ch_bytes);
+                }
+                if (timeout_ticks < 0 && k > 0) {       // test hook (option inject_timeout): give up at the first hand-off
+                    if (lane == 0 && atomicCAS(err, 0u, 1u) == 0u) {
+                        err[1] = (unsigned)je.x;
+                        err[2] = (unsigned)t;
+                        err[3] = blockIdx.x;
+                    }
+                    *abort_flag = 1;
+                    pend = 0;
+                }
+                long long t_start = 0;
+                for (;;) {
+#pragma unroll
+                    for (int kk = 0; kk < NK; ++kk) {
+                        if (((pend >> (2 * kk)) & 1u) && va[kk].y == want) {
+                            xsb[btab[kk] & 0xfff] = __uint_as_float(va[kk].x);
+                            pend &= ~(1u << (2 * kk));
+                        }
+                        if (((pend >> (2 * kk)) & 2u) && va[kk].w == want) {
+                            xsb[(btab[kk] & 0xfff) + 1] = __uint_as_float(va[kk].z);
+                            pend &= ~(2u << (2 * kk));
+                        }
+                    }
+                    if (!__builtin_amdgcn_ballot_w64(pend != 0)) break;
+                    issue(src, c * ch_bytes);
+                    const long long now = wall_clock64();
+                    if (t_start == 0) t_start = now;
+                    else if (now - t_start > timeout_ticks ||
+                             __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+                        if (lane == 0 && atomicCAS(err, 0u, 1u) == 0u) {
+                            err[1] = (unsigned)je.x;
+                            err[2] = (unsigned)t;
+                            err[3] = blockIdx.x;
+                        }
+                        *abort_flag = 1;
+                        break;
+                    }
+                }
+            }
+            __syncthreads();
+            if (*abort_flag) return;
+            if (PROF && pslot) pslot[1] = wall_clock64();
+
+            // ---- [B] prefetch: the next step's poll is issued as soon as its input can be there ----
+            // chain cn was stored C-1 steps ago: long ago for C >= 3 (issue before the arithmetic), at the
+            // end of the previous step for C = 2 (issue behind the arithmetic, ~1 us after the stores)
+            int tn = t, cn = c + 1;
+            if (cn == C) {
+                cn = 0;
+                ++tn;
+            }
+            polled = C >= 2 && k + 1 < n_steps;
+            if (polled && poller && C >= 3) issue(state_rsrc(tn), cn * ch_bytes);
+
+            // ---- [C] partial sums -> LDS -> fp64 combine -> store ----
+            if constexpr (PIPE) {
+                {
+                    const float *xrow = xsb + (ly + H) * LW + lx + HP;
+                    float acc[4];
+                    float *partf = reinterpret_cast<float *>(part);
+                    // the combining thread's pixel of step k-1: partial sums, centre term and 1/deg are requested now and
+                    // consumed behind the first row segment of this step's arithmetic
+                    const bool comb = !poller && k > 0;
+                    // recomputed from an opaque copy of the thread id every step: hoisted out of the loops these few
+                    // integers would be kernel-long registers, and the kernel has none to spare (they were spilled)
+                    int ctid = tid;
+                    asm volatile("" : "+v"(ctid));
+                    const int cprow = (ctid >> 5) & 7, cx = ctid & 31;
+                    float cps[Q];
+                    float ccen = 0.f;
+                    double civ = 0.0;
+                    if (comb) {
+                        const float *pr = partf + ((k - 1) & 1) * (kWaves * 256) + (cprow * 8 + (cx >> 2)) * 4 + (cx & 3);
+#pragma unroll
+                        for (int q = 0; q < Q; ++q) cps[q] = pr[q * 256];
+                        ccen = xs_prev[(cprow + H) * LW + cx + HP];
+                        civ = invd[ctid];
+                    }
+                    auto finish_prev = [&]() __attribute__((always_inline)) {
+                        if (!comb) return;
+                        resident_store_px<R, Q>(cps, ccen, civ, I, state_rsrc(pt + 1), pt, pc, t_total, ty0 + cprow, tx0 + cx, cx, h, w, n,
+                                                ch_bytes, plain_st);
+                    };
+                    switch (qi) {
+                        case 0: partial_sums_piped<R, 0>(wr, xrow, acc, finish_prev); break;
+                        case 1: partial_sums_piped<R, 1 % Q>(wr, xrow, acc, finish_prev); break;
+                        case 2: partial_sums_piped<R, 2 % Q>(wr, xrow, acc, finish_prev); break;
+                        case 3: partial_sums_piped<R, 3 % Q>(wr, xrow, acc, finish_prev); break;
+                        case 4: partial_sums_piped<R, 4 % Q>(wr, xrow, acc, finish_prev); break;
+                        case 5: partial_sums_piped<R, 5 % Q>(wr, xrow, acc, finish_prev); break;
+                        case 6: partial_sums_piped<R, 6 % Q>(wr, xrow, acc, finish_prev); break;
+                        default: partial_sums_piped<R, 7 % Q>(wr, xrow, acc, finish_prev); break;
+                    }
+                    int wl = lane;                     // opaque: the LDS address is rebuilt per step instead of living in a register
+                    asm volatile("" : "+v"(wl));
+                    *reinterpret_cast<f4a *>(partf + (k & 1) * (kWaves * 256) + wv * 256 + wl * 4) = f4a{acc[0], acc[1], acc[2], acc[3]};
+                }
+            }
+            if constexpr (!PIPE) {
+                const float *xrow = xsb + (ly + H) * LW + lx + HP;
+                float acc[4];
+                if (R == 10 && C == 2) {
+                    switch (qi) {
+                        case 0: partial_sums<R, 0, 0>(wr, xrow, acc); break;
+                        case 1: partial_sums<R, 1 % Q, 0>(wr, xrow, acc); break;
+                        case 2: partial_sums<R, 2 % Q, 0>(wr, xrow, acc); break;
+                        case 3: partial_sums<R, 3 % Q, 0>(wr, xrow, acc); break;
+                        case 4: partial_sums<R, 4 % Q, 0>(wr, xrow, acc); break;
+                        case 5: partial_sums<R, 5 % Q, 0>(wr, xrow, acc); break;
+                        case 6: partial_sums<R, 6 % Q, 0>(wr, xrow, acc); break;
+                        default: partial_sums<R, 7 % Q, 0>(wr, xrow, acc); break;
+                    }
+                    // C = 2: the next step's chain was stored at the end of the previous step; half-way through
+                    // the arithmetic (~0.7 us behind those stores) its poll goes out and flies under the rest
+                    if (polled && poller) issue(state_rsrc(tn), cn * ch_bytes);
+                    switch (qi) {
+                        case 0: partial_sums<R, 0, 1>(wr, xrow, acc); break;
+                        case 1: partial_sums<R, 1 % Q, 1>(wr, xrow, acc); break;
+                        case 2: partial_sums<R, 2 % Q, 1>(wr, xrow, acc); break;
+                        case 3: partial_sums<R, 3 % Q, 1>(wr, xrow, acc); break;
+                        case 4: partial_sums<R, 4 % Q, 1>(wr, xrow, acc); break;
+                        case 5: partial_sums<R, 5 % Q, 1>(wr, xrow, acc); break;
+                        case 6: partial_sums<R, 6 % Q, 1>(wr, xrow, acc); break;
+                        default: partial_sums<R, 7 % Q, 1>(wr, xrow, acc); break;
+                    }
+                } else {
+                    switch (qi) {
+                        case 0: partial_sums<R, 0, 2>(wr, xrow, acc); break;
+                        case 1: partial_sums<R, 1 % Q, 2>(wr, xrow, acc); break;
+                        case 2: partial_sums<R, 2 % Q, 2>(wr, xrow, acc); break;
+                        case 3: partial_sums<R, 3 % Q, 2>(wr, xrow, acc); break;
+                        case 4: partial_sums<R, 4 % Q, 2>(wr, xrow, acc); break;
+                        case 5: partial_sums<R, 5 % Q, 2>(wr, xrow, acc); break;
+                        case 6: partial_sums<R, 6 % Q, 2>(wr, xrow, acc); break;
+                        default: partial_sums<R, 7 % Q, 2>(wr, xrow, acc); break;
+                    }
+                    if (polled && poller && C == 2) issue(state_rsrc(tn), cn * ch_bytes);   // radius 5
+                }
+                // the wave's four chains leave as ONE 16-byte LDS write; [buffer][wave][lane][j] fp32
+                float *partf = reinterpret_cast<float *>(part);
+                int wl = lane;                         // opaque: see the pipelined steps
+                asm volatile("" : "+v"(wl));
+                *reinterpret_cast<f4a *>(partf + (k & 1) * (kWaves * 256) + wv * 256 + wl * 4) = f4a{acc[0], acc[1], acc[2], acc[3]};
+                __syncthreads();
+                if (PROF && pslot) pslot[2] = wall_clock64();
+                // One pixel per combining thread, consecutive threads = consecutive pixels of a tile row (their
+                // partial sums are contiguous in LDS).  Neighbouring lanes then swap results and the even lane
+                // stores BOTH granules with one 16-byte store (8-byte sc1 stores are the expensive form, lesson 10;
+                // folding two pixels per thread instead doubled the combine's latency chain: 0.21 -> 0.40 us).
+                if constexpr (R == 10) {
+#pragma unroll
+                for (int i = tid; i < (poller ? 0 : G::SLABS * 256); i += 256) {
+                    const int s2 = i >> 8, prow = (i >> 5) & 7, x = i & 31;
+                    const int py = (s2 / G::C::SL_X) * kSlabH + prow;
+                    const int px = (s2 % G::C::SL_X) * kSlabW + x;
+                    const float *pr = partf + (k & 1) * (kWaves * 256) + (s2 * Q) * 256 + (prow * 8 + (x >> 2)) * 4 + (x & 3);
+                    // the Q fp32 chains of the pixel: pairwise in fp32 (as close to the exact operator as adding them in
+                    // fp64: the model of tests/test_precision_model.py gives the same 1.5e-6 after 256 sweeps), then centre
+                    // term and normalisation in fp64.  A chain of Q dependent fp64 conversions + additions was most of the
+                    // combine's latency.
+                    float ps[Q];
+#pragma unroll
+                    for (int q = 0; q < Q; ++q) ps[q] = pr[q * 256];
+#pragma unroll
+                    for (int span = 1; span < Q; span *= 2)
+#pragma unroll
+                        for (int q = 0; q + span < Q; q += 2 * span) ps[q] = ps[q] + ps[q + span];
+                    const double sum = (double)xsb[(py + H) * LW + px + HP] + (double)ps[0];
+                    const float res = (float)(sum * invd[i]);
+                    // neighbour lane's result through a DPP quad permute (lanes 2n <-> 2n+1) instead of an LDS round trip
+                    const float other = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(res), 0xB1, 0xF, 0xF, true));
+                    const int yy = ty0 + py, xx = tx0 + px;
+                    if (yy < h && xx < w) {
+                        const unsigned o = (unsigned)(yy * w + xx);
+                        if (last) ((gf_t)I.out)[(unsigned)c * n + o] = res;
+                        else if ((x & 1) == 0 && xx + 1 < w) {
+                            if (plain_st) st_granule2<0>(dst, (int)o * 8, c * ch_bytes, want + 1, res, other);
+                            else st_granule2(dst, (int)o * 8, c * ch_bytes, want + 1, res, other);
+                        } else if ((x & 1) == 0) {
+                            if (plain_st) st_granule<0>(dst, (int)o * 8, c * ch_bytes, want + 1, res);
+                            else st_granule(dst, (int)o * 8, c * ch_bytes, want + 1, res);
+                        }
+                    }
+                }
+                } else {
+                    // radius 5 (1024 pixels per tile, 4 per combining thread): a pixel PAIR per thread and iteration
+                    // (0.41 vs 0.75 us for four single pixels); the sums of all iterations are formed before the
+                    // first store so that their LDS reads overlap
+                    constexpr int NIT = G::SLABS * 128 / 256;
+                    if (!poller) {
+                        float r0v[NIT], r1v[NIT];
+#pragma unroll
+                        for (int it = 0; it < NIT; ++it) {
+                            const int i = tid + it * 256;
+                            const int s2 = i >> 7, prow = (i >> 4) & 7, x = (i & 15) * 2;
+                            const int py = (s2 / G::C::SL_X) * kSlabH + prow;
+                            const int px = (s2 % G::C::SL_X) * kSlabW + x;
+                            const float *pr = partf + (k & 1) * (kWaves * 256) + (s2 * Q) * 256 + (prow * 8 + (x >> 2)) * 4 + (x & 3);
+                            const float *xc = xsb + (py + H) * LW + px + HP;
+                            float ps0 = pr[0], ps1 = pr[1];
+#pragma unroll
+                            for (int q = 1; q < Q; ++q) {
+                                ps0 += pr[q * 256];
+                                ps1 += pr[q * 256 + 1];
+                            }
+                            const double sum0 = (double)xc[0] + (double)ps0, sum1 = (double)xc[1] + (double)ps1;
+                            const int ii = s2 * 256 + prow * 32 + x;
+                            r0v[it] = (float)(sum0 * invd[ii]);
+                            r1v[it] = (float)(sum1 * invd[ii + 1]);
+                        }
+#pragma unroll
+                        for (int it = 0; it < NIT; ++it) {
+                            const int i = tid + it * 256;
+                            const int s2 = i >> 7, prow = (i >> 4) & 7, x = (i & 15) * 2;
+                            const int yy = ty0 + (s2 / G::C::SL_X) * kSlabH + prow;
+                            const int xx = tx0 + (s2 % G::C::SL_X) * kSlabW + x;
+                            const float r0 = r0v[it], r1 = r1v[it];
+                            if (yy < h && xx < w) {
+                                const unsigned o = (unsigned)(yy * w + xx);
+                                if (last) {
+                                    ((gf_t)I.out)[(unsigned)c * n + o] = r0;
+                                    if (xx + 1 < w) ((gf_t)I.out)[(unsigned)c * n + o + 1] = r1;
+                                } else if (xx + 1 < w) {
+                                    if (plain_st) st_granule2<0>(dst, (int)o * 8, c * ch_bytes, want + 1, r0, r1);
+                                    else st_granule2(dst, (int)o * 8, c * ch_bytes, want + 1, r0, r1);
+                                } else {
+                                    if (plain_st) st_granule<0>(dst, (int)o * 8, c * ch_bytes, want + 1, r0);
+                                    else st_granule(dst, (int)o * 8, c * ch_bytes, want + 1, r0);
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+            fresh = false;
+            // C = 1: the next poll is timed from our own stores, so every wave has to start its delay
+            // behind them (the waves that do not combine would otherwise poll ~0.2 us early)
+            if (C == 1) __syncthreads();
+            if (PROF && pslot) pslot[3] = wall_clock64();
+            pt = t;
+            pc = c;
+            xs_prev = xsb;
+            xb = xb == 2 ? 0 : xb + 1;
+            t = tn;
+            c = cn;
+        }
+        if constexpr (PIPE) {
+            if (n_steps > 0) {          // the last step of a pipelined job is combined behind the loop
+                __syncthreads();
+                if (!poller) {
+                    int ctid = tid;
+                    asm volatile("" : "+v"(ctid));
+                    const int cprow = (ctid >> 5) & 7, cx = ctid & 31;
+                    const float *pr = reinterpret_cast<const float *>(part) + ((n_steps - 1) & 1) * (kWaves * 256) +
+                                      (cprow * 8 + (cx >> 2)) * 4 + (cx & 3);
+                    float cps[Q];
+#pragma unroll
+                    for (int q = 0; q < Q; ++q) cps[q] = pr[q * 256];
+                    resident_store_px<R, Q>(cps, xs_prev[(cprow + H) * LW + cx + HP], invd[ctid], I, state_rsrc(pt + 1), pt, pc, t_total,
+                                            ty0 + cprow, tx0 + cx, cx, h, w, n, ch_bytes, plain_st);
+                }
+            }
+        }
+    }
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------
+static void tile_shape(int radius, int *th, int *tw) {
+    if (radius == 10) { *th = Geom<10>::TH; *tw = Geom<10>::TW; }
+    else { *th = Geom<5>::TH; *tw = Geom<5>::TW; }
+}
+
+bool resident_supported(const irn_walk_ctx *ctx) { return ctx->radius == 5 || ctx->radius == 10; }
+
+template <int R, bool PROF, bool PIPE = false>
+static int resident_capacity(int n_cu, int *capacity);
+
+void resident_destroy(irn_walk_ctx *ctx) {
+    if (ctx->res_jobs_dev) (void)hipFree(ctx->res_jobs_dev);
+    if (ctx->res_err_dev) (void)hipFree(ctx->res_err_dev);
+    if (ctx->res_err_host) (void)hipHostFree(ctx->res_err_host);
+    if (ctx->res_prof_dev) (void)hipFree(ctx->res_prof_dev);
+    if (ctx->res_votes_dev) (void)hipFree(ctx->res_votes_dev);
+    ctx->res_votes_dev = nullptr;
+    ctx->res_votes_cap = 0;
+    ctx->res_prof_dev = nullptr;
+    ctx->res_jobs_dev = nullptr;
+    ctx->res_err_dev = nullptr;
+    ctx->res_err_host = nullptr;
+}
+
+// Pack the batch into rounds of at most n_wg tiles.  Sets ctx->res_ok = false (not an error) when an
+// image does not fit one round or is narrower than the radius (then irn_walk_run falls back to the
+// streaming sweeps).
+int resident_configure(irn_walk_ctx *ctx) {
+    ctx->res_ok = false;
+    if (!resident_supported(ctx)) return IRN_OK;
+    if (ctx->res_nwg == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        IRN_HIP_TRY(hipGetDevice(&dev));
+        IRN_HIP_TRY(hipGetDeviceProperties(&prop, dev));
+        ctx->res_nwg = prop.multiProcessorCount;
+    }
+    const int n_wg = ctx->res_nwg;
+    int th, tw;
+    tile_shape(ctx->radius, &th, &tw);
+    const int n = (int)ctx->h.size();
+    std::vector<int> tiles(n);
+    for (int i = 0; i < n; ++i) {
+        if (ctx->w[i] < ctx->radius) return IRN_OK;
+        tiles[i] = cdiv(ctx->h[i], th) * cdiv(ctx->w[i], tw);
+        if (tiles[i] > n_wg) return IRN_OK;
+    }
+    // First-fit over the images in descending cost order (channels = steps per sweep, then tiles);
+    // slots of an image are consecutive.  Workgroups run their rounds back to back without a grid
+    // barrier, so what matters is that the tile groups sharing a round carry similar work (equal
+    // channel counts) and that the light images form the tail.  Results do not depend on the order.
+    std::vector<int> order(n);
+    for (int i = 0; i < n; ++i) order[i] = i;
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
+        if (ctx->c[a] != ctx->c[b]) return ctx->c[a] > ctx->c[b];
+        return tiles[a] > tiles[b];
+    });
+    std::vector<std::vector<int4>> rounds;
+    std::vector<int> used;
+    for (int oi = 0; oi < n; ++oi) {
+        const int i = order[oi];
+        size_t r = 0;
+        for (; r < rounds.size(); ++r)
+            if (used[r] + tiles[i] <= n_wg) break;
+        if (r == rounds.size()) {
+            rounds.emplace_back(n_wg, make_int4(-1, 0, 0, 0));
+            used.push_back(0);
+        }
+        for (int ty = 0; ty < ctx->h[i]; ty += th)
+            for (int tx = 0; tx < ctx->w[i]; tx += tw) {
+                const int slot = used[r]++;
+                // consecutive slots share an XCD: block b is dispatched to XCD b % 8 (observed)
+                const int per = (n_wg + 7) / 8;
+                int b = (slot % per) * 8 + slot / per;
+                if (n_wg % 8 != 0 || b >= n_wg) b = slot;
+                rounds[r][b] = make_int4(i, ty, tx, tiles[i]);
+            }
+    }
+    const int total = (int)rounds.size() * n_wg;
+    if (total > ctx->res_cap_jobs) {
+        if (ctx->res_jobs_dev) (void)hipFree(ctx->res_jobs_dev);
+        ctx->res_jobs_dev = nullptr;
+        IRN_HIP_TRY(hipMalloc((void **)&ctx->res_jobs_dev, sizeof(int4) * total));
+        ctx->res_cap_jobs = total;
+    }
+    std::vector<int4> flat;
+    flat.reserve(total);
+    for (auto &r : rounds) flat.insert(flat.end(), r.begin(), r.end());
+    IRN_HIP_TRY(hipMemcpy(ctx->res_jobs_dev, flat.data(), sizeof(int4) * total, hipMemcpyHostToDevice));
+    if (ctx->res_votes_cap < n) {
+        if (ctx->res_votes_dev) (void)hipFree(ctx->res_votes_dev);
+        ctx->res_votes_dev = nullptr;
+        IRN_HIP_TRY(hipMalloc((void **)&ctx->res_votes_dev, sizeof(unsigned long long) * n));
+        ctx->res_votes_cap = n;
+    }
+    if (!ctx->res_err_dev) {
+        IRN_HIP_TRY(hipMalloc((void **)&ctx->res_err_dev, 4 * sizeof(unsigned)));
+        IRN_HIP_TRY(hipHostMalloc((void **)&ctx->res_err_host, 4 * sizeof(unsigned), hipHostMallocDefault));
+    }
+    ctx->res_rounds = (int)rounds.size();
+    ctx->res_max_round_channels = 1;
+    ctx->res_min_round_channels = n ? ctx->c[0] : 0;
+    for (int i = 0; i < n; ++i) {
+        ctx->res_max_round_channels = std::max(ctx->res_max_round_channels, ctx->c[i]);
+        ctx->res_min_round_channels = std::min(ctx->res_min_round_channels, ctx->c[i]);
+    }
+    // the grid must be co-resident: ask the runtime how many workgroups of this kernel fit (a partitioned device or a
+    // different LDS / register budget changes the answer); otherwise the streaming sweeps take the batch
+    int capacity = 0;
+    const int rc_cap = ctx->radius == 10 ? resident_capacity<10, false>(n_wg, &capacity) : resident_capacity<5, false>(n_wg, &capacity);
+    if (rc_cap) return rc_cap;
+    ctx->res_ok = capacity >= n_wg;
+    return IRN_OK;
+}
+
+// One workgroup per compute unit only works if every workgroup of the grid is resident at the same time (tiles wait
+// for each other inside the launch).  How many fit is asked of the runtime, not assumed: 1 workgroup of 8 waves x 256
+// VGPRs and ~100 KB of LDS per compute unit on an idle MI355X.
+template <int R, bool PROF, bool PIPE>
+static int resident_capacity(int n_cu, int *capacity) {
+    using G = Geom<R>;
+    int dev = 0;
+    IRN_HIP_TRY(hipGetDevice(&dev));
+    static bool attr_set[64] = {};                  // the dynamic-LDS limit is a per-device function attribute (one flag set per instantiation)
+    if (dev < 0 || dev >= 64) return fail(IRN_ERR_STATE, "device ordinal %d out of range", dev);
+    if (!attr_set[dev]) {
+        IRN_HIP_TRY(hipFuncSetAttribute((const void *)resident_kernel<R, PROF, PIPE>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        G::LDS_BYTES));
+        attr_set[dev] = true;
+    }
+    int per_cu = 0;
+    IRN_HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void *)resident_kernel<R, PROF, PIPE>, 512,
+                                                             G::LDS_BYTES));
+    *capacity = per_cu * n_cu;
+    return IRN_OK;
+}
+
+template <int R, bool PROF, bool PIPE = false>
+static int launch_resident(irn_walk_ctx *ctx, int t_first, int t_count, int t_total, hipStream_t stream) {
+    using G = Geom<R>;
+    int capacity = 0;
+    int rc = resident_capacity<R, PROF, PIPE>(ctx->res_nwg, &capacity);
+    if (rc) return rc;
+    if (capacity < ctx->res_nwg)
+        return fail(IRN_ERR_STATE, "resident walk: only %d of %d workgroups can be resident", capacity, ctx->res_nwg);
+    // Bounded waits: a tile that cannot make progress reports instead of hanging.  The bound covers the slowest legal
+    // wait — a workgroup that has moved on to its next round waits for neighbours still busy with a heavy image of the
+    // previous one — so it grows with the work of the launch (3 us per channel-step is twice the measured rate).
+    long long ticks = 200000000LL;                  // 2 s of the 100 MHz wall clock
+    ticks += 4LL * 300LL * (long long)ctx->res_max_round_channels * (long long)t_count * (long long)std::max(ctx->res_rounds, 1);
+    if (ctx->res_inject_timeout) {                  // test hook: every poll that misses once gives up
+        ticks = -1;
+        ctx->res_inject_timeout = 0;
+    }
+    unsigned long long *votes = nullptr;
+    if (R == 5 && ctx->res_plain_store) {           // one vote word per image, cleared before every launch
+        votes = ctx->res_votes_dev;
+        IRN_HIP_TRY(hipMemsetAsync(votes, 0, sizeof(unsigned long long) * ctx->n, stream));
+    }
+    const WalkImg *imgs = ctx->imgs_dev;
+    const int4 *jobs = ctx->res_jobs_dev;
+    int n_rounds = ctx->res_rounds;
+    unsigned *err = ctx->res_err_dev;
+    long long *prof = ctx->res_prof_dev;
+    int delays = ctx->res_poll_delay | (ctx->res_poll_delay_plain << 16);
+    if (ctx->res_cooperative && !ctx->res_coop_refused) {
+        void *args[] = {&imgs, &jobs, &n_rounds, &t_first, &t_count, &t_total, &err, &ticks, &prof, &delays, &votes};
+        const hipError_t e = hipLaunchCooperativeKernel((const void *)resident_kernel<R, PROF, PIPE>, dim3(ctx->res_nwg), dim3(512),
+                                                        args, G::LDS_BYTES, stream);
+        if (e == hipSuccess) return IRN_OK;
+        (void)hipGetLastError();                    // refused (e.g. a partition without cooperative queues): plain launch,
+        ctx->res_coop_refused = true;               // the occupancy check above still holds
+    }
+    hipLaunchKernelGGL((resident_kernel<R, PROF, PIPE>), dim3(ctx->res_nwg), dim3(512), G::LDS_BYTES, stream, imgs, jobs, n_rounds,
+                       t_first, t_count, t_total, err, ticks, prof, delays, votes);
+    IRN_LAUNCH_CHECK("resident_kernel");
+    return IRN_OK;
+}
+
+// x_0 and all sweeps of the configured batch.  The descriptors (imgs_dev) are already uploaded.
+int resident_run(irn_walk_ctx *ctx, int n_sweeps, hipStream_t stream) {
+    const int n = ctx->n;
+    IRN_HIP_TRY(hipMemsetAsync(ctx->res_err_dev, 0, 4 * sizeof(unsigned), stream));
+    hipLaunchKernelGGL(x0_granule_kernel, dim3(cdiv(ctx->max_n, 256), n), dim3(256), 0, stream, ctx->imgs_dev);
+    IRN_LAUNCH_CHECK("x0_granule_kernel");
+    const int step = ctx->res_sweeps_per_launch > 0 ? ctx->res_sweeps_per_launch : n_sweeps;
+    for (int t = 0; t < n_sweeps; t += step) {
+        const int cnt = std::min(step, n_sweeps - t);
+        int rc;
+        if (ctx->res_prof_dev)
+            rc = ctx->radius == 10 ? launch_resident<10, true>(ctx, t, cnt, n_sweeps, stream)
+                                   : launch_resident<5, true>(ctx, t, cnt, n_sweeps, stream);
+        else if (ctx->radius == 10 && IRN_PIPELINED_STEPS && ctx->res_pipelined && ctx->res_min_round_channels >= 3)
+            rc = launch_resident<10, false, true>(ctx, t, cnt, n_sweeps, stream);      // every image has >= 3 channels
+        else
+            rc = ctx->radius == 10 ? launch_resident<10, false>(ctx, t, cnt, n_sweeps, stream)
+                                   : launch_resident<5, false>(ctx, t, cnt, n_sweeps, stream);
+        if (rc) return rc;
+    }
+    IRN_HIP_TRY(hipMemcpyAsync(ctx->res_err_host, ctx->res_err_dev, 4 * sizeof(unsigned), hipMemcpyDeviceToHost, stream));
+    return IRN_OK;
+}
+
+}  // namespace irn
