@@ -636,7 +636,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 }
                 // the wave's four chains leave as ONE 16-byte LDS write; [buffer][wave][lane][j] fp32
                 float *partf = reinterpret_cast<float *>(part);
-                *reinterpret_cast<f4a *>(partf + (k & 1) * (kWaves * 256) + wv * 256 + lane * 4) = f4a{acc[0], acc[1], acc[2], acc[3]};
+                int wl = lane;                         // opaque: the LDS address is rebuilt per step instead of living in a register
+                asm volatile("" : "+v"(wl));
+                *reinterpret_cast<f4a *>(partf + (k & 1) * (kWaves * 256) + wv * 256 + wl * 4) = f4a{acc[0], acc[1], acc[2], acc[3]};
                 __syncthreads();
                 if (PROF && pslot) pslot[2] = wall_clock64();
                 // One pixel per combining thread, consecutive threads = consecutive pixels of a tile row (their
