@@ -477,7 +477,7 @@ def run_workload(a, workload, rank, world, device, dist, parallel, steps, warmup
 
 
 LEG_RUNS = {   # short runs for the `legs` object of the default line: (steps, warmup, batch)
-    "cam": (2, 1, 8), "e2e": (2, 1, 8), "steps": (1, 1, 64), "walk_r5": (3, 1, 256), "ins": (8, 2, 64), "ins_r10": (6, 2, 64), "coco": (3, 1, 2),
+    "cam": (2, 1, 8), "e2e": (2, 1, 8), "steps": (1, 1, 128), "walk_r5": (3, 1, 256), "ins": (8, 2, 64), "ins_r10": (6, 2, 64), "coco": (3, 1, 2),
 }
 
 
