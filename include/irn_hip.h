@@ -112,6 +112,23 @@ int irn_walk_run(irn_walk_ctx *ctx, const float *const *edge_dev, const float *c
                  float *const *out_dev, float beta, int n_sweeps,
                  void *workspace_dev, size_t workspace_bytes, void *stream);
 
+/* How x . T^n_sweeps is evaluated (round 3).  T is similar to a symmetric matrix with spectrum in [-1, 1], and
+ * lambda^n = sum_k c_k T_k(lambda) (Chebyshev polynomials) with c_k = 2^(1-n) C(n, (n-k)/2) ~ exp(-k^2 / 2n): the terms
+ * beyond K ~ sqrt(2 n ln(1/tol)) are dropped (their sum is the bound `tol` on the change of the result, 1e-7 by default:
+ * below the rounding of the fp32 state) and the walk runs the three-term recurrence y_{t+1} = 2 T y_t - y_{t-1} for K
+ * operator applications instead of n (84 instead of 256 at exp_times = 8), accumulating s = sum_k c_k y_k.  Measured
+ * against the fp64 oracle the result is as close as that of the plain iteration (tests/test_gpu_schedule.py).
+ *   option "accel" = 1 (default) / 0: truncated Chebyshev series / plain powers (n applications, bit-identical to the
+ *   recurrence-free kernels of rounds 1-2); "accel_tol_exp" = e: tol = 10^-e (default 7).
+ *   irn_walk_steps reports the operator applications a run with `n_sweeps` would execute (for flop accounting).
+ * The caller's edge / cam / inst_map device buffers must stay valid and unmodified until irn_walk_sync (or the next
+ * irn_walk_run) returns: a run that irn_walk_sync has to repeat reads them again. */
+int irn_walk_steps(irn_walk_ctx *ctx, int n_sweeps, int *n_steps);
+/* The series itself (host only, no device needed): *n_steps = K operator applications, *recurrence = 1 for the
+ * three-term recurrence / 0 for plain powers (n < 8 or nothing to gain), coef_out[0..K] = c_k renormalised to sum 1
+ * (may be NULL; coef_cap = its capacity). */
+int irn_power_series(int n, int tol_exp, double *coef_out, int coef_cap, int *n_steps, int *recurrence);
+
 /* Tuning knobs (performance only, never results): name/value pairs, e.g. "variant" = 0 generic table-driven sweep
  * (any radius; the default for radii other than 5 and 10), 1 = register-blocked streaming sweep (radius 5/10),
  * 2 = weights-stationary persistent walk (radius 5/10; the DEFAULT there, with a per-batch fall-back to variant 1

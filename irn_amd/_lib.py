@@ -40,6 +40,8 @@ _SIGS = {
     "irn_walk_configure": (i32, [vp, i32, pi32, pi32, pi32, C.POINTER(sz)]),
     "irn_walk_run": (i32, [vp, ppv, ppv, ppv, pi32, ppv, f32, i32, vp, sz, vp]),
     "irn_walk_set_option": (i32, [vp, C.c_char_p, i32]),
+    "irn_walk_steps": (i32, [vp, i32, C.POINTER(i32)]),
+    "irn_power_series": (i32, [i32, i32, C.POINTER(C.c_double), i32, C.POINTER(i32), C.POINTER(i32)]),
     "irn_walk_sync": (i32, [vp, C.POINTER(i32)]),
     "irn_walk_check": (i32, [vp]),
     "irn_walk_fallback_runs": (i32, [vp]),

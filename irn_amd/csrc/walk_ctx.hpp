@@ -16,6 +16,8 @@ struct WalkImg {
     float *wts;          // plane 0 / pixel 0 (front pad lies before it)
     double *inv_deg;     // [h*w]
     float *xa, *xb;      // [C, h*w] ping-pong state: fp32 (streaming sweeps) or 8-byte {tag,value} granules (resident)
+    float *xc;           // [C, h*w] x 8 bytes, private to the pixel's owner: the polynomial schedule's carried terms —
+                         // resident walk: {y_{t-1}, s_t} pairs; streaming sweeps: s_t as plain fp32 [C, h*w]
     int h, w, C, k_inst;
     long plane_stride;
     int front_pad, n_dirs;
@@ -72,7 +74,7 @@ struct irn_walk_ctx {
     // batch
     int n = 0;
     std::vector<int> h, w, c;
-    std::vector<size_t> off_wts, off_deg, off_xa, off_xb;   // byte offsets into the workspace
+    std::vector<size_t> off_wts, off_deg, off_xa, off_xb, off_xc;   // byte offsets into the workspace
     std::vector<long> plane_stride;
     std::vector<int> front_pad;
     size_t ws_bytes = 0;
@@ -123,6 +125,16 @@ struct irn_walk_ctx {
     bool last_valid = false, last_resident = false;
     int last_n_sweeps = 0;
     int fallback_runs = 0;                 // batches re-run on the streaming sweeps after a resident time-out
+    // polynomial schedule of the walk (walk.hip: irn::walk_schedule)
+    int accel = 1;                         // 1: T^n as a truncated Chebyshev series when that needs fewer operator applications
+    int accel_tol_exp = 7;                 // truncation bound 10^-accel_tol_exp on the series' dropped coefficients
+    int sched_n = -1, sched_accel = -1, sched_tol = -1;   // what coef_dev currently holds
+    int sched_steps = 0;                   // operator applications of the schedule
+    bool sched_cheb = false;               // three-term recurrence (else plain powers)
+    float *coef_dev = nullptr;             // [sched_steps + 1] series coefficients c_0 .. c_steps
+    std::vector<double> sched_coef;        // the same on the host
+    std::vector<float> sched_coef_f;       // staging of the upload (must outlive the asynchronous copy)
+    int coef_cap = 0;
 };
 
 namespace irn {
@@ -130,6 +142,12 @@ namespace irn {
 bool resident_supported(const irn_walk_ctx *ctx);
 int resident_configure(irn_walk_ctx *ctx);
 int resident_run(irn_walk_ctx *ctx, int n_sweeps, hipStream_t stream);
+// walk.hip: the schedule that evaluates x . T^n_sweeps for this context's options (uploads the coefficient table on
+// first use; stream-ordered) — ctx->sched_steps operator applications
+int walk_schedule(irn_walk_ctx *ctx, int n_sweeps, hipStream_t stream);
+// series coefficients of lambda^n in the Chebyshev basis, truncated where the dropped ones sum to <= tol; returns the
+// number of recurrence steps K (coef gets K + 1 entries), or n itself with the unit "series" when that is not shorter
+int chebyshev_power_series(int n, double tol, std::vector<double> *coef, bool *cheb);
 // walk.hip: degree + x0 + n_sweeps streaming sweeps of the configured batch (weights already built)
 int streaming_run(irn_walk_ctx *ctx, int n_sweeps, hipStream_t stream, bool timed);
 void resident_destroy(irn_walk_ctx *ctx);

@@ -31,6 +31,12 @@
 //   after every reader of its x_t has finished reading.  Polls are bounded (wall clock): a
 //   workgroup that cannot make progress reports through `err` and the launch fails loudly.
 //
+// Schedule (round 3, walk.hip header): a step is one application of the operator inside the three-term recurrence
+//   y_{t+1} = 2 T y_t - y_{t-1},  s += c_{t+1} y_{t+1}   (first step y_1 = T y_0; plain powers when `cheb` is 0)
+// — what is exchanged between tiles is y_t, exactly as before; y_{t-1} and s of a pixel are private to the thread that
+// combines it and live in LDS ({prev, s} pairs, Geom::CAPC channels) or, for the channels beyond that, in the `xc`
+// region of the workspace (plain loads and stores by the owner).  The last step hands out s.
+//
 // Scheduling: grid = one workgroup per CU.  The host packs images into rounds of <= #CU tiles in
 // descending cost order (tile = 8x32 px at radius 10, 16x64 at radius 5); workgroup b runs
 // job[round][b] for every round.
@@ -48,6 +54,9 @@ typedef const double IRN_GLOBAL *gcd_t;
 typedef float IRN_GLOBAL *gf_t;
 typedef float f4a __attribute__((ext_vector_type(4)));
 
+#ifndef IRN_PS_LDS_BYTES
+#define IRN_PS_LDS_BYTES (96 * 1024)       // LDS spent on the recurrence's private terms: 48 channels at radius 10, 12 at radius 5
+#endif
 constexpr int kSlabH = 8, kSlabW = 32;     // 64 lanes x 4 px
 constexpr int kWaves = 8;                  // 512 threads
 
@@ -112,7 +121,12 @@ struct Geom {
     static constexpr int XS_BYTES = 2 * LH * LW * 4;               // [2][LH][LW] fp32, double-buffered per step
     static constexpr int PART_BYTES = 2 * kWaves * 4 * 64 * 8;      // [2][wave][lane][j]: fp64 for the degree (prologue), fp32 chains in the steps
     static constexpr int INVD_BYTES = SLABS * 4 * 64 * 8;           // [slab][row][column] fp64
-    static constexpr int LDS_BYTES = XS_BYTES + PART_BYTES + INVD_BYTES + 16;
+    // {y_{t-1}, s_t} of the tile's own pixels for the first CAPC channels of a job (the rest go through the workspace)
+    static constexpr int TPX = TH * TW;
+    static constexpr int CAPC = IRN_PS_LDS_BYTES / (TPX * 8);
+    static constexpr int PS_OFF = XS_BYTES + PART_BYTES + INVD_BYTES + 16;
+    static constexpr int LDS_BYTES = PS_OFF + CAPC * TPX * 8;
+    static_assert(LDS_BYTES <= 160 * 1024, "LDS budget of one compute unit");
 };
 
 // first / last neighbour of row dy inside wave part QI (raster order => contiguous), or lo > hi
@@ -324,7 +338,8 @@ __device__ __forceinline__ void st_granule2(__amdgpu_buffer_rsrc_t rsrc, int vof
 
 // x_0 = cam * (1 - edge) (misc/indexing.py:162; instance split step/make_ins_seg_labels.py:77-80) as
 // granules with tag 1 into xa; xb's tags are cleared so that no stale tag of an earlier run matches.
-__global__ __launch_bounds__(256) void x0_granule_kernel(const WalkImg *__restrict__ imgs) {
+typedef float f2a __attribute__((ext_vector_type(2)));
+__global__ __launch_bounds__(256) void x0_granule_kernel(const WalkImg *__restrict__ imgs, int cheb, float c0) {
     const WalkImg I = imgs[blockIdx.y];
     const long n = (long)I.h * I.w;
     const long p = (long)blockIdx.x * 256 + threadIdx.x;
@@ -339,6 +354,7 @@ __global__ __launch_bounds__(256) void x0_granule_kernel(const WalkImg *__restri
         if (I.inst) v = v * (id == kk ? 1.0f : 0.0f);
         xa[(long)c * n + p] = ((u64)1 << 32) | (u64)__float_as_uint(v * one_minus);
         xb[(long)c * n + p] = 0;
+        if (cheb) ((f2a *)I.xc)[(long)c * n + p] = f2a{0.f, c0 * (v * one_minus)};     // {y_{-1}, s_0 = c_0 y_0}
     }
 }
 
@@ -347,7 +363,8 @@ __global__ __launch_bounds__(256) void x0_granule_kernel(const WalkImg *__restri
 template <int R, bool PROF>
 __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void resident_kernel(
     const WalkImg *__restrict__ imgs, const int4 *__restrict__ jobs, int n_rounds, int t_first, int t_count,
-    int t_total, unsigned *err, long long timeout_ticks, long long *prof, int poll_delay, unsigned long long *votes) {
+    int t_total, unsigned *err, long long timeout_ticks, long long *prof, int poll_delay, unsigned long long *votes,
+    const float *__restrict__ coef, int cheb) {
     using G = Geom<R>;
     constexpr int H = G::H, HP = G::HP, LH = G::LH, LW = G::LW, LWU = G::LWU, RG = G::RG, Q = G::Q, NK = G::NK;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -355,6 +372,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     double *part = reinterpret_cast<double *>(smem + G::XS_BYTES);
     double *invd = reinterpret_cast<double *>(smem + G::XS_BYTES + G::PART_BYTES);
     int *abort_flag = reinterpret_cast<int *>(smem + G::XS_BYTES + G::PART_BYTES + G::INVD_BYTES);
+    f2a *psl = reinterpret_cast<f2a *>(smem + G::PS_OFF);          // [CAPC][TPX] {y_{t-1}, s_t}, combine's pixel order
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -485,6 +503,21 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             if (ok1) vmask |= 2u << (2 * k);
         }
         for (int i = tid; i < 2 * LH * LW; i += 512) xs[i] = 0.f;
+        // the recurrence's private terms {y_{t-1}, s_t} of the tile's own pixels, first CAPC channels: from the workspace
+        // (written by x0_granule_kernel, or by the previous launch of a walk cut into several) into LDS
+        const __amdgpu_buffer_rsrc_t prs =
+            __builtin_amdgcn_make_buffer_rsrc((void *)I.xc, 0, (int)(8u * n * (unsigned)I.C), 0x00020000);
+        const int c_lds = cheb ? (I.C < G::CAPC ? I.C : G::CAPC) : 0;
+        for (int idx = tid; idx < c_lds * G::TPX; idx += 512) {
+            const int cc = idx / G::TPX, i = idx - cc * G::TPX;
+            const int s2 = i >> 8, prow = (i >> 5) & 7, x = i & 31;
+            const int yy = ty0 + (s2 / G::C::SL_X) * kSlabH + prow;
+            const int xx = tx0 + (s2 % G::C::SL_X) * kSlabW + x;
+            f2a v{0.f, 0.f};
+            if (yy < h && xx < w)
+                v = __builtin_bit_cast(f2a, __builtin_amdgcn_raw_buffer_load_b64(prs, (yy * w + xx) * 8, cc * (int)(8u * n), 0));
+            psl[idx] = v;
+        }
         __syncthreads();
 
         // ---- the walk of this tile: a pipeline of steps (sweep t, channel c), c fastest ----
@@ -522,6 +555,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             const __amdgpu_buffer_rsrc_t src = state_rsrc(t), dst = state_rsrc(t + 1);
             const bool last = (t + 1 == t_total);
             const unsigned want = (unsigned)(t + 1);
+            const float ck = cheb ? coef[t + 1] : 0.f;       // coefficient of y_{t+1} in the series (scalar load)
+            const bool rec2 = cheb && t > 0;                 // y_{t+1} = 2 T y_t - y_{t-1}; the first step is y_1 = T y_0
             float *xsb = xs + (k & 1) * (LH * LW);
             long long *pslot = nullptr;   // diagnostic time stamps of round 0 for two workgroups
             if (PROF && prof && round == 0 && tid == 0 && (blockIdx.x == 0 || blockIdx.x == gridDim.x / 2) && k < 256)
@@ -652,6 +687,16 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     const int py = (s2 / G::C::SL_X) * kSlabH + prow;
                     const int px = (s2 % G::C::SL_X) * kSlabW + x;
                     const float *pr = partf + (k & 1) * (kWaves * 256) + (s2 * Q) * 256 + (prow * 8 + (x >> 2)) * 4 + (x & 3);
+                    const int yy = ty0 + py, xx = tx0 + px;
+                    const bool inimg = yy < h && xx < w;
+                    const unsigned o = (unsigned)(yy * w + xx);
+                    // {y_{t-1}, s_t} of this pixel: LDS for the first CAPC channels, else the workspace (asked for first:
+                    // an L2 round trip that the partial sums below cover)
+                    f2a pv{0.f, 0.f};
+                    if (cheb) {
+                        if (c < G::CAPC) pv = psl[c * G::TPX + i];
+                        else if (inimg) pv = __builtin_bit_cast(f2a, __builtin_amdgcn_raw_buffer_load_b64(prs, (int)o * 8, c * ch_bytes, 0));
+                    }
                     // the Q fp32 chains of the pixel: pairwise in fp32 (as close to the exact operator as adding them in
                     // fp64: the model of tests/test_precision_model.py gives the same 1.5e-6 after 256 sweeps), then centre
                     // term and normalisation in fp64.  A chain of Q dependent fp64 conversions + additions was most of the
@@ -663,14 +708,21 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     for (int span = 1; span < Q; span *= 2)
 #pragma unroll
                         for (int q = 0; q + span < Q; q += 2 * span) ps[q] = ps[q] + ps[q + span];
-                    const double sum = (double)xsb[(py + H) * LW + px + HP] + (double)ps[0];
-                    const float res = (float)(sum * invd[i]);
+                    const float centre = xsb[(py + H) * LW + px + HP];
+                    const double m = ((double)centre + (double)ps[0]) * invd[i];
+                    const float res = rec2 ? (float)(2.0 * m - (double)pv.x) : (float)m;
+                    float outv = res;
+                    if (cheb) {
+                        outv = fmaf(ck, res, pv.y);
+                        const f2a nv{centre, outv};
+                        if (c < G::CAPC) psl[c * G::TPX + i] = nv;
+                        else if (inimg && !last)
+                            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2v, nv), prs, (int)o * 8, c * ch_bytes, 0);
+                    }
                     // neighbour lane's result through a DPP quad permute (lanes 2n <-> 2n+1) instead of an LDS round trip
                     const float other = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(res), 0xB1, 0xF, 0xF, true));
-                    const int yy = ty0 + py, xx = tx0 + px;
-                    if (yy < h && xx < w) {
-                        const unsigned o = (unsigned)(yy * w + xx);
-                        if (last) ((gf_t)I.out)[(unsigned)c * n + o] = res;
+                    if (inimg) {
+                        if (last) ((gf_t)I.out)[(unsigned)c * n + o] = outv;
                         else if ((x & 1) == 0 && xx + 1 < w) {
                             if (plain_st) st_granule2<0>(dst, (int)o * 8, c * ch_bytes, want + 1, res, other);
                             else st_granule2(dst, (int)o * 8, c * ch_bytes, want + 1, res, other);
@@ -695,16 +747,46 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                             const int px = (s2 % G::C::SL_X) * kSlabW + x;
                             const float *pr = partf + (k & 1) * (kWaves * 256) + (s2 * Q) * 256 + (prow * 8 + (x >> 2)) * 4 + (x & 3);
                             const float *xc = xsb + (py + H) * LW + px + HP;
+                            const int ii = s2 * 256 + prow * 32 + x;
+                            const int yy = ty0 + py, xx = tx0 + px;
+                            const bool in0 = yy < h && xx < w, in1 = in0 && xx + 1 < w;
+                            const unsigned o = (unsigned)(yy * w + xx);
+                            // {y_{t-1}, s_t} of the pixel pair (see the radius-10 branch)
+                            f4a pv{0.f, 0.f, 0.f, 0.f};
+                            if (cheb) {
+                                if (c < G::CAPC) pv = *reinterpret_cast<const f4a *>(psl + c * G::TPX + ii);
+                                else if (in1) pv = __builtin_bit_cast(f4a, __builtin_amdgcn_raw_buffer_load_b128(prs, (int)o * 8, c * ch_bytes, 0));
+                                else if (in0) {
+                                    const f2a p2 = __builtin_bit_cast(f2a, __builtin_amdgcn_raw_buffer_load_b64(prs, (int)o * 8, c * ch_bytes, 0));
+                                    pv.x = p2.x;
+                                    pv.y = p2.y;
+                                }
+                            }
                             float ps0 = pr[0], ps1 = pr[1];
 #pragma unroll
                             for (int q = 1; q < Q; ++q) {
                                 ps0 += pr[q * 256];
                                 ps1 += pr[q * 256 + 1];
                             }
-                            const double sum0 = (double)xc[0] + (double)ps0, sum1 = (double)xc[1] + (double)ps1;
-                            const int ii = s2 * 256 + prow * 32 + x;
-                            r0v[it] = (float)(sum0 * invd[ii]);
-                            r1v[it] = (float)(sum1 * invd[ii + 1]);
+                            const float ce0 = xc[0], ce1 = xc[1];
+                            const double m0 = ((double)ce0 + (double)ps0) * invd[ii], m1 = ((double)ce1 + (double)ps1) * invd[ii + 1];
+                            float r0 = rec2 ? (float)(2.0 * m0 - (double)pv.x) : (float)m0;
+                            float r1 = rec2 ? (float)(2.0 * m1 - (double)pv.z) : (float)m1;
+                            if (cheb) {
+                                const float s0 = fmaf(ck, r0, pv.y), s1 = fmaf(ck, r1, pv.w);
+                                const f4a nv{ce0, s0, ce1, s1};
+                                if (c < G::CAPC) *reinterpret_cast<f4a *>(psl + c * G::TPX + ii) = nv;
+                                else if (!last) {
+                                    if (in1) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4v, nv), prs, (int)o * 8, c * ch_bytes, 0);
+                                    else if (in0) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2v, f2a{ce0, s0}), prs, (int)o * 8, c * ch_bytes, 0);
+                                }
+                                if (last) {         // the series sum is the result
+                                    r0 = s0;
+                                    r1 = s1;
+                                }
+                            }
+                            r0v[it] = r0;
+                            r1v[it] = r1;
                         }
 #pragma unroll
                         for (int it = 0; it < NIT; ++it) {
@@ -737,6 +819,18 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             if (PROF && pslot) pslot[3] = wall_clock64();
             t = tn;
             c = cn;
+        }
+        // a walk cut into several launches (test hook): the LDS-held terms go back to the workspace for the next one
+        if (c_lds > 0 && t_first + t_count < t_total) {
+            __syncthreads();
+            for (int idx = tid; idx < c_lds * G::TPX; idx += 512) {
+                const int cc = idx / G::TPX, i = idx - cc * G::TPX;
+                const int s2 = i >> 8, prow = (i >> 5) & 7, x = i & 31;
+                const int yy = ty0 + (s2 / G::C::SL_X) * kSlabH + prow;
+                const int xx = tx0 + (s2 % G::C::SL_X) * kSlabW + x;
+                if (yy < h && xx < w)
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2v, psl[idx]), prs, (yy * w + xx) * 8, cc * (int)(8u * n), 0);
+            }
         }
     }
 }
@@ -907,8 +1001,10 @@ static int launch_resident(irn_walk_ctx *ctx, int t_first, int t_count, int t_to
     unsigned *err = ctx->res_err_dev;
     long long *prof = ctx->res_prof_dev;
     int delays = ctx->res_poll_delay | (ctx->res_poll_delay_plain << 16);
+    const float *coef = ctx->coef_dev;
+    int cheb = ctx->sched_cheb ? 1 : 0;
     if (ctx->res_cooperative && !ctx->res_coop_refused) {
-        void *args[] = {&imgs, &jobs, &n_rounds, &t_first, &t_count, &t_total, &err, &ticks, &prof, &delays, &votes};
+        void *args[] = {&imgs, &jobs, &n_rounds, &t_first, &t_count, &t_total, &err, &ticks, &prof, &delays, &votes, &coef, &cheb};
         const hipError_t e = hipLaunchCooperativeKernel((const void *)resident_kernel<R, PROF>, dim3(ctx->res_nwg), dim3(512),
                                                         args, G::LDS_BYTES, stream);
         if (e == hipSuccess) return IRN_OK;
@@ -916,7 +1012,7 @@ static int launch_resident(irn_walk_ctx *ctx, int t_first, int t_count, int t_to
         ctx->res_coop_refused = true;               // the occupancy check above still holds
     }
     hipLaunchKernelGGL((resident_kernel<R, PROF>), dim3(ctx->res_nwg), dim3(512), G::LDS_BYTES, stream, imgs, jobs, n_rounds,
-                       t_first, t_count, t_total, err, ticks, prof, delays, votes);
+                       t_first, t_count, t_total, err, ticks, prof, delays, votes, coef, cheb);
     IRN_LAUNCH_CHECK("resident_kernel");
     return IRN_OK;
 }
@@ -924,8 +1020,14 @@ static int launch_resident(irn_walk_ctx *ctx, int t_first, int t_count, int t_to
 // x_0 and all sweeps of the configured batch.  The descriptors (imgs_dev) are already uploaded.
 int resident_run(irn_walk_ctx *ctx, int n_sweeps, hipStream_t stream) {
     const int n = ctx->n;
+    {
+        const int rc_s = walk_schedule(ctx, n_sweeps, stream);     // operator applications of x . T^n_sweeps (walk.hip)
+        if (rc_s) return rc_s;
+    }
+    n_sweeps = ctx->sched_steps;
     IRN_HIP_TRY(hipMemsetAsync(ctx->res_err_dev, 0, 4 * sizeof(unsigned), stream));
-    hipLaunchKernelGGL(x0_granule_kernel, dim3(cdiv(ctx->max_n, 256), n), dim3(256), 0, stream, ctx->imgs_dev);
+    hipLaunchKernelGGL(x0_granule_kernel, dim3(cdiv(ctx->max_n, 256), n), dim3(256), 0, stream, ctx->imgs_dev,
+                       ctx->sched_cheb ? 1 : 0, ctx->sched_cheb ? (float)ctx->sched_coef[0] : 0.f);
     IRN_LAUNCH_CHECK("x0_granule_kernel");
     const int step = ctx->res_sweeps_per_launch > 0 ? ctx->res_sweeps_per_launch : n_sweeps;
     for (int t = 0; t < n_sweeps; t += step) {

@@ -243,6 +243,7 @@ class RandomWalk:
         self._sig = None
         self._ws = None
         self._ws_bytes = 0
+        self._live = None      # inputs of the last run: the re-run of `sync()` reads them again (include/irn_hip.h)
 
     def close(self):
         if self._ctx:
@@ -266,7 +267,15 @@ class RandomWalk:
         fell = C.c_int()
         with torch.cuda.device(self.device):
             check(lib.irn_walk_sync(self._ctx, C.byref(fell)))
+        self._live = None
         return bool(fell.value)
+
+    def steps(self, n_sweeps):
+        """Operator applications the context spends on x . T^n_sweeps (irn_walk_steps): n_sweeps itself for the plain
+        powers, ~sqrt(2 n ln(1/tol)) with the truncated Chebyshev series (option accel=1, the default)."""
+        k = C.c_int()
+        check(lib.irn_walk_steps(self._ctx, int(n_sweeps), C.byref(k)))
+        return int(k.value)
 
     @property
     def fallback_runs(self):
@@ -349,7 +358,10 @@ class RandomWalk:
                                    ptr_array([c.data_ptr() for c in cs]), im_ptrs, ks,
                                    ptr_array([o.data_ptr() for o in outs]), float(beta), int(n_sweeps),
                                    self._ws.data_ptr(), self._ws.numel(), _stream()))
-        del keep
+        # the edge / CAM / cluster-map tensors must outlive the run AND a possible re-run by `sync()` (which reads them
+        # again, walk.hip x0_kernel): callers routinely drop theirs right after the call, and the caching allocator would
+        # hand the blocks to the next batch's uploads
+        self._live = (es, cs, keep)
         return outs
 
     def export_weights(self, image, n_dirs):
