@@ -27,13 +27,14 @@ def _need_cuda(t, what):
         raise ValueError("%s must be a GPU tensor: the HIP path has no CPU fallback" % what)
 
 
-def label_epilogue(rws, out_sizes, bg_thres, keys=None, want_labels=True, want_argmax=False, want_rw_up=False):
+def label_epilogue(rws, out_sizes, bg_thres, keys=None, want_labels=True, want_argmax=False, want_rw_up=False, packed=False):
     """Batched x4-upsample / normalise / background / argmax.
 
     rws[i]: GPU fp32 [C,1,h,w] (or [C,h,w]); out_sizes[i] = (H, W) with H <= 4h, W <= 4w;
     keys[i]: GPU int64 [C] (0-based class ids, the CAM dict's ``keys``) when labels are wanted.
     Returns dict of lists: 'labels' uint8 [H,W] (0 = background, else key+1), 'argmax' int32 [H,W],
-    'rw_up' fp32 [C,H,W] (divided by the global max) — each present only if requested."""
+    'rw_up' fp32 [C,H,W] (divided by the global max) — each present only if requested.  With `packed` the label maps are
+    views of ONE uint8 buffer, returned as 'labels_flat' (a step brings a whole batch to the host with one copy)."""
     n = len(rws)
     dev = rws[0].device
     rs, cs, hs, ws, ohs, ows = [], [], [], [], [], []
@@ -43,7 +44,13 @@ def label_epilogue(rws, out_sizes, bg_thres, keys=None, want_labels=True, want_a
         rs.append(r)
         cs.append(r.shape[0]); hs.append(r.shape[1]); ws.append(r.shape[2])
         ohs.append(int(out_sizes[i][0])); ows.append(int(out_sizes[i][1]))
-    labels = [torch.empty((ohs[i], ows[i]), dtype=torch.uint8, device=dev) for i in range(n)] if want_labels else None
+    labels = flat = None
+    if want_labels and packed:
+        offs = np.concatenate([[0], np.cumsum([ohs[i] * ows[i] for i in range(n)])])
+        flat = torch.empty(int(offs[-1]), dtype=torch.uint8, device=dev)
+        labels = [flat[int(offs[i]):int(offs[i + 1])].view(ohs[i], ows[i]) for i in range(n)]
+    elif want_labels:
+        labels = [torch.empty((ohs[i], ows[i]), dtype=torch.uint8, device=dev) for i in range(n)]
     argmax = [torch.empty((ohs[i], ows[i]), dtype=torch.int32, device=dev) for i in range(n)] if want_argmax else None
     rw_up = [torch.empty((cs[i], ohs[i], ows[i]), dtype=torch.float32, device=dev) for i in range(n)] if want_rw_up else None
     ks = None
@@ -64,6 +71,8 @@ def label_epilogue(rws, out_sizes, bg_thres, keys=None, want_labels=True, want_a
     out = {}
     if want_labels:
         out["labels"] = labels
+        if flat is not None:
+            out["labels_flat"] = flat
     if want_argmax:
         out["argmax"] = argmax
     if want_rw_up:

@@ -1,10 +1,22 @@
 """Shared plumbing of the label-generation steps: one worker process per GPU over strided shards
-(reference step/make_cam.py:67-74), fail-fast, no communication between workers."""
+(reference step/make_cam.py:67-74), fail-fast, no communication between workers.
+
+Unlike the reference, which forks a fresh set of workers inside every `run(args)` (`multiprocessing.spawn`,
+step/make_cam.py:74, step/make_sem_seg_labels.py:70, step/make_ins_seg_labels.py:171), the workers here are spawned
+ONCE per process and device list and serve every later step (`WorkerPool`): a HIP context, MIOpen's solver search and
+the CAMs `make_cam` left in device memory (`CamStore`) survive from one step of `run_sample.py` to the next.  The step
+API is unchanged: `step.X.run(args)` works on its own and returns when every shard is done."""
+import atexit
 import importlib
+import os
+import sys
+import traceback
 from concurrent.futures import ThreadPoolExecutor
 
+import numpy as np
 import torch
 from torch import multiprocessing
+from torch.utils.data import Subset
 
 _NET_ALIASES = {"net.resnet50_cam": "irn_amd.net.resnet50_cam", "net.resnet50_irn": "irn_amd.net.resnet50_irn"}
 
@@ -14,20 +26,216 @@ def import_network(dotted):
     return importlib.import_module(_NET_ALIASES.get(dotted, dotted))
 
 
-def n_gpus_or_raise():
+def worker_devices(args=None):
+    """Device ordinal of every worker process: one per visible GPU like the reference (`torch.cuda.device_count()`
+    shards, step/make_cam.py:67), unless `args.worker_devices` (run_sample.py --worker_devices, or the environment
+    variable IRN_WORKER_DEVICES) lists them, e.g. "0,0" = two workers sharing GPU 0 (tests of the N > 1 path on a
+    one-GPU box), "0,2,4,6" = every other GPU."""
+    spec = getattr(args, "worker_devices", None) if args is not None else None
+    if spec is None or spec == "" or spec == []:
+        spec = os.environ.get("IRN_WORKER_DEVICES")
+    if spec:
+        devs = [int(v) for v in (spec.split(",") if isinstance(spec, str) else spec)]
+        n = torch.cuda.device_count()
+        if n < 1 or any(d < 0 or d >= n for d in devs):
+            raise RuntimeError("worker_devices %s: %d GPU(s) visible" % (devs, n))
+        return devs
     n = torch.cuda.device_count()
     if n < 1:
         # the reference silently does nothing with zero GPUs (spawn(nprocs=0)); fail loudly instead
         raise RuntimeError("irn_amd steps need at least one GPU (torch.cuda.device_count() == 0)")
-    return n
+    return list(range(n))
+
+
+def n_gpus_or_raise(args=None):
+    """Number of shards = number of worker processes (reference: torch.cuda.device_count())."""
+    return len(worker_devices(args))
+
+
+def worker_device(process_id, args=None):
+    """The device worker `process_id` computes on.  The reference uses the process id itself
+    (`torch.cuda.device(process_id)`, step/make_cam.py:24); a pool worker was told its device at start-up."""
+    if _WORKER_DEVICE[0] is not None:
+        return _WORKER_DEVICE[0]
+    devs = worker_devices(args)
+    return devs[process_id] if process_id < len(devs) else process_id
+
+
+_WORKER_DEVICE = [None]      # set inside a pool worker process
+_POOL = [None]               # the parent's pool
+
+
+def _pool_worker(rank, device, n_workers, cmd_q, res_q):
+    """Main loop of a pool worker: bound to one device for its whole life, runs the `_work` functions the parent names."""
+    try:
+        # every worker searches MIOpen's solvers on its own: eight processes appending to one user database collide
+        base = os.environ.get("MIOPEN_USER_DB_PATH") or os.path.join(os.path.expanduser("~"), ".config", "miopen")
+        os.environ["MIOPEN_USER_DB_PATH"] = os.path.join(base, "irn_worker_%d" % rank)
+        os.makedirs(os.environ["MIOPEN_USER_DB_PATH"], exist_ok=True)
+        os.environ.setdefault("MIOPEN_FIND_MODE", "2")
+        _WORKER_DEVICE[0] = int(device)
+        if int(device) >= 0:                  # negative ordinals: workers without a GPU (the pool's own CPU tests)
+            torch.cuda.set_device(int(device))
+        res_q.put((rank, "ready", None))
+        while True:
+            cmd = cmd_q.get()
+            if cmd is None:
+                break
+            mod, fn, model, shards, args = cmd
+            try:
+                work = getattr(importlib.import_module(mod), fn)
+                work(rank, model, shards, args)
+                if int(device) >= 0:
+                    torch.cuda.synchronize()
+                res_q.put((rank, "ok", {"cam_store_hits": CAM_STORE.hits, "cam_store_misses": CAM_STORE.misses,
+                                        "walk_fallback_runs": WALK_STATS["fallback_runs"]}))
+            except BaseException:
+                res_q.put((rank, "error", traceback.format_exc()))
+    except BaseException:
+        res_q.put((rank, "error", traceback.format_exc()))
+
+
+class WorkerPool:
+    """One process per entry of `devices`, spawned once and alive until `close()` (or interpreter exit)."""
+
+    def __init__(self, devices):
+        self.devices = list(devices)
+        ctx = multiprocessing.get_context("spawn")       # a forked child cannot use the parent's HIP runtime
+        self._res_q = ctx.Queue()
+        self._cmd_qs = [ctx.Queue() for _ in self.devices]
+        self._procs = []
+        self.stats = [{} for _ in self.devices]
+        for rank, dev in enumerate(self.devices):
+            p = ctx.Process(target=_pool_worker, args=(rank, dev, len(self.devices), self._cmd_qs[rank], self._res_q), daemon=True)
+            p.start()
+            self._procs.append(p)
+        self._collect("ready")
+
+    def _collect(self, want):
+        done = 0
+        while done < len(self._procs):
+            try:
+                rank, status, payload = self._res_q.get(timeout=5.0)
+            except Exception:            # queue.Empty: is everybody still alive?
+                dead = [i for i, p in enumerate(self._procs) if not p.is_alive()]
+                if dead:
+                    self.close(force=True)
+                    raise RuntimeError("step worker(s) %s died without reporting (exit codes %s)" %
+                                       (dead, [self._procs[i].exitcode for i in dead]))
+                continue
+            if status == "error":        # fail fast like spawn(join=True): the other workers are stopped, the error surfaces
+                self.close(force=True)
+                raise RuntimeError("step worker %d failed:\n%s" % (rank, payload))
+            if status == want or (want == "ok" and status == "ok"):
+                if payload:
+                    self.stats[rank] = payload
+                done += 1
+
+    def run(self, work, model, shards, args):
+        for q in self._cmd_qs:
+            q.put((work.__module__, work.__name__, model, shards, args))
+        self._collect("ok")
+
+    def alive(self):
+        return bool(self._procs) and all(p.is_alive() for p in self._procs)
+
+    def close(self, force=False):
+        for q, p in zip(self._cmd_qs, self._procs):
+            if p.is_alive() and not force:
+                try:
+                    q.put(None)
+                except Exception:
+                    pass
+        for p in self._procs:
+            p.join(timeout=0.1 if force else 20.0)
+            if p.is_alive():
+                p.terminate()
+                p.join(timeout=5.0)
+        self._procs = []
+
+
+def get_pool(devices):
+    pool = _POOL[0]
+    if pool is not None and (pool.devices != list(devices) or not pool.alive()):
+        pool.close()
+        pool = _POOL[0] = None
+    if pool is None:
+        pool = _POOL[0] = WorkerPool(devices)
+    return pool
+
+
+def shutdown_workers():
+    """Stop the worker processes (they otherwise live until the interpreter exits)."""
+    if _POOL[0] is not None:
+        _POOL[0].close()
+        _POOL[0] = None
+
+
+atexit.register(shutdown_workers)
+
+
+def pool_stats():
+    """Per-worker counters after the last step ({} entries before any): CAM hand-offs served from device memory, and
+    batches the persistent walk handed to the streaming sweeps."""
+    return [] if _POOL[0] is None else [dict(s) for s in _POOL[0].stats]
 
 
 def spawn_workers(work, model, shards, args):
+    """Run `work(process_id, model, shards, args)` for every shard, one worker process per shard, and wait for all of
+    them (reference: `multiprocessing.spawn(_work, nprocs=n_gpus, args=(model, dataset, args), join=True)`).  One shard
+    on the process's current device runs in-process; otherwise the shards go to the persistent pool.  `work` functions
+    that never touch a GPU (CPU tests) may pass args without device information."""
     n = len(shards)
-    if n == 1:
-        work(0, model, shards, args)        # same code path, no fork needed for a single GPU
-    else:
-        multiprocessing.spawn(work, nprocs=n, args=(model, shards, args), join=True)
+    try:
+        devs = worker_devices(args if not isinstance(args, dict) else None)[:n]
+    except RuntimeError:
+        devs = None                      # no GPU: the callers that need one have raised already (n_gpus_or_raise)
+    if devs is None or len(devs) != n:
+        if n == 1:
+            work(0, model, shards, args)
+        else:
+            multiprocessing.spawn(work, nprocs=n, args=(model, shards, args), join=True)
+        return
+    if n == 1 and not getattr(args, "always_use_workers", False):
+        work(0, model, shards, args)        # same code path, no second process needed for a single GPU
+        return
+    get_pool(devs).run(work, model, shards, args)
+
+
+def split_by_owner(dataset, n_splits, names, owners, slack=0.25):
+    """Shards for a label step that follows `make_cam` in the same run: image `names[i]` goes to the worker that holds
+    its CAM in device memory (`owners[name]`, what `make_cam.run` recorded) as long as that worker's shard stays within
+    (1 + slack) of the even share; everything else goes to the least loaded worker, like the reference's strided split
+    (misc/torchutils.py:66-68) would balance it.  Which worker processes an image never changes its outputs."""
+    n_items = len(names)
+    cap = int(np.ceil(n_items / float(n_splits) * (1.0 + slack)))
+    shards = [[] for _ in range(n_splits)]
+    later = []
+    for i, name in enumerate(names):
+        o = owners.get(name)
+        if o is not None and 0 <= o < n_splits and len(shards[o]) < cap:
+            shards[o].append(i)
+        else:
+            later.append(i)
+    for i in later:
+        k = min(range(n_splits), key=lambda j: len(shards[j]))
+        shards[k].append(i)
+    return [Subset(dataset, np.asarray(sorted(s), dtype=np.int64)) for s in shards]
+
+
+CAM_OWNERS = {}       # abspath(cam_out_dir) -> {image name: worker that made (and still holds) its CAM}
+WALK_STATS = {"fallback_runs": 0}
+
+
+def label_step_shards(dataset, n_workers, args):
+    """Shards of make_sem_seg_labels / make_ins_seg_labels: CAM-owner aware when make_cam ran before in this process
+    with the same worker layout, else the reference's strided split."""
+    from ..misc import torchutils
+    owners = CAM_OWNERS.get(os.path.abspath(args.cam_out_dir)) if keep_cams(args) else None
+    if owners and owners.get("__n_workers__") == n_workers and n_workers > 1:
+        from ..voc12.dataloader import decode_int_filename
+        return split_by_owner(dataset, n_workers, [decode_int_filename(v) for v in dataset.img_name_list], owners)
+    return torchutils.split_dataset(dataset, n_workers)
 
 
 def device_preprocess(args):
@@ -51,39 +259,60 @@ class CamStore:
     """CAMs of this process kept on the device between steps: `make_cam` puts every image's
     {keys, cam} here besides writing the reference's `.npy` (step/make_cam.py:55-56), and the label steps take them
     from here instead of reading the 1-6 MB pickle back and uploading it again (step/make_sem_seg_labels.py:34-39).
-    A miss — another process or an earlier run made the CAM — falls back to the file, so results never depend on the
-    store.  One store per process and device; a 128x128 CAM is 64 KB per class, so all of VOC12 train_aug (10 582
-    images) is ~1 GB of the 288 GB: capped at `max_bytes` anyway."""
+    Entries are keyed by (cam_out_dir, image name) and a later `put` replaces an earlier one, so a second make_cam run
+    (other weights, scales or output directory) can never be answered with the first run's CAMs.  A miss — another
+    process or an earlier run made the CAM — falls back to the file, so results never depend on the store.  One store
+    per process (= per worker and device); a 128x128 CAM is 64 KB per class, so all of VOC12 train_aug (10 582 images)
+    is ~1 GB of the 288 GB: capped at `max_bytes` anyway (oldest entries leave first)."""
 
     def __init__(self, max_bytes=16 << 30):
-        self._items = {}
+        self._items = {}             # insertion-ordered
         self._bytes = 0
         self._max = max_bytes
         self.hits = self.misses = 0
 
-    def put(self, name, keys_cpu, keys_dev, cam):
+    @staticmethod
+    def _key(name, cam_out_dir):
+        return (os.path.abspath(cam_out_dir) if cam_out_dir else "", name)
+
+    def put(self, name, keys_cpu, keys_dev, cam, cam_out_dir=None):
+        key = self._key(name, cam_out_dir)
         nbytes = cam.numel() * cam.element_size()
-        if name in self._items or self._bytes + nbytes > self._max:
+        old = self._items.pop(key, None)
+        if old is not None:
+            self._bytes -= old[2].numel() * old[2].element_size()
+        while self._items and self._bytes + nbytes > self._max:
+            dropped = self._items.pop(next(iter(self._items)))
+            self._bytes -= dropped[2].numel() * dropped[2].element_size()
+        if nbytes > self._max:
             return
-        self._items[name] = (keys_cpu, keys_dev, cam)
+        self._items[key] = (keys_cpu, keys_dev, cam)
         self._bytes += nbytes
 
     def get(self, name, cam_out_dir, device):
         """-> (keys int64 on the CPU, keys on the device, cam fp32 [K,h,w] on the device)."""
-        hit = self._items.get(name)
+        hit = self._items.get(self._key(name, cam_out_dir))
         if hit is not None and hit[2].device == device:
             self.hits += 1
             return hit
         self.misses += 1
-        import os
-        import numpy as np
         d = np.load(os.path.join(cam_out_dir, name + ".npy"), allow_pickle=True).item()
         keys = torch.as_tensor(d["keys"])
         return keys, keys.to(device), torch.as_tensor(d["cam"]).to(device)
 
+    def drop_dir(self, cam_out_dir):
+        """Forget the entries of one output directory (make_cam.run starts with this: its files are about to change)."""
+        d = os.path.abspath(cam_out_dir)
+        for key in [k for k in self._items if k[0] == d]:
+            old = self._items.pop(key)
+            self._bytes -= old[2].numel() * old[2].element_size()
+
     def clear(self):
         self._items.clear()
         self._bytes = 0
+
+    def __len__(self):
+        return len(self._items)
 
 
 CAM_STORE = CamStore()

@@ -78,7 +78,7 @@ def _flush_group(model, group, scales, args, writer, store):
         keys_cpu = torch.nonzero(g["label"])[:, 0]
         keys, cam, high_res = merge_scales([o[i] for o in outs], g["size"], g["label"])
         if store is not None:
-            store.put(g["name"], keys_cpu, keys, cam)
+            store.put(g["name"], keys_cpu, keys, cam, cam_out_dir=args.cam_out_dir)
         n_cam, n_hi = cam.numel() * 4, high_res.numel() * 4
         staging = _common.PINNED.take(n_cam + n_hi)
         cam_view = staging[:n_cam].view(torch.float32).view(cam.shape)
@@ -101,9 +101,11 @@ def _work(process_id, model, dataset, args):
     # are stacked per scale — VOC is mostly 500x375 / 375x500 — and every size group is flushed at the end
     batch = int(getattr(args, "cam_batch", 0) or 8)
     store = _common.CAM_STORE if _common.keep_cams(args) else None
+    _common.CAM_STORE.drop_dir(args.cam_out_dir)        # this directory's files are about to be rewritten
     groups = {}
+    pending_bytes, max_pending = 0, int(getattr(args, "cam_pending_bytes", 0) or (4 << 30))
     try:
-        with torch.no_grad(), torch.cuda.device(process_id):
+        with torch.no_grad(), torch.cuda.device(_common.worker_device(process_id, args)):
             model.cuda()
             for it, pack in enumerate(loader):
                 img_name = pack["name"][0]
@@ -116,10 +118,18 @@ def _work(process_id, model, dataset, args):
                     warnings.warn("%s: no positive class in the image-level label, skipped" % img_name)
                     continue
                 group = groups.setdefault(size, [])
-                group.append({"name": img_name, "size": size, "label": label,
-                              "imgs": _common.device_images(pack, scales)})
+                imgs = _common.device_images(pack, scales)
+                group.append({"name": img_name, "size": size, "label": label, "imgs": imgs})
+                pending_bytes += sum(t.numel() * t.element_size() for t in imgs)
                 if len(group) == batch:
+                    pending_bytes -= sum(t.numel() * t.element_size() for g in group for t in g["imgs"])
                     _flush_group(model, group, scales, args, writer, store)
+                elif pending_bytes > max_pending:
+                    # VOC has hundreds of distinct image sizes: incomplete size groups may not pile up on the device
+                    # without bound (34 MB per waiting 500x375 image) — the fullest one goes early
+                    big = max(groups.values(), key=len)
+                    pending_bytes -= sum(t.numel() * t.element_size() for g in big for t in g["imgs"])
+                    _flush_group(model, big, scales, args, writer, store)
                 _common.progress(process_id, n_gpus, it, len(databin))
             for group in groups.values():
                 _flush_group(model, group, scales, args, writer, store)
@@ -131,13 +141,19 @@ def run(args):
     model = getattr(_common.import_network(args.cam_network), "CAM")()
     model.load_state_dict(torch.load(args.cam_weights_name + ".pth", map_location="cpu"), strict=True)
     model.eval()
-    n_gpus = _common.n_gpus_or_raise()
+    n_gpus = _common.n_gpus_or_raise(args)
     scales = tuple(float(s) for s in args.cam_scales)
     dataset = voc12_dataloader.VOC12ClassificationDatasetMSF(args.train_list, voc12_root=args.voc12_root,
                                                              scales=scales, raw=_common.device_preprocess(args))
+    names = [voc12_dataloader.decode_int_filename(v) for v in dataset.img_name_list]
     dataset = torchutils.split_dataset(dataset, n_gpus)
     os.makedirs(args.cam_out_dir, exist_ok=True)
     print("[ ", end="")
     _common.spawn_workers(_work, model, dataset, args)
     print("]")
+    # which worker made (and, with keep_cams_on_device, still holds) every image's CAM: strided like the shards
+    # (misc/torchutils.py:66-68) — the label steps of this run send an image to the worker that has its CAM
+    owners = {name: i % n_gpus for i, name in enumerate(names)}
+    owners["__n_workers__"] = n_gpus
+    _common.CAM_OWNERS[os.path.abspath(args.cam_out_dir)] = owners
     torch.cuda.empty_cache()

@@ -17,7 +17,7 @@ import numpy as np
 import torch
 
 from .. import ops
-from ..misc import indexing, torchutils
+from ..misc import indexing
 from ..voc12 import dataloader as voc12_dataloader
 from . import _common, make_sem_seg_labels
 
@@ -91,9 +91,10 @@ def _work(process_id, model, dataset, args):
     batch = int(getattr(args, "walk_batch", 0) or 32)   # images per walk launch (results per image unchanged)
     writer = _common.AsyncWriter()
     try:
-        with torch.no_grad(), torch.cuda.device(process_id):
+        dev_id = _common.worker_device(process_id, args)
+        with torch.no_grad(), torch.cuda.device(dev_id):
             model.cuda()
-            dev = torch.device("cuda", process_id)
+            dev = torch.device("cuda", dev_id)
             walker = indexing.RandomWalk(_common.walk_radius(args, RADIUS))
             pend, in_flight = [], [None]
             for it, pack in enumerate(loader):
@@ -109,6 +110,7 @@ def _work(process_id, model, dataset, args):
                 _common.progress(process_id, n_gpus, it, len(databin))
             _flush(model, walker, pend, args, writer, in_flight)      # the last batch ...
             _flush(model, walker, pend, args, writer, in_flight)      # ... and its collection
+            _common.WALK_STATS["fallback_runs"] += walker.fallback_runs
             walker.close()
     finally:
         writer.close()
@@ -118,10 +120,10 @@ def run(args):
     model = getattr(_common.import_network(args.irn_network), "EdgeDisplacement")()
     model.load_state_dict(torch.load(args.irn_weights_name, map_location="cpu"), strict=False)
     model.eval()
-    n_gpus = _common.n_gpus_or_raise()
+    n_gpus = _common.n_gpus_or_raise(args)
     dataset = voc12_dataloader.VOC12ClassificationDatasetMSF(args.infer_list, voc12_root=args.voc12_root,
                                                              scales=(1.0,), raw=_common.device_preprocess(args))
-    dataset = torchutils.split_dataset(dataset, n_gpus)
+    dataset = _common.label_step_shards(dataset, n_gpus, args)     # strided (misc/torchutils.py:66-68) or CAM-owner aware
     os.makedirs(args.ins_seg_out_dir, exist_ok=True)
     print("[ ", end="")
     _common.spawn_workers(_work, model, dataset, args)

@@ -13,12 +13,11 @@ reference's hard-coded value) selects the walk radius.
 """
 import os
 
-import numpy as np
 import torch
 from PIL import Image
 
 from .. import ops
-from ..misc import indexing, torchutils
+from ..misc import indexing
 from ..voc12 import dataloader as voc12_dataloader
 from . import _common
 
@@ -38,27 +37,53 @@ def edges_for(model, pend, irn_batch):
             p["edge"], p["dp"] = edge, dp
 
 
+def _start_copy(batch):
+    """The batch's label maps (views of one device buffer) leave for the host as ONE copy into page-locked memory on the
+    copy stream, behind everything enqueued so far; `_collect` waits for it when the next batch is already queued."""
+    flat = batch["flat"]
+    staging = _common.PINNED.take(flat.numel())
+    ready = torch.cuda.Event()
+    ready.record()
+    cs = ops._copy_stream(flat.device)
+    cs.wait_event(ready)
+    with torch.cuda.stream(cs):
+        staging[:flat.numel()].copy_(flat, non_blocking=True)
+        done = torch.cuda.Event()
+        done.record(cs)
+    batch["staging"], batch["done"] = staging, done
+
+
 def _enqueue(model, walker, pend, args):
-    """IRNet forward, walk and label epilogue of the images in `pend`, enqueued only; returns what `_collect` needs."""
+    """IRNet forward, walk, label epilogue and the transfer of the label maps of the images in `pend`, enqueued only;
+    returns what `_collect` needs."""
     edges_for(model, pend, int(getattr(args, "irn_batch", 0) or 8))
     rws = walker([p["edge"] for p in pend], [p["cam"] for p in pend],
                  beta=float(args.beta), exp_times=int(args.exp_times))
     sizes, keys = [p["size"] for p in pend], [p["keys_dev"] for p in pend]
-    out = ops.label_epilogue(rws, sizes, float(args.sem_seg_bg_thres), keys=keys)
-    batch = {"names": [p["name"] for p in pend], "rws": rws, "sizes": sizes, "keys": keys, "labels": out["labels"]}
+    out = ops.label_epilogue(rws, sizes, float(args.sem_seg_bg_thres), keys=keys, packed=True)
+    batch = {"names": [p["name"] for p in pend], "rws": rws, "sizes": sizes, "keys": keys, "flat": out["labels_flat"]}
+    _start_copy(batch)
     pend.clear()
     return batch
 
 
 def _collect(walker, batch, args, writer):
-    """Wait for the batch enqueued last, bring its label maps to the host and hand them to the writer threads."""
+    """Wait for the batch enqueued last and hand its label maps (already on their way to the host) to the writer threads."""
     if batch is None:
         return
     if walker.sync():                       # the persistent walk gave up and the batch was re-run on the streaming sweeps
-        batch["labels"] = ops.label_epilogue(batch["rws"], batch["sizes"], float(args.sem_seg_bg_thres),
-                                             keys=batch["keys"])["labels"]
-    for name, lab in zip(batch["names"], batch["labels"]):
-        writer.submit(_save_png, os.path.join(args.sem_seg_out_dir, name + ".png"), lab.cpu().numpy())
+        _common.PINNED.give(batch["staging"])
+        batch["flat"] = ops.label_epilogue(batch["rws"], batch["sizes"], float(args.sem_seg_bg_thres), keys=batch["keys"],
+                                           packed=True)["labels_flat"]
+        _start_copy(batch)
+    batch["done"].synchronize()
+    host = batch["staging"].numpy()
+    off = 0
+    for name, (hh, ww) in zip(batch["names"], batch["sizes"]):
+        lab = host[off:off + hh * ww].reshape(hh, ww).copy()      # 256 KB: the staging buffer goes back at once
+        off += hh * ww
+        writer.submit(_save_png, os.path.join(args.sem_seg_out_dir, name + ".png"), lab)
+    _common.PINNED.give(batch["staging"])
 
 
 def _flush(model, walker, pend, args, writer):
@@ -74,9 +99,10 @@ def _work(process_id, model, dataset, args):
     batch = int(getattr(args, "walk_batch", 0) or 64)   # 64 VOC-size images = 3-4 rounds of the resident walk
     writer = _common.AsyncWriter()
     try:
-        with torch.no_grad(), torch.cuda.device(process_id):
+        dev_id = _common.worker_device(process_id, args)
+        with torch.no_grad(), torch.cuda.device(dev_id):
             model.cuda()
-            dev = torch.device("cuda", process_id)
+            dev = torch.device("cuda", dev_id)
             walker = indexing.RandomWalk(_common.walk_radius(args, RADIUS))
             # a batch is enqueued and left running while the loop gathers the next one (decoded images from the loader
             # threads, their uploads, the CAMs); it is collected just before the next batch is enqueued
@@ -96,6 +122,7 @@ def _work(process_id, model, dataset, args):
                 _common.progress(process_id, n_gpus, it, len(databin))
             _collect(walker, running, args, writer)
             _flush(model, walker, pend, args, writer)
+            _common.WALK_STATS["fallback_runs"] += walker.fallback_runs
             walker.close()
     finally:
         writer.close()
@@ -105,10 +132,10 @@ def run(args):
     model = getattr(_common.import_network(args.irn_network), "EdgeDisplacement")()
     model.load_state_dict(torch.load(args.irn_weights_name, map_location="cpu"), strict=False)
     model.eval()
-    n_gpus = _common.n_gpus_or_raise()
+    n_gpus = _common.n_gpus_or_raise(args)
     dataset = voc12_dataloader.VOC12ClassificationDatasetMSF(args.infer_list, voc12_root=args.voc12_root,
                                                              scales=(1.0,), raw=_common.device_preprocess(args))
-    dataset = torchutils.split_dataset(dataset, n_gpus)
+    dataset = _common.label_step_shards(dataset, n_gpus, args)     # strided (misc/torchutils.py:66-68) or CAM-owner aware
     os.makedirs(args.sem_seg_out_dir, exist_ok=True)
     print("[", end="")
     _common.spawn_workers(_work, model, dataset, args)

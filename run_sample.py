@@ -41,6 +41,17 @@ def build_parser():
     p.add_argument("--radius", default=5, type=int,
                    help="random-walk radius of the label steps (not a flag of the reference, which hard-codes 5 at "
                         "step/make_sem_seg_labels.py:41 and step/make_ins_seg_labels.py:135; 10 = BASELINE configs[2])")
+    # training / CRF / evaluation hyper-parameters of the reference (run_sample.py:25-40): accepted so that an existing
+    # command line keeps parsing; the steps that read them are not part of this build
+    for name, default, typ in (("cam_crop_size", 512, int), ("cam_batch_size", 16, int), ("cam_num_epoches", 5, int),
+                               ("cam_learning_rate", 0.1, float), ("cam_weight_decay", 1e-4, float),
+                               ("cam_eval_thres", 0.15, float), ("conf_fg_thres", 0.30, float), ("conf_bg_thres", 0.05, float),
+                               ("irn_crop_size", 512, int), ("irn_batch_size", 32, int), ("irn_num_epoches", 3, int),
+                               ("irn_learning_rate", 0.1, float), ("irn_weight_decay", 1e-4, float)):
+        p.add_argument("--" + name, default=default, type=typ, help="accepted and ignored (training / CRF side of the reference)")
+    p.add_argument("--worker_devices", default="", type=str,
+                   help="device ordinal of every worker process, e.g. 0,1,2,3 (default: one per visible GPU like the reference; "
+                        "0,0 = two workers sharing GPU 0)")
     p.add_argument("--cam_batch", default=0, type=int, help="images of one size per CAM trunk pass (0 = 8)")
     p.add_argument("--irn_batch", default=0, type=int, help="images per IRNet trunk pass (0 = 8)")
     p.add_argument("--keep_cams_on_device", default=True, type=_flag,
@@ -87,6 +98,8 @@ def main(argv=None):
         from irn_amd.step import make_sem_seg_labels
         timer = pyutils.Timer("step.make_sem_seg_labels:")  # noqa: F841
         make_sem_seg_labels.run(args)
+    from irn_amd.step import _common
+    _common.shutdown_workers()           # the per-GPU workers served every pass above
 
 
 if __name__ == "__main__":

@@ -163,10 +163,13 @@ def test_walk_128_labels_vs_reference_epilogue(golden):
                 beta=10, exp_times=8)
     walker.sync()
     lab = ops.label_epilogue(rw, [(512, 512)], 0.25, keys=[torch.from_numpy(keys).to(_dev())])["labels"][0].cpu().numpy()
-    _, want, _ = O.sem_seg_epilogue(wk[n + "_rw"], (512, 512), keys, 0.25)
-    assert lab.shape == want.shape
-    # the two walks differ by fp32 rounding (<= 1e-4): a label may flip only where the top two scores tie at that level
-    assert (lab != want).mean() <= 2e-4, (lab != want).mean()
+    up, want, _ = O.sem_seg_epilogue(wk[n + "_rw"], (512, 512), keys, 0.25)
+    # the two walks differ by fp32 rounding (<= 1e-4): a label may flip only where the two best scores tie at that level,
+    # and only to the other one of the pair — counted and checked pixel by pixel, no fractional allowance
+    from _parity import label_mismatches
+    n_diff, gap = label_mismatches(lab, want, up, 0.25, lut=np.concatenate([[0], keys + 1]), what="walk128 r10 labels")
+    print("labels vs the reference's walk + epilogue at 512x512: %d of %d pixels differ (largest top-2 gap %.2e)" % (n_diff, lab.size, gap))
+    assert n_diff <= 16
     walker.close()
 
 

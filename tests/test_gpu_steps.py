@@ -9,6 +9,8 @@ import pytest
 import torch
 from PIL import Image
 
+from _parity import label_mismatches
+
 pytestmark = pytest.mark.gpu
 
 
@@ -115,8 +117,9 @@ def test_steps_end_to_end(tmp_path):
         # VALUES: the oracle's walk + epilogue (step/make_sem_seg_labels.py:36-49) on the same edge map and the CAM file
         d = np.load(os.path.join(args.cam_out_dir, n + ".npy"), allow_pickle=True).item()
         rw = build_oracle.walk(olib, d["cam"].numpy(), edges[n], 5, 10, 256)
-        _, want, _ = O.sem_seg_epilogue(rw, (H, W), d["keys"].numpy(), 0.25)
-        assert (png != want).mean() <= 2e-4, (n, (png != want).mean())
+        up, want, _ = O.sem_seg_epilogue(rw, (H, W), d["keys"].numpy(), 0.25)
+        n_diff, gap = label_mismatches(png, want, up, 0.25, lut=np.concatenate([[0], d["keys"].numpy() + 1]), what=n)
+        print("%s: %d of %d label pixels differ from the oracle (ties, largest top-2 gap %.2e)" % (n, n_diff, png.size, gap))
 
     # the same step reading the CAM files (no device hand-off) and with the walk radius of BASELINE configs[2]
     file_args = argparse.Namespace(**{**vars(args), "sem_seg_out_dir": str(tmp_path / "sem_files")})
@@ -136,9 +139,10 @@ def test_steps_end_to_end(tmp_path):
     W, H = Image.open(root / "JPEGImages" / (n + ".jpg")).size
     d = np.load(os.path.join(args.cam_out_dir, n + ".npy"), allow_pickle=True).item()
     rw = build_oracle.walk(olib, d["cam"].numpy(), cap10.edges[n], 10, 10, 256)
-    _, want, _ = O.sem_seg_epilogue(rw, (H, W), d["keys"].numpy(), 0.25)
+    up, want, _ = O.sem_seg_epilogue(rw, (H, W), d["keys"].numpy(), 0.25)
     png = np.asarray(Image.open(os.path.join(r10_args.sem_seg_out_dir, n + ".png")))
-    assert (png != want).mean() <= 2e-4
+    n_diff, gap = label_mismatches(png, want, up, 0.25, lut=np.concatenate([[0], d["keys"].numpy() + 1]), what=n + " radius 10")
+    print("%s radius 10: %d of %d label pixels differ from the oracle (largest top-2 gap %.2e)" % (n, n_diff, png.size, gap))
 
     with _CaptureEdges(make_sem_seg_labels) as capi:
         make_ins_seg_labels.run(args)
@@ -155,15 +159,92 @@ def test_steps_end_to_end(tmp_path):
         # VALUES: the oracle's instance pipeline (step/make_ins_seg_labels.py:131-150) on the same edge / dp / CAM
         cd = np.load(os.path.join(args.cam_out_dir, n + ".npy"), allow_pickle=True).item()
         walk = lambda x, e, radius, beta, exp_times: build_oracle.walk(olib, x, e, radius, beta, 2 ** exp_times)
-        _, _, _, _, want = O.instance_labels(cd["cam"].numpy(), cd["keys"].numpy(), capi.edges[n], capi.dps[n], (H, W), walk=walk)
+        _, inst, rw_i, _, want = O.instance_labels(cd["cam"].numpy(), cd["keys"].numpy(), capi.edges[n], capi.dps[n], (H, W), walk=walk)
         # the class-id map the detections paint (masks are disjoint): identical up to argmax ties between the fp32 walk and
-        # the fp64 oracle; when no tie moved a fragment, detections agree one by one
+        # the fp64 oracle — every differing pixel must be such a tie between channels (class x instance) of the oracle's
+        # score stack; when no tie moved a fragment, detections agree one by one
         paint = lambda det: (np.asarray(det["mask"]).astype(np.int64) * (np.asarray(det["class"], np.int64) + 1)[:, None, None]).sum(0)
-        assert (paint(want) != paint(d)).mean() <= 2e-4, n
+        up_i, _, _ = O.sem_seg_epilogue(rw_i, (H, W), np.zeros(rw_i.shape[0], np.int64), 0.25)
+        chan_class = np.concatenate([[0], np.repeat(cd["keys"].numpy(), inst.shape[0]) + 1])
+        n_diff, gap = label_mismatches(paint(d), paint(want), up_i, 0.25, lut=chan_class, what=n + " instance classes")
+        print("%s: %d of %d instance-class pixels differ from the oracle (largest top-2 gap %.2e)" % (n, n_diff, H * W, gap))
         if len(want["score"]) == len(d["score"]):
             assert np.array_equal(np.asarray(want["class"]), d["class"]), n
-            assert (np.asarray(want["mask"]).astype(bool) != d["mask"]).mean() <= 2e-4, n
+            mask_diff = int((np.asarray(want["mask"]).astype(bool) != d["mask"]).sum())
+            assert mask_diff <= 2 * max(n_diff, 8), (n, mask_diff, n_diff)      # a tied pixel flips in at most two masks
             assert np.abs(np.asarray(want["score"], np.float32) - d["score"]).max() <= 1e-3, n
+
+
+def test_steps_two_worker_processes_on_one_device(tmp_path):
+    """The N > 1 path of the steps on a one-GPU box: `worker_devices="0,0"` = two persistent worker processes sharing
+    GPU 0 (reference: one process per GPU, step/make_cam.py:71-74).  Exercises spawn, model pickling, HIP + MIOpen
+    start-up in the children, the CAM hand-off in EACH worker's device memory across steps (CAM-owner aware shards), two
+    resident (cooperative, all-CU) walks contending for one GPU — whichever loses its bounded wait is re-run on the
+    streaming sweeps — and compares every output file with the single-process run."""
+    from irn_amd.net import weights
+    from irn_amd.step import _common, make_cam, make_ins_seg_labels, make_sem_seg_labels
+    root, names, labels = _make_voc(tmp_path, n=6)
+    torch.save(weights.random_cam_state(1), tmp_path / "res50_cam.pth")
+    torch.save(weights.random_irn_state(2), tmp_path / "res50_irn.pth")
+
+    def make_args(tag, **kw):
+        a = argparse.Namespace(
+            num_workers=2, voc12_root=str(root), train_list=str(tmp_path / "lists" / "train.txt"),
+            infer_list=str(tmp_path / "lists" / "train.txt"), cam_network="net.resnet50_cam",
+            cam_weights_name=str(tmp_path / "res50_cam"), cam_scales=(1.0, 0.5),
+            irn_network="net.resnet50_irn", irn_weights_name=str(tmp_path / "res50_irn.pth"),
+            beta=10, exp_times=8, sem_seg_bg_thres=0.25, ins_seg_bg_thres=0.25, radius=10,
+            cam_out_dir=str(tmp_path / (tag + "_cam")), sem_seg_out_dir=str(tmp_path / (tag + "_sem")),
+            ins_seg_out_dir=str(tmp_path / (tag + "_ins")), walk_batch=2, cam_batch=1, irn_batch=1, **kw)
+        for d in (a.cam_out_dir, a.sem_seg_out_dir, a.ins_seg_out_dir):
+            os.makedirs(d)
+        return a
+
+    two = make_args("two", worker_devices="0,0")
+    try:
+        make_cam.run(two)
+        make_sem_seg_labels.run(two)
+        stats_sem = _common.pool_stats()
+        make_ins_seg_labels.run(two)
+        stats = _common.pool_stats()
+        pool = _common._POOL[0]
+        assert pool is not None and pool.alive() and len(pool.devices) == 2
+    finally:
+        _common.shutdown_workers()
+    assert len(stats) == 2
+    hits = sum(s["cam_store_hits"] for s in stats)
+    misses = sum(s["cam_store_misses"] for s in stats)
+    print("two workers on device 0: CAM hand-offs in device memory %d, from files %d; walk batches re-run on the streaming "
+          "sweeps: %s" % (hits, misses, [s["walk_fallback_runs"] for s in stats]))
+    assert sum(s["cam_store_hits"] for s in stats_sem) == len(names)      # every CAM was found in its worker's memory
+    assert hits == 2 * len(names) and misses == 0
+
+    one = make_args("one")
+    _common.CAM_STORE.clear()
+    make_cam.run(one)
+    make_sem_seg_labels.run(one)
+    make_ins_seg_labels.run(one)
+    assert _common.CAM_STORE.hits == 2 * len(names)
+    n_px = n_diff = 0
+    for n in names:
+        a = np.load(os.path.join(two.cam_out_dir, n + ".npy"), allow_pickle=True).item()
+        b = np.load(os.path.join(one.cam_out_dir, n + ".npy"), allow_pickle=True).item()
+        assert torch.equal(a["keys"], b["keys"])
+        assert (a["cam"] - b["cam"]).abs().max().item() <= 1e-5 and np.abs(a["high_res"] - b["high_res"]).max() <= 1e-5, n
+        pa = np.asarray(Image.open(os.path.join(two.sem_seg_out_dir, n + ".png")))
+        pb = np.asarray(Image.open(os.path.join(one.sem_seg_out_dir, n + ".png")))
+        assert pa.shape == pb.shape
+        n_px += pa.size
+        n_diff += int((pa != pb).sum())
+        fa, fb = os.path.join(two.ins_seg_out_dir, n + ".npy"), os.path.join(one.ins_seg_out_dir, n + ".npy")
+        assert os.path.exists(fa) == os.path.exists(fb), n
+        if os.path.exists(fa):
+            da, db = np.load(fa, allow_pickle=True).item(), np.load(fb, allow_pickle=True).item()
+            if len(da["score"]) == len(db["score"]):
+                assert np.array_equal(da["class"], db["class"]), n
+                assert int((da["mask"] != db["mask"]).sum()) <= 16, n
+    print("two-worker vs one-process label maps: %d of %d pixels differ" % (n_diff, n_px))
+    assert n_diff <= 8          # same kernels on the same inputs; MIOpen may pick another solver in another process
 
 
 def test_cam_merge_kernel_vs_oracle_and_reference_golden(golden):

@@ -273,22 +273,59 @@ def test_thread_loader_collates_like_dataloader(tmp_path):
 
 def test_cam_store_hit_and_file_fallback(tmp_path):
     """step/_common.CamStore: a CAM put by make_cam is handed to the label steps from memory; anything else comes from the
-    `.npy` the reference's make_cam writes (step/make_cam.py:55-56) — same values either way."""
+    `.npy` the reference's make_cam writes (step/make_cam.py:55-56) — same values either way.  Entries belong to ONE
+    output directory and a later put replaces an earlier one (a second make_cam run must never be answered with the
+    first run's CAMs)."""
     from irn_amd.step import _common
     store = _common.CamStore(max_bytes=1 << 20)
     dev = torch.device("cpu")
     keys = torch.tensor([3, 7])
     cam = torch.rand(2, 8, 9)
     np.save(tmp_path / "2008_000001.npy", {"keys": keys, "cam": cam, "high_res": np.zeros((2, 32, 36), np.float32)})
-    store.put("2008_000001", keys, keys.clone(), cam.clone())
+    store.put("2008_000001", keys, keys.clone(), cam.clone(), cam_out_dir=str(tmp_path))
     k_cpu, k_dev, c = store.get("2008_000001", str(tmp_path), dev)
     assert store.hits == 1 and store.misses == 0 and torch.equal(k_cpu, keys) and torch.equal(c, cam)
-    store.clear()
+    # a second run with other weights: same name, new values -> the new ones are served
+    cam2 = torch.rand(2, 8, 9)
+    store.put("2008_000001", keys, keys.clone(), cam2.clone(), cam_out_dir=str(tmp_path))
+    assert torch.equal(store.get("2008_000001", str(tmp_path), dev)[2], cam2) and len(store) == 1
+    assert store._bytes == cam2.numel() * 4
+    # the same name under another output directory is another entry: served from ITS file
+    other = tmp_path / "other"
+    other.mkdir()
+    cam3 = torch.rand(2, 8, 9)
+    np.save(other / "2008_000001.npy", {"keys": keys, "cam": cam3, "high_res": np.zeros((2, 32, 36), np.float32)})
+    assert torch.equal(store.get("2008_000001", str(other), dev)[2], cam3) and store.misses == 1
+    store.drop_dir(str(tmp_path))
+    assert len(store) == 0 and store._bytes == 0
     k_cpu, k_dev, c = store.get("2008_000001", str(tmp_path), dev)
-    assert store.hits == 1 and store.misses == 1 and torch.equal(k_cpu, keys) and torch.equal(k_dev, keys) and torch.equal(c, cam)
+    assert store.misses == 2 and torch.equal(k_cpu, keys) and torch.equal(k_dev, keys) and torch.equal(c, cam)
     big = torch.zeros(1, 1024, 1024)                       # 4 MB > the 1 MB cap: not kept, never an error
-    store.put("big", keys[:1], keys[:1], big)
-    assert "big" not in store._items
+    store.put("big", keys[:1], keys[:1], big, cam_out_dir=str(tmp_path))
+    assert len(store) == 0
+    for i in range(40):                                    # 40 x 36 KB > 1 MB: the oldest entries leave
+        store.put("n%d" % i, keys, keys, torch.zeros(1, 96, 96), cam_out_dir=str(tmp_path))
+    assert store._bytes <= 1 << 20 and ("%s" % tmp_path, "n39") in store._items and ("%s" % tmp_path, "n0") not in store._items
+
+
+def test_split_by_owner_hits_and_balance():
+    """Label-step shards that follow make_cam's CAM placement: every image whose CAM a worker holds goes to that worker
+    while the shards stay within 25 % of the even share; unknown images fill the lightest shards; every image exactly
+    once (the reference's strided split, misc/torchutils.py:66-68, is the fallback)."""
+    from irn_amd.step import _common
+    rng = np.random.default_rng(0)
+    names = ["img%04d" % i for i in range(1000)]
+    made = {"img%04d" % i: int(i % 8) for i in rng.permutation(1200)[:900]}      # CAMs of 900 images, strided over 8 workers
+    shards = _common.split_by_owner(list(range(1000)), 8, names, made)
+    seen = sorted(int(i) for s in shards for i in s.indices)
+    assert seen == list(range(1000))
+    assert max(len(s) for s in shards) <= int(np.ceil(1000 / 8 * 1.25))
+    hits = sum(1 for k, s in enumerate(shards) for i in s.indices if made.get(names[int(i)]) == k)
+    known = sum(1 for n in names if n in made)
+    assert hits >= 0.97 * known, (hits, known)
+    # a pathological placement (everything on worker 0) is capped, not followed
+    shards = _common.split_by_owner(list(range(100)), 4, names[:100], {n: 0 for n in names[:100]})
+    assert [len(s) for s in shards][0] == 32 and sorted(int(i) for s in shards for i in s.indices) == list(range(100))
 
 
 def test_frozen_batch_norm_folding_and_composed_path():

@@ -29,6 +29,53 @@ def test_spawn_workers_strided_shards(tmp_path):
         assert d["rank"] == i % 3
 
 
+_CALLS = []          # lives in a pool worker: grows from one step to the next if (and only if) the process persists
+
+
+def _stateful_work(process_id, model, shards, args):
+    _CALLS.append(args["tag"])
+    for item in shards[process_id]:
+        np.save(os.path.join(args["out"], "%s_%05d.npy" % (args["tag"], item)),
+                {"rank": process_id, "pid": os.getpid(), "calls": list(_CALLS), "model": None if model is None else float(model.sum())})
+
+
+def _failing_work(process_id, model, shards, args):
+    if process_id == 1:
+        raise ValueError("shard %d cannot be processed" % process_id)
+
+
+def test_worker_pool_persists_across_steps_and_fails_fast(tmp_path):
+    """The per-GPU workers are spawned once and serve every step (the reference re-spawns per step,
+    step/make_cam.py:74): same PIDs and surviving module state in the second step, the model travels by pickling, a
+    failing shard surfaces in the parent like spawn(join=True) would raise, and a new pool works afterwards."""
+    from irn_amd.step import _common
+    pool = _common.WorkerPool([-1, -1, -1])                      # three workers without a GPU
+    try:
+        shards = torchutils.split_dataset(list(range(10)), 3)
+        pool.run(_stateful_work, torch.ones(4), shards, {"out": str(tmp_path), "tag": "a"})
+        pool.run(_stateful_work, None, shards, {"out": str(tmp_path), "tag": "b"})
+        for i in range(10):
+            a = np.load(tmp_path / ("a_%05d.npy" % i), allow_pickle=True).item()
+            b = np.load(tmp_path / ("b_%05d.npy" % i), allow_pickle=True).item()
+            assert a["rank"] == b["rank"] == i % 3 and a["pid"] == b["pid"] != os.getpid()
+            assert a["calls"] == ["a"] and b["calls"] == ["a", "b"] and a["model"] == 4.0 and b["model"] is None
+        assert len({np.load(tmp_path / ("a_%05d.npy" % i), allow_pickle=True).item()["pid"] for i in range(3)}) == 3
+        try:
+            pool.run(_failing_work, None, shards, {})
+            raise AssertionError("a failing shard must raise in the parent")
+        except RuntimeError as e:
+            assert "shard 1 cannot be processed" in str(e) and "ValueError" in str(e)
+        assert not pool.alive()
+    finally:
+        pool.close(force=True)
+    pool = _common.WorkerPool([-1])
+    try:
+        pool.run(_stateful_work, None, torchutils.split_dataset([7], 1), {"out": str(tmp_path), "tag": "c"})
+        assert os.path.exists(tmp_path / "c_00007.npy")
+    finally:
+        pool.close()
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
