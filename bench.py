@@ -14,19 +14,25 @@ data path (weak scaling: every rank processes its own `--batch` images per step)
 
 One JSON line on rank 0:
   metric/value     images/s, whole job
-  roofline         of the dominant kernel, `resident_kernel<10>` (one launch = all sweeps of the batch).  Its binding
-                   ceiling is the fp32 vector FMA rate (F = 2*(2|S|+1) flops per pixel, channel and
-                   sweep): `bound` = "fp32_vector", achieved/peak in TFLOP/s from HIP events around the launch on its
-                   own stream.  The kernel reads the weights from HBM once per image and keeps them in registers, so the
-                   streaming-kernel formula of §8(d) (weights re-read every sweep) does not describe it; that figure
-                   is kept as `hbm_equivalent`, next to `traffic` (PMC-measured HBM bytes per launch).
+  roofline         of the dominant kernel, `resident_kernel<10>` (one launch = the whole walk of the batch).  Its binding
+                   ceiling is the fp32 vector FMA rate: `bound` = "fp32_vector", achieved/peak in TFLOP/s from HIP events
+                   around the launch on its own stream.  `achieved` / `frac` count the flops the kernel EXECUTES:
+                   2*(2|S|+1) per pixel, channel and operator application, times the applications of the schedule (round 3:
+                   x.T^256 as an 84-term Chebyshev series, `schedule`).  `power_equivalent` is SURVEY.md §8(d)'s
+                   F = 2*(2|S|+1)*N*C'*2^exp_times over the same time: what a kernel that applies the operator 2^exp_times
+                   times would have to sustain for this throughput.  The kernel reads the weights from HBM once per image and
+                   keeps them in registers, so the streaming-kernel byte formula of §8(d) does not describe it; that figure
+                   is kept as `hbm_equivalent`, next to `traffic` (PMC-measured HBM bytes per launch, from profiles/).
   cpu_baseline     kind "port": oracle/walk_oracle.c (fp64 stencil port, one image per host thread) on a bounded
-                   sample of the same workload; `reference_algorithm`: the reference's own dense algorithm
-                   (oracle/dense_ref.py = misc/indexing.py:91-165 op for op on torch CPU) timed at 64^2 and 96^2 grids
-                   and extrapolated ~N^3 to the 128^2 grid (labelled extrapolated).
+                   sample of the same workload; `label_parity`: the GPU's label maps of the first images of the batch
+                   against the port's walk + the oracle's epilogue (pixels differing, every one checked to be a top-2 tie
+                   below 1e-4); `reference_algorithm`: the reference's own dense algorithm (oracle/dense_ref.py =
+                   misc/indexing.py:91-165 op for op on torch CPU) timed IN FULL at the workload's 128x128 grid (and at
+                   64x64 as the scaling check), per-phase seconds, same thread count as the port.
   legs             short runs of the other configurations at N = 1: cam (configs[1]), e2e (cam + IRNet + walk +
-                   labels), steps (the run_sample.py step API on a synthetic VOC directory), walk_r5, ins (configs[3]),
-                   coco (configs[4]) — images/s each.
+                   labels), steps (the run_sample.py step API through `run(args)` on a synthetic VOC directory), walk_r5,
+                   walk_plain (the default workload with the plain 2^exp_times iteration, option accel = 0), ins
+                   (configs[3]), coco (configs[4]) — images/s each.
 Other main workloads: --workload walk_r5 | ins | coco | cam | e2e | steps.
 """
 import argparse
@@ -52,7 +58,7 @@ def parse(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="walk", choices=["walk", "walk_r5", "ins", "ins_r10", "coco", "cam", "e2e", "steps"])
+    ap.add_argument("--workload", default="walk", choices=["walk", "walk_r5", "walk_plain", "ins", "ins_r10", "coco", "cam", "e2e", "steps"])
     ap.add_argument("--batch", type=int, default=0, help="images per GPU per step (0 = workload default)")
     ap.add_argument("--unique", type=int, default=96, help="distinct synthetic images per GPU")
     ap.add_argument("--variant", type=int, default=2, help="0 generic sweep, 1 blocked streaming sweep, 2 weights-stationary persistent walk")
@@ -63,9 +69,16 @@ def parse(argv=None):
     ap.add_argument("--probe", type=int, default=0, help="diagnostic: time the weight-streaming skeleton instead")
     ap.add_argument("--walk-option", action="append", default=[], metavar="NAME=VALUE",
                     help="extra irn_walk_set_option settings (tuning experiments), e.g. poll_delay=8")
+    ap.add_argument("--accel", type=int, default=1,
+                    help="1: x.T^n as a truncated Chebyshev series (the product's default); 0: the plain n-fold iteration")
+    ap.add_argument("--ref-grids", default="64,128",
+                    help="grid sizes at which the reference's dense algorithm is timed on the host (the last one is reported; 128 = "
+                         "the workload's own grid, ~3 minutes of CPU; '64' alone = quick runs, extrapolated)")
+    ap.add_argument("--backend", default="auto", help="process group of the barrier / max-over-ranks: nccl (= RCCL), gloo, or auto = "
+                                                      "nccl with a fall-back to gloo (the data path has no collective)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-legs", action="store_true", help="skip the short secondary runs (cam, e2e, steps, walk_r5, ins, coco)")
-    ap.add_argument("--legs", default="walk_r5,ins,ins_r10,coco,cam,e2e,steps")
+    ap.add_argument("--legs", default="walk_r5,walk_plain,ins,ins_r10,coco,cam,e2e,steps")
     ap.add_argument("--legs-budget-s", type=float, default=240.0,
                     help="stop starting new legs once the legs have used this much wall time (the rest are recorded as skipped)")
     ap.add_argument("--loader-workers", type=int, default=4, help="DataLoader workers of the `steps` workload")
@@ -79,6 +92,7 @@ def parse(argv=None):
 WORKLOADS = {
     #            h    w    radius beta exp  out      default batch
     "walk":    (128, 128, 10, 10.0, 8, (512, 512), 192),     # BASELINE configs[2]
+    "walk_plain": (128, 128, 10, 10.0, 8, (512, 512), 192),  # the same with the plain 2^exp_times iteration (accel = 0)
     "walk_r5": (128, 128, 5, 10.0, 8, (512, 512), 256),     # configs[0]'s operator setting at full batch
     "ins":     (128, 128, 5, 10.0, 8, (512, 512), 64),      # configs[3]: instance labels, radius 5 = the reference's call site (step/make_ins_seg_labels.py:135)
     "ins_r10": (128, 128, 10, 10.0, 8, (512, 512), 64),     # the same at SURVEY.md 8(d)'s row 4 radius
@@ -116,9 +130,21 @@ def flops_per_sweep(shapes, n_dirs):
 # CPU baselines (rank 0, N = 1 only)
 # ------------------------------------------------------------------------------------------------
 
-def cpu_baseline(workload, n_images, seed0):
+def _label_ties(got, want, up, bg, lut):
+    """(#pixels differing, largest top-2 gap of the oracle's score stack among them, #of them that are NOT ties below 1e-4)."""
+    diff = got != want
+    n = int(diff.sum())
+    if n == 0:
+        return 0, 0.0, 0
+    stack = np.concatenate([np.full((1,) + up.shape[1:], bg, np.float32), up], 0)[:, diff]
+    srt = np.sort(stack, axis=0)
+    gap = srt[-1] - srt[-2]
+    return n, float(gap.max()), int((gap >= 1e-4).sum())
+
+
+def cpu_baseline(a, workload, n_images, seed0, gpu_labels=None):
     from irn_amd import synth
-    from oracle import build_oracle
+    from oracle import build_oracle, irn_oracle
     h, w, radius, beta, exp_times, out_hw, _ = WORKLOADS[workload]
     try:
         lib = build_oracle.load(native=True, out_dir="/tmp/irn_oracle_native")
@@ -131,46 +157,70 @@ def cpu_baseline(workload, n_images, seed0):
     edges = [synth.edge_field(h, w, seed0 + i) for i in range(n_images)]
     build_oracle.walk_batch(lib, cams[:threads], edges[:threads], radius, beta, 2)            # warm (threads, pages)
     t0 = time.perf_counter()
-    build_oracle.walk_batch(lib, cams, edges, radius, beta, 2 ** exp_times)
+    rws = build_oracle.walk_batch(lib, cams, edges, radius, beta, 2 ** exp_times)
     dt = time.perf_counter() - t0
     res = {"value": n_images / dt, "unit": "images/s", "cores": threads, "kind": "port",
            "sample": "%d images of the same workload (walk only: oracle/walk_oracle.c irn_oracle_walk_batch, fp64 stencil port of "
                      "misc/indexing.py:141-165, one image per OpenMP thread, rows vectorised; %.1f s)" % (n_images, dt)}
+    if gpu_labels:
+        # by-product: the label maps the GPU wrote in the timed run against the port's walk + the oracle's epilogue
+        # (step/make_sem_seg_labels.py:43-49) for the first images of the batch — measured, not a tolerance
+        tot = {"images": 0, "pixels": 0, "pixels_differing": 0, "max_top2_gap": 0.0, "not_a_tie": 0}
+        for i, (lab, keys) in enumerate(gpu_labels[:n_images]):
+            up, want, _ = irn_oracle.sem_seg_epilogue(rws[i], out_hw, keys, 0.25)
+            n_diff, gap, bad = _label_ties(lab, want, up, 0.25, np.concatenate([[0], keys + 1]))
+            tot["images"] += 1
+            tot["pixels"] += int(lab.size)
+            tot["pixels_differing"] += n_diff
+            tot["max_top2_gap"] = max(tot["max_top2_gap"], gap)
+            tot["not_a_tie"] += bad
+        tot["criterion"] = "a pixel may differ only where the two best entries of the oracle's normalised score stack are closer than 1e-4"
+        res["label_parity"] = tot
     try:
-        res["reference_algorithm"] = reference_algorithm_baseline(radius, beta, exp_times, h * w, seed0)
+        res["reference_algorithm"] = reference_algorithm_baseline(radius, beta, exp_times, h, seed0, threads,
+                                                                  [int(g) for g in a.ref_grids.split(",") if g])
     except Exception as e:                                   # never lose the bench line to the baseline
         res["reference_algorithm"] = {"error": repr(e)[:200]}
     return res
 
 
-def reference_algorithm_baseline(radius, beta, exp_times, n_target, seed0, budget_s=25.0):
+def reference_algorithm_baseline(radius, beta, exp_times, grid_target, seed0, threads, grids):
     """The reference's own DENSE algorithm (misc/indexing.py:91-165: dense (hw x hw) matrix, `exp_times` sgemm
-    squarings) restated op for op on torch CPU tensors (oracle/dense_ref.py), timed on this box's host cores at grids
-    small enough to finish in seconds, extrapolated ~N^3 (the squarings are 2*N^3 flops each; N = h*w) to the
-    workload's grid.  The reference tree itself does not travel to the GPU box."""
+    squarings) restated op for op on torch CPU tensors (oracle/dense_ref.py; the reference tree itself does not travel
+    to the GPU box), timed on this box's host cores with the thread count the port used.  The workload's own grid
+    (128x128: 70 TFLOP of sgemm, ~1 GB matrices) is run IN FULL; the smaller grid before it is the scaling check
+    (set-up ~N^2, squarings ~N^3).  Only when the target grid is not in `grids` is the figure extrapolated, and says so."""
     from irn_amd import synth
     from oracle import dense_ref
-    threads = os.cpu_count() or 1
     torch.set_num_threads(threads)
     measured = {}
     last = None
-    for g in (64, 96):
-        if last is not None and (last[1] * (g * g / float(last[0])) ** 2 + last[2] * (g * g / float(last[0])) ** 3) * 1.2 > budget_s:
-            break
+    for g in grids:
         cam = synth.cam_blobs(2, g, g, seed0)
         edge = synth.edge_field(g, g, seed0)
         tm = {}
+        t0 = time.perf_counter()
         dense_ref.propagate_to_edge(cam, edge[None], radius, beta, exp_times, timings=tm)
-        measured["%dx%d" % (g, g)] = {"setup_s": tm["setup"], "transition_s": tm["transition"]}
-        last = (g * g, tm["setup"], tm["transition"])
-    # setup builds index tables and a dense (hw x hw) matrix: ~N^2; the squarings are 2*N^3 flops each
-    scale = float(n_target) / last[0]
-    est = last[1] * scale ** 2 + last[2] * scale ** 3
-    return {"value": 1.0 / est, "unit": "images/s", "cores": threads,
-            "kind": "reference algorithm (dense, torch CPU restatement oracle/dense_ref.py of misc/indexing.py:91-165)",
-            "extrapolated": True, "seconds_measured": measured, "seconds_extrapolated_per_image": est,
-            "sample": "1 image per grid size, radius %d, exp_times=%d; setup ~N^2 and squarings ~N^3 extrapolated from the largest "
-                      "measured grid to N=%d" % (radius, exp_times, n_target)}
+        tm["total"] = time.perf_counter() - t0
+        measured["%dx%d" % (g, g)] = {k: round(float(v), 3) for k, v in tm.items()}
+        last = (g, tm)
+    g, tm = last
+    full = g == grid_target
+    scale = float(grid_target * grid_target) / (g * g)
+    est = tm["total"] if full else tm["setup"] * scale ** 2 + tm["transition"] * scale ** 3
+    out = {"value": 1.0 / est, "unit": "images/s", "cores": threads,
+           "kind": "reference algorithm (dense, torch CPU restatement oracle/dense_ref.py of misc/indexing.py:91-165)",
+           "extrapolated": not full, "seconds_per_image": est, "seconds_measured": measured,
+           "sample": "1 image (2 classes) per grid size, radius %d, exp_times=%d, %d torch threads; %s" %
+                     (radius, exp_times, threads, "the %dx%d grid of the workload measured in full" % (g, g) if full else
+                      "set-up ~N^2 and squarings ~N^3 extrapolated from %dx%d to %dx%d" % (g, g, grid_target, grid_target))}
+    if full and len(grids) > 1:
+        g0 = grids[-2]
+        t0m = measured["%dx%d" % (g0, g0)]
+        sc = float(g * g) / (g0 * g0)
+        out["scaling_check"] = {"from": "%dx%d" % (g0, g0), "predicted_seconds": t0m["setup"] * sc ** 2 + t0m["transition"] * sc ** 3,
+                                "measured_seconds": tm["total"]}
+    return out
 
 
 # ------------------------------------------------------------------------------------------------
@@ -221,6 +271,7 @@ def run_walk(a, workload, rank, world, device, dist, parallel, steps, warmup, ba
     walker.set_option("streams", a.streams)
     walker.set_option("merged", a.merged)
     walker.set_option("probe", a.probe)
+    walker.set_option("accel", 0 if workload == "walk_plain" else a.accel)
     for kv in a.walk_option:
         name, value = kv.split("=")
         walker.set_option(name, int(value))
@@ -236,22 +287,24 @@ def run_walk(a, workload, rank, world, device, dist, parallel, steps, warmup, ba
     sweep_ms, sweep_launches = walker.last_sweep_ms()      # HIP events recorded inside the timed region on the launch stream
     walker.check()                                         # a launch that gave up its bounded wait invalidates the run
     checksum = int(sum(int(l.sum().item()) for l in labels[:4]))
+    n_sweeps = 2 ** exp_times
+    n_applied = walker.steps(n_sweeps)                     # operator applications the schedule spends on T^n_sweeps
+    head = [(labels[i].cpu().numpy(), keys[i].cpu().numpy()) for i in range(min(8, n_unique))]   # for cpu_baseline.label_parity
     walker.close()
     n_dirs = N_DIRS[radius]
-    n_sweeps = 2 ** exp_times
     avg_sweep_ms = sweep_ms / max(sweep_launches, 1)
-    # one "launch" of the dominant kernel: the streaming variants launch once per sweep; the weights-stationary walk
-    # is ONE launch for all 2^exp_times sweeps of the batch
-    sweeps_per_launch = n_sweeps if a.variant == 2 else 1
+    # one "launch" of the dominant kernel: the streaming variants launch once per operator application; the
+    # weights-stationary walk is ONE launch for the whole walk of the batch
+    sweeps_per_launch = n_applied if a.variant == 2 else 1
     avg_launch_ms = avg_sweep_ms * sweeps_per_launch
     flops_per_launch = flops_per_sweep(shapes, n_dirs) * sweeps_per_launch
     bytes_per_launch = algorithmic_bytes_per_sweep(shapes, n_dirs) * sweeps_per_launch
     return {"value": steps * batch * world / elapsed, "ms_per_step": 1e3 * elapsed / steps, "batch": batch,
             "shapes": shapes, "radius": radius, "beta": beta, "exp_times": exp_times, "out_hw": out_hw, "h": h, "w": w,
-            "avg_launch_ms": avg_launch_ms, "sweeps_per_launch": sweeps_per_launch,
-            "launches_timed": sweep_launches // sweeps_per_launch, "flops_per_launch": flops_per_launch,
+            "avg_launch_ms": avg_launch_ms, "sweeps_per_launch": sweeps_per_launch, "n_applied": n_applied, "n_sweeps": n_sweeps,
+            "launches_timed": sweep_launches // max(sweeps_per_launch, 1), "flops_per_launch": flops_per_launch,
             "bytes_per_launch": bytes_per_launch, "sweep_share_of_step": sweep_ms / (1e3 * elapsed),
-            "label_checksum": checksum}
+            "label_checksum": checksum, "head_labels": head}
 
 
 def run_ins(a, workload, rank, world, device, dist, parallel, steps, warmup, batch=0):
@@ -389,19 +442,9 @@ def run_steps(a, rank, world, device, dist, parallel, steps, warmup, batch=0):
             cam_out_dir=os.path.join(tmp, "cam"), sem_seg_out_dir=os.path.join(tmp, "sem"), radius=10, walk_batch=64)
         os.makedirs(args.cam_out_dir)
         os.makedirs(args.sem_seg_out_dir)
-        # the steps shard over torch.cuda.device_count() GPUs by themselves; inside a torch.distributed job every rank
-        # must stay on its own device, so the rank runs the single-GPU worker path on its device
-        model_c = getattr(_common.import_network(args.cam_network), "CAM")()
-        model_c.load_state_dict(torch.load(args.cam_weights_name + ".pth", map_location="cpu"), strict=True)
-        model_c.eval()
-        model_i = getattr(_common.import_network(args.irn_network), "EdgeDisplacement")()
-        model_i.load_state_dict(torch.load(args.irn_weights_name, map_location="cpu"), strict=False)
-        model_i.eval()
-        from irn_amd.misc import torchutils
-        from irn_amd.voc12 import dataloader as vd
-        ds_c = torchutils.split_dataset(vd.VOC12ClassificationDatasetMSF(args.train_list, voc12_root=root, scales=args.cam_scales, raw=True), 1)
-        ds_i = torchutils.split_dataset(vd.VOC12ClassificationDatasetMSF(args.infer_list, voc12_root=root, scales=(1.0,), raw=True), 1)
-        dev_index = device.index or 0
+        # the steps shard over the visible GPUs by themselves (one worker process per GPU); inside a torch.distributed job
+        # every rank must stay on its own device, so each rank runs the steps with a one-entry device list (in-process)
+        args.worker_devices = str(device.index or 0)
 
         class _Quiet:
             def write(self, s):
@@ -416,39 +459,33 @@ def run_steps(a, rank, world, device, dist, parallel, steps, warmup, batch=0):
             real = sys.stdout
             sys.stdout = _Quiet()                      # progress ticks of the steps would break the one-JSON-line contract
             try:
-                _common.CAM_STORE.clear()
+                # the step API itself, as run_sample.py calls it (checkpoints loaded, shards made, workers run, files written)
                 t0 = time.perf_counter()
-                _on_device(dev_index, make_cam._work, model_c, ds_c, args)
+                make_cam.run(args)
                 t1 = time.perf_counter()
-                _on_device(dev_index, make_sem_seg_labels._work, model_i, ds_i, args)
+                make_sem_seg_labels.run(args)
                 pass_s["make_cam"], pass_s["make_sem_seg_labels"] = t1 - t0, time.perf_counter() - t1
             finally:
                 sys.stdout = real
 
         t_setup = time.perf_counter() - t_setup
+        hits0, misses0 = _common.CAM_STORE.hits, _common.CAM_STORE.misses
         elapsed, _ = timed_loop(step, steps, warmup, dist, parallel, device)
         n_png = len([f for f in os.listdir(args.sem_seg_out_dir) if f.endswith(".png")])
         if n_png != batch:
             raise RuntimeError("steps leg: %d label maps written for %d images" % (n_png, batch))
         return {"value": steps * batch * world / elapsed, "ms_per_step": 1e3 * elapsed / steps, "batch": batch,
-                "cam_store_hits": _common.CAM_STORE.hits, "loader_workers": args.num_workers,
+                "cam_store_hits": _common.CAM_STORE.hits - hits0, "cam_store_misses": _common.CAM_STORE.misses - misses0,
+                "loader_workers": args.num_workers, "through": "make_cam.run(args) + make_sem_seg_labels.run(args)",
                 "last_pass_seconds": dict(pass_s), "setup_seconds": t_setup}
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
 
 
-def _on_device(index, work, model, dataset, args):
-    """Run a step worker (written for process_id == device ordinal) on device `index` of a multi-rank job."""
-    class _Shift(list):
-        def __getitem__(self, i):
-            return list.__getitem__(self, 0)
-    work(index, model, _Shift(dataset), args)
-
-
 # ------------------------------------------------------------------------------------------------
 
 def describe(workload, r):
-    if workload in ("walk", "walk_r5", "coco"):
+    if workload in ("walk", "walk_r5", "walk_plain", "coco"):
         return ("%s: VOC12-shaped %dx%d images (%dx%d stride-4 grids), affinity random walk radius=%d beta=%g 2^%d sweeps "
                 "+ x4 upsample/argmax label epilogue; K~VOC label histogram%s; inputs resident in HBM" %
                 (workload, r["out_hw"][0], r["out_hw"][1], r["h"], r["w"], r["radius"], r["beta"], r["exp_times"],
@@ -467,7 +504,7 @@ def describe(workload, r):
 
 
 def run_workload(a, workload, rank, world, device, dist, parallel, steps, warmup, batch=0):
-    if workload in ("walk", "walk_r5", "coco"):
+    if workload in ("walk", "walk_r5", "walk_plain", "coco"):
         return run_walk(a, workload, rank, world, device, dist, parallel, steps, warmup, batch)
     if workload in ("ins", "ins_r10"):
         return run_ins(a, workload, rank, world, device, dist, parallel, steps, warmup, batch)
@@ -477,34 +514,40 @@ def run_workload(a, workload, rank, world, device, dist, parallel, steps, warmup
 
 
 LEG_RUNS = {   # short runs for the `legs` object of the default line: (steps, warmup, batch)
-    "cam": (2, 1, 8), "e2e": (2, 1, 8), "steps": (1, 1, 128), "walk_r5": (3, 1, 256), "ins": (8, 2, 64), "ins_r10": (6, 2, 64), "coco": (3, 1, 2),
+    "cam": (8, 1, 8), "e2e": (8, 1, 8), "steps": (1, 1, 128), "walk_r5": (3, 1, 256), "walk_plain": (3, 1, 192),
+    "ins": (8, 2, 64), "ins_r10": (6, 2, 64), "coco": (3, 1, 2),
 }
 
 
 def roofline_object(a, workload, r):
-    if workload not in ("walk", "walk_r5", "coco"):
+    if workload not in ("walk", "walk_r5", "walk_plain", "coco"):
         return None
-    tflops = r["flops_per_launch"] / (r["avg_launch_ms"] * 1e-3) / 1e12
-    gbs = r["bytes_per_launch"] / (r["avg_launch_ms"] * 1e-3) / 1e9
-    traffic = None
+    sec = r["avg_launch_ms"] * 1e-3
+    tflops = r["flops_per_launch"] / sec / 1e12
+    gbs = r["bytes_per_launch"] / sec / 1e9
+    # SURVEY.md 8(d)'s F and B are quoted for 2^exp_times applications of the operator; the schedule applies it n_applied times
+    power_scale = float(r["n_sweeps"]) / max(r["n_applied"], 1) if a.variant == 2 else 1.0
+    traffic = traffic_src = None
     tpath = os.path.join(ROOT, "profiles", "traffic_%s.json" % workload)
     if os.path.exists(tpath):
         try:
             tj = json.load(open(tpath))
-            if tj.get("batch") == r["batch"] and tj.get("variant", 1) == a.variant:
+            if tj.get("batch") == r["batch"] and tj.get("variant", 1) == a.variant and tj.get("n_applied", r["n_applied"]) == r["n_applied"]:
                 traffic = tj.get("hbm_bytes_per_launch")
+                traffic_src = "profiles/traffic_%s.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, %s); not re-measured in this run" % (
+                    workload, tj.get("session", "see profiles/README.md"))
         except Exception:
             traffic = None
     resident = a.variant == 2
-    kernel = ("resident_kernel<%d> (weights-stationary persistent walk: one launch = all sweeps of the batch)" % r["radius"]) if resident else \
-             ("sweep_blocked_kernel<%d,CH> (one sweep over the batch = 1 launch per channel-chunk width)" % r["radius"])
+    kernel = ("resident_kernel<%d> (weights-stationary persistent walk: one launch = the whole walk of the batch)" % r["radius"]) if resident else \
+             ("sweep_blocked_kernel<%d,CH> (one operator application over the batch = 1 launch per channel-chunk width)" % r["radius"])
     hbm = {"achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS,
            "algorithmic_bytes_per_launch": r["bytes_per_launch"],
-           "note": "SURVEY.md 8(d) bytes of a STREAMING kernel (weights re-read every sweep: 4*N*(|S|+1+2C') per image and sweep) / launch time"}
+           "note": "SURVEY.md 8(d) bytes of a STREAMING kernel (weights re-read every application: 4*N*(|S|+1+2C') per image and application) / launch time"}
     fma = {"achieved": tflops, "peak": FP32_VECTOR_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tflops / FP32_VECTOR_PEAK_TFLOPS,
            "flops_per_launch": r["flops_per_launch"]}
     if resident:
-        # the weights live in registers for all sweeps: HBM is not what bounds this kernel (traffic << algorithmic
+        # the weights live in registers for the whole walk: HBM is not what bounds this kernel (traffic << algorithmic
         # streaming bytes); its ceiling is the fp32 vector FMA rate — and, for 1-2 channel images, the tile-to-tile
         # exchange latency
         top = dict(fma)
@@ -512,13 +555,21 @@ def roofline_object(a, workload, r):
         top["hbm_equivalent"] = hbm
         hbm["note"] += ("; this kernel reads the weights ONCE per image, so the figure may exceed the HBM peak — it measures speed-up "
                         "over any weight-streaming kernel, not HBM utilisation (see `traffic`)")
+        top["power_equivalent"] = {
+            "achieved": tflops * power_scale, "unit": "TFLOP/s", "frac_of_peak": tflops * power_scale / FP32_VECTOR_PEAK_TFLOPS,
+            "flops": r["flops_per_launch"] * power_scale,
+            "note": "SURVEY.md 8(d) F = 2*(2|S|+1)*N*C'*2^exp_times (the reference operator applied 2^exp_times times) over the same "
+                    "launch time; the kernel executes n_applied/n_sweeps of that (`schedule`), which is what `achieved`/`frac` count"}
     else:
         top = dict(hbm)
         top["bound"] = "hbm"
         top["fp32_vector"] = fma
-    top.update({"traffic": traffic, "kernel": kernel, "avg_launch_ms": r["avg_launch_ms"],
+    top.update({"traffic": traffic, "traffic_source": traffic_src, "kernel": kernel, "avg_launch_ms": r["avg_launch_ms"],
                 "sweeps_per_launch": r["sweeps_per_launch"], "launches_timed": r["launches_timed"],
-                "sweep_share_of_step": r["sweep_share_of_step"]})
+                "sweep_share_of_step": r["sweep_share_of_step"],
+                "schedule": {"n_sweeps": r["n_sweeps"], "operator_applications": r["n_applied"],
+                             "kind": "plain powers" if r["n_applied"] == r["n_sweeps"] else
+                                     "truncated Chebyshev series of lambda^n (dropped coefficients sum to < 1e-7), three-term recurrence"}})
     return top
 
 
@@ -532,11 +583,14 @@ def main(argv=None):
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     from irn_amd import parallel
-    dist = parallel.init_process_group(backend="nccl", device=device)      # nccl == RCCL on ROCm; None at N=1
+    # nccl == RCCL on ROCm.  The data path has no collective — the group only serves the contract's barrier and
+    # max-over-ranks — so a failing RCCL start-up must not cost the line: `auto` falls back to gloo and says so
+    dist, backend_used = parallel.init_process_group_with_fallback(a.backend, device)
 
     r = run_workload(a, a.workload, rank, world, device, dist, parallel, a.steps, a.warmup, a.batch)
     if rank == 0:
         stage = {"walk": "random-walk label generation stage", "walk_r5": "random-walk label generation stage, radius 5",
+                 "walk_plain": "random-walk label generation stage, plain 2^exp_times iteration",
                  "coco": "random-walk label generation stage, COCO shape", "ins": "instance label generation stage",
                  "ins_r10": "instance label generation stage, radius 10",
                  "cam": "multi-scale CAM inference stage", "e2e": "CAM + IRNet + walk + labels, end to end",
@@ -547,18 +601,22 @@ def main(argv=None):
             "ms_per_step": r["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": describe(a.workload, r), "images_per_gpu_per_step": r["batch"],
-                       "sharding": "images strided over ranks, no collective"},
+                       "sharding": "images strided over ranks, no collective",
+                       "process_group": {"backend": backend_used, "ranks": world,
+                                         "used_for": "barrier + max-over-ranks of the timed region only"}},
             "roofline": roofline_object(a, a.workload, r),
         }
         if "shapes" in r:
             res["config"].update({"variant": a.variant, "mean_channels": float(np.mean([s[2] for s in r["shapes"]]))})
             res["label_checksum"] = r["label_checksum"]
-        for k in ("detections_per_image", "fallback_runs", "cam_store_hits", "loader_workers", "last_pass_seconds"):
+        for k in ("detections_per_image", "fallback_runs", "cam_store_hits", "cam_store_misses", "loader_workers", "last_pass_seconds", "through"):
             if k in r:
                 res["config"][k] = r[k]
         res["cpu_baseline"] = None
-        if world == 1 and not a.no_cpu_baseline and a.workload in ("walk", "walk_r5", "coco"):
-            res["cpu_baseline"] = cpu_baseline(a.workload, a.cpu_images, 1000)
+        if world == 1 and not a.no_cpu_baseline and a.workload in ("walk", "walk_r5", "walk_plain", "coco"):
+            res["cpu_baseline"] = cpu_baseline(a, a.workload, a.cpu_images, 1000, gpu_labels=r.get("head_labels"))
+            if "label_parity" in res["cpu_baseline"]:
+                res["label_parity"] = res["cpu_baseline"]["label_parity"]
         if world == 1 and not a.no_legs and a.workload == "walk":
             legs = {}
             legs_t0 = time.perf_counter()
@@ -575,7 +633,7 @@ def main(argv=None):
                     if "shapes" in lr:
                         ro = roofline_object(a, name, lr)
                         legs[name]["fp32_vector_frac"] = ro["frac"] if ro.get("bound") == "fp32_vector" else ro["fp32_vector"]["frac"]
-                    for k in ("detections_per_image", "cam_store_hits", "loader_workers", "last_pass_seconds", "setup_seconds"):
+                    for k in ("detections_per_image", "cam_store_hits", "cam_store_misses", "loader_workers", "last_pass_seconds", "setup_seconds", "through", "n_applied"):
                         if k in lr:
                             legs[name][k] = lr[k]
                 except Exception as e:                      # a leg must never cost the headline line

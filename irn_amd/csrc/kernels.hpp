@@ -21,10 +21,11 @@ struct DeviceTable {
 int get_device_table(int radius, int order, const DeviceTable **out);
 
 // Copy `bytes` of host data into a library-private device scratch buffer (grown on demand) with
-// stream order.  The returned pointer stays valid until the next scratch_upload on this thread.
+// stream order.  The scratch is a ring of four slots: the returned pointer stays valid until the fourth scratch_upload
+// after this one on this thread (each batched entry point uploads once and enqueues its kernels before it returns).
 int scratch_upload(const void *host, size_t bytes, void **dev_out, hipStream_t stream);
 // Record, on `stream`, that the kernels reading the scratch have been enqueued; the next
-// scratch_upload waits for them before it overwrites the buffers.
+// scratch_upload that reuses this slot waits for them before it overwrites the buffers.
 int scratch_release(hipStream_t stream);
 
 // tile of the affinity kernel: source rows x cols per workgroup (one wave covers two rows)

@@ -19,12 +19,20 @@ int upload(const std::vector<T> &v, T **dev) {
     return IRN_OK;
 }
 
-struct Scratch {
+// Descriptor scratch of the batched entry points: a small ring of slots, each with its own completion event, so that
+// back-to-back calls do not wait for each other's kernels (one slot made every call block the host until the previous
+// call's kernels — e.g. the 300-iteration centroid kernel — had finished)
+struct ScratchSlot {
     void *dev = nullptr;
     void *host = nullptr;    // pinned
     size_t cap = 0;
     hipEvent_t ev = nullptr;
     int device = -1;
+};
+constexpr int kScratchSlots = 4;
+struct Scratch {
+    ScratchSlot slot[kScratchSlots];
+    int next = 0, last = 0;
 };
 thread_local Scratch t_scratch;
 }  // namespace
@@ -94,10 +102,13 @@ int get_device_table(int radius, int order, const DeviceTable **out) {
 }
 
 int scratch_upload(const void *host, size_t bytes, void **dev_out, hipStream_t stream) {
-    Scratch &s = t_scratch;
+    Scratch &ring = t_scratch;
+    ring.last = ring.next;
+    ring.next = (ring.next + 1) % kScratchSlots;
+    ScratchSlot &s = ring.slot[ring.last];
     int dev = 0;
     IRN_HIP_TRY(hipGetDevice(&dev));
-    if (s.ev) IRN_HIP_TRY(hipEventSynchronize(s.ev));   // previous user of the buffers is done with them
+    if (s.ev) IRN_HIP_TRY(hipEventSynchronize(s.ev));   // the slot's previous user (kScratchSlots calls ago) is done with it
     if (bytes > s.cap || dev != s.device) {
         if (s.dev) (void)hipFree(s.dev);
         if (s.host) (void)hipHostFree(s.host);
@@ -117,7 +128,7 @@ int scratch_upload(const void *host, size_t bytes, void **dev_out, hipStream_t s
 
 // Callers record completion of the kernels that read the scratch so the next upload can wait.
 int scratch_release(hipStream_t stream) {
-    Scratch &s = t_scratch;
+    ScratchSlot &s = t_scratch.slot[t_scratch.last];
     if (s.ev) IRN_HIP_TRY(hipEventRecord(s.ev, stream));
     return IRN_OK;
 }

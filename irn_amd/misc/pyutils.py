@@ -59,6 +59,24 @@ class Timer:
         dt, self._lap = now - self._lap, now
         return dt
 
+    # progress estimates of the reference's training loops (misc/pyutils.py:61-76; step/train_cam.py, step/train_irn.py
+    # call them): same names and attributes, on the monotonic clock; wall-clock dates only where one is printed
+    def update_progress(self, progress):
+        """progress in (0, 1]: sets `est_total`, `est_remaining` (seconds) and `est_finish` (epoch seconds)."""
+        done = self.elapsed()
+        self.est_total = done / progress
+        self.est_remaining = self.est_total - done
+        self.est_finish = int(time.time() + self.est_remaining)
+
+    def str_estimated_complete(self):
+        return time.ctime(self.est_finish)
+
+    def get_stage_elapsed(self):
+        return time.perf_counter() - self._lap
+
+    def reset_stage(self):
+        self._lap = time.perf_counter()
+
     def __enter__(self):
         return self
 

@@ -28,7 +28,9 @@ FUSED_EPILOGUE = os.environ.get("IRN_FUSED_EPILOGUE", "1") != "0"
 
 
 def _fused(x):
-    return FUSED_EPILOGUE and x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and not torch.is_grad_enabled()
+    # irn_bn_act walks the tensor in 16-byte pieces: an offset view of another tensor takes the composed ops instead
+    return (FUSED_EPILOGUE and x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and x.data_ptr() % 16 == 0
+            and not torch.is_grad_enabled())
 
 
 def _version(t):
@@ -64,7 +66,7 @@ class FrozenBatchNorm(nn.BatchNorm2d):
         """act(forward(x) (+ r)) with r = residual, or residual_bn.forward(residual) when a second layer is given (the
         projection shortcut's batch norm); overwrites x on the inference path (x must be a tensor nobody else reads: the
         output of the convolution in front of this layer)."""
-        if _fused(x) and (residual is None or (residual.is_contiguous() and residual.dtype == x.dtype)):
+        if _fused(x) and (residual is None or (residual.is_contiguous() and residual.dtype == x.dtype and residual.data_ptr() % 16 == 0)):
             from .. import ops          # the HIP library; raises if it has not been built — there is no other GPU path
             scale, shift = self.folded()
             return ops.bn_act_(x, scale, shift, residual, relu, None if residual_bn is None else residual_bn.folded())

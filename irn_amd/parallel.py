@@ -26,10 +26,44 @@ def init_process_group(backend=None, device=None):
     return dist
 
 
+def init_process_group_with_fallback(backend="auto", device=None):
+    """-> (dist or None, name of the backend in use).  `auto` tries RCCL ("nccl") and, when its start-up or first
+    collective fails (missing IPC support, a bad fabric), joins the same rendezvous over gloo instead: the hot path
+    has no collective, the group only serves a benchmark's barrier and max-over-ranks."""
+    rank, _, world = rank_world()
+    if world == 1:
+        return None, None
+    import torch.distributed as dist
+    want = ("nccl" if torch.cuda.is_available() else "gloo") if backend == "auto" else backend
+    if want == "nccl":
+        try:
+            d = init_process_group("nccl", device)
+            t = torch.zeros(1, device=device)
+            d.all_reduce(t)                       # the first collective is where a broken fabric shows
+            torch.cuda.synchronize()
+            return d, "nccl"
+        except Exception as e:                    # every rank sees the failure of the collective start-up
+            if backend != "auto":
+                raise
+            import sys
+            print("irn_amd.parallel: RCCL start-up failed (%s); using gloo for the barrier" % (repr(e)[:200],), file=sys.stderr)
+            try:
+                if dist.is_initialized():
+                    dist.destroy_process_group()
+            except Exception:
+                pass
+            # a fresh rendezvous on the next port: the store of the failed group may be half torn down
+            os.environ["MASTER_PORT"] = str(int(os.environ.get("MASTER_PORT", "29500")) + 1)
+            want = "gloo"
+    return init_process_group(want, device), want
+
+
 def max_over_ranks(value, dist, device="cpu"):
     """Wall time of the slowest rank (the bench contract: barrier, time, MAX over ranks)."""
     if dist is None:
         return float(value)
+    if dist.get_backend() == "gloo":
+        device = "cpu"
     t = torch.tensor([float(value)], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())

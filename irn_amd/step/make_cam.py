@@ -17,9 +17,8 @@ import warnings
 
 import numpy as np
 import torch
-import torch.nn.functional as F
 
-from ..misc import imutils, torchutils
+from ..misc import torchutils
 from ..voc12 import dataloader as voc12_dataloader
 from . import _common
 
@@ -27,33 +26,9 @@ from . import _common
 def merge_scales(outputs, size, label):
     """outputs: per-scale GPU [20,hs,ws] activation maps -> (keys, cam [K,ceil(H/4),ceil(W/4)],
     high_res [K,H,W]) — step/make_cam.py:38-52 in two launches of libirn_hip.so (irn_cam_merge).
-    GPU tensors only; `merge_scales_torch` below is the torch-op restatement the CPU tests use."""
+    GPU tensors only (the torch-op restatement the tests compare with lives in oracle/torch_mirrors.py)."""
     from .. import ops
     return ops.cam_merge(outputs, size, label)
-
-
-def merge_scales_torch(outputs, size, label):
-    """The reference's own op sequence (step/make_cam.py:32-52) on whatever device the tensors live
-    on.  Not on the product path (which is `merge_scales`): kept as the host-logic mirror that
-    tests/test_host_logic.py checks against the reference's golden output on CPU, and as the
-    cross-check of the HIP kernel in the GPU tests."""
-    size = (int(size[0]), int(size[1]))
-    strided_size = imutils.get_strided_size(size, 4)
-    strided_up_size = imutils.get_strided_up_size(size, 16)
-    strided_cam = torch.sum(torch.stack(
-        [F.interpolate(o[None], strided_size, mode="bilinear", align_corners=False)[0] for o in outputs]), 0)
-    highres = torch.sum(torch.stack(
-        [F.interpolate(o[:, None], strided_up_size, mode="bilinear", align_corners=False) for o in outputs], 0), 0)
-    highres = highres[:, 0, :size[0], :size[1]]
-    valid_cat = torch.nonzero(label)[:, 0]
-    # per-channel spatial max: the reference calls F.adaptive_max_pool2d(x, (1, 1)), which on the GPU
-    # runs one serial thread per channel over the whole map (24 ms per 512^2 image, twice the backbone);
-    # amax is the same value
-    strided_cam = strided_cam[valid_cat]
-    strided_cam = strided_cam / (strided_cam.amax(dim=(1, 2), keepdim=True) + 1e-5)
-    highres = highres[valid_cat]
-    highres = highres / (highres.amax(dim=(1, 2), keepdim=True) + 1e-5)
-    return valid_cat, strided_cam, highres
 
 
 def _save_cam(path, keys_cpu, event, staging, cam_view, hi_view):

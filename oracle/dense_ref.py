@@ -58,24 +58,43 @@ def to_transition_matrix(affinity_dense, beta, times):
 
 def propagate_to_edge(x, edge, radius=5, beta=10, exp_times=8, timings=None):
     """misc/indexing.py:141-165.  x: float32 [..., h, w]; edge [1, h, w]; returns [C', 1, h, w].
-    `timings` (a dict) receives the seconds of the two phases: "setup" (index tables, path-max affinity, dense matrix:
-    ~N^2) and "transition" (power, normalisation and the `exp_times` squarings: 2*N^3 flops each)."""
+    `timings` (a dict) receives the seconds of the phases, in the reference's own order: "path_index" (:148, the index
+    tables), "affinity" (:150-151, pad + path-max gather), "dense" (:154-157, COO -> dense (hp*wp)^2 -> crop to (h*w)^2),
+    "pow_normalise" (:133-135), "squarings" (:136-137, `exp_times` dense sgemm: 2*N^3 flops each), "final" (:162-164), and
+    the two sums "setup" = the first three (~N^2) and "transition" = the rest (~N^3)."""
     import time
+    tm = {}
     t0 = time.perf_counter()
     x = torch.as_tensor(np.asarray(x, np.float32))
     edge = torch.as_tensor(np.asarray(edge, np.float32)).reshape(1, *x.shape[-2:])
     h, w = x.shape[-2:]
     hp, wp = h + radius, w + 2 * radius
     pi = O.PathIndexOracle(radius, (hp, wp))
+    t1 = time.perf_counter()
+    tm["path_index"] = t1 - t0
     edge_padded = F.pad(edge, (radius, radius, 0, radius), mode="constant", value=1.0)
     aff = edge_to_affinity(edge_padded.reshape(1, -1), pi.path_indices)
+    t2 = time.perf_counter()
+    tm["affinity"] = t2 - t1
     dense = affinity_sparse2dense(aff, pi.src_indices, pi.dst_indices, hp * wp)
     dense = dense.view(hp, wp, hp, wp)[:-radius, radius:-radius, :-radius, radius:-radius].reshape(h * w, h * w)
-    t1 = time.perf_counter()
-    t = to_transition_matrix(dense, beta, exp_times)
+    t3 = time.perf_counter()
+    tm["dense"] = t3 - t2
+    s = torch.pow(dense, beta)                                  # to_transition_matrix, misc/indexing.py:132-139
+    del dense
+    t = s / torch.sum(s, dim=0, keepdim=True)
+    del s
+    t4 = time.perf_counter()
+    tm["pow_normalise"] = t4 - t3
+    for _ in range(exp_times):
+        t = torch.matmul(t, t)
+    t5 = time.perf_counter()
+    tm["squarings"] = t5 - t4
     xe = x.reshape(-1, h, w) * (1 - edge)
     out = torch.matmul(xe.view(-1, h * w), t).view(-1, 1, h, w)
+    tm["final"] = time.perf_counter() - t5
+    tm["setup"] = t3 - t0
+    tm["transition"] = time.perf_counter() - t3
     if timings is not None:
-        timings["setup"] = t1 - t0
-        timings["transition"] = time.perf_counter() - t1
+        timings.update(tm)
     return out

@@ -251,8 +251,7 @@ def test_cam_merge_kernel_vs_oracle_and_reference_golden(golden):
     """irn_cam_merge (step/make_cam.py:38-52) bit for bit against the oracle's restatement, against the
     reference's own output (1e-6; bar 1e-4) and against the torch-op mirror on the GPU."""
     from irn_amd import ops
-    from irn_amd.step import make_cam
-    from oracle import irn_oracle as O
+    from oracle import irn_oracle as O, torch_mirrors
     dev = torch.device("cuda", 0)
     cm = golden("cam_merge")
     for name in "ab":
@@ -277,7 +276,7 @@ def test_cam_merge_kernel_vs_oracle_and_reference_golden(golden):
         ok, olo, ohi = O.cam_merge(outs, (H, W), label)
         assert np.array_equal(keys.cpu().numpy(), ok)
         assert np.array_equal(cam.cpu().numpy(), olo) and np.array_equal(hi.cpu().numpy(), ohi)
-        tk, tc, th = make_cam.merge_scales_torch([torch.from_numpy(o).to(dev) for o in outs], (H, W),
+        tk, tc, th = torch_mirrors.merge_scales_torch([torch.from_numpy(o).to(dev) for o in outs], (H, W),
                                                  torch.from_numpy(label).to(dev))
         assert torch.equal(tk, keys) and (tc - cam).abs().max().item() <= 1e-5 and (th - hi).abs().max().item() <= 1e-5
 
@@ -290,7 +289,8 @@ def test_bench_contract_one_json_line():
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "2", "--warmup", "1", "--batch", "8",
-                          "--cpu-images", "2", "--legs", "coco,ins"], capture_output=True, text=True, timeout=900, cwd=root)
+                          "--cpu-images", "2", "--ref-grids", "64", "--legs", "coco,ins,walk_plain"], capture_output=True, text=True,
+                         timeout=900, cwd=root)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1
@@ -305,10 +305,19 @@ def test_bench_contract_one_json_line():
     assert rf["bound"] == "fp32_vector" and rf["unit"] == "TFLOP/s" and rf["peak"] == 157.3
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9 and 0 < rf["frac"] < 1 and "traffic" in rf
     assert rf["hbm_equivalent"]["unit"] == "GB/s" and rf["hbm_equivalent"]["peak"] == 8000.0
+    # `achieved` counts the flops the kernel executes (84 applications of the operator for T^256); 8(d)'s F beside it
+    sch = rf["schedule"]
+    assert sch["n_sweeps"] == 256 and sch["operator_applications"] == 84 and rf["sweeps_per_launch"] == 84
+    pe = rf["power_equivalent"]
+    assert abs(pe["achieved"] / rf["achieved"] - 256.0 / 84.0) < 1e-6 and abs(pe["flops"] / rf["flops_per_launch"] - 256.0 / 84.0) < 1e-6
+    lp = r["label_parity"]
+    assert lp["images"] == 2 and lp["not_a_tie"] == 0 and lp["pixels_differing"] <= 16 * lp["images"] and lp["max_top2_gap"] < 1e-4
     assert abs(r["value"] - 2 * 8 / (r["ms_per_step"] * 2e-3)) / r["value"] < 1e-6
     cb = r["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and cb["unit"] == "images/s" and cb["sample"]
     ra = cb["reference_algorithm"]
-    assert ra["extrapolated"] is True and ra["value"] > 0 and ra["seconds_measured"]
-    for leg in ("coco", "ins"):
+    assert ra["extrapolated"] is True and ra["value"] > 0 and ra["seconds_measured"]["64x64"]["squarings"] > 0
+    assert ra["cores"] == cb["cores"]
+    for leg in ("coco", "ins", "walk_plain"):
         assert r["legs"][leg].get("value", 0) > 0, r["legs"][leg]
+    assert r["legs"]["walk_plain"]["n_applied"] == 256 and r["legs"]["walk_plain"]["value"] < r["value"]

@@ -86,11 +86,11 @@ def test_dataset_msf(tmp_path):
 def test_cam_merge_matches_reference_golden(golden):
     """step/make_cam.py:32-52 through the torch-op mirror of the merge (CPU here) against the reference's
     outputs; the HIP kernel the step uses is checked against the same fixture in test_gpu_steps.py."""
-    from irn_amd.step import make_cam
+    from oracle import torch_mirrors
     cm = golden("cam_merge")
     for name in "ab":
         outs = [torch.from_numpy(cm["%s_out%d" % (name, i)]) for i in range(4)]
-        keys, cam, hi = make_cam.merge_scales_torch(outs, tuple(int(v) for v in cm[name + "_size"]),
+        keys, cam, hi = torch_mirrors.merge_scales_torch(outs, tuple(int(v) for v in cm[name + "_size"]),
                                               torch.from_numpy(cm[name + "_label"]))
         assert np.array_equal(keys.numpy(), cm[name + "_keys"])
         assert np.abs(cam.numpy() - cm[name + "_cam"]).max() <= 1e-6
