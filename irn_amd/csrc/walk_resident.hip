@@ -401,6 +401,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     for (int round = 0; round < n_rounds; ++round) {
         const int4 je = jobs[round * gridDim.x + blockIdx.x];
         if (je.x < 0) continue;
+        long long *jslot = nullptr;     // diagnostic: per-job prologue stamps of two workgroups, rounds 0-7 -> rows 248-255
+        if (PROF && prof && round < 8 && tid == 0 && (blockIdx.x == 0 || blockIdx.x == gridDim.x / 2))
+            jslot = prof + ((blockIdx.x == 0 ? 0 : 256) + 248 + round) * 4;
+        if (PROF && jslot) jslot[0] = wall_clock64();
         const WalkImg I = imgs[je.x];
         const int ty0 = je.y, tx0 = je.z;
         const int h = I.h, w = I.w;
@@ -450,6 +454,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 #undef IRN_LOAD_PART
         // 1/deg of the tile: the waves' parts meet in LDS (the combine's partial-sum buffer), fp64 throughout
         __syncthreads();   // previous job's readers of part / invd / xs are done
+        if (PROF && jslot) jslot[1] = wall_clock64();
         {
             double *pw = part + wv * 256 + lane * 4;
 #pragma unroll
@@ -502,6 +507,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             if (ok0) vmask |= 1u << (2 * k);
             if (ok1) vmask |= 2u << (2 * k);
         }
+        if (PROF && jslot) jslot[2] = wall_clock64();
         for (int i = tid; i < 2 * LH * LW; i += 512) xs[i] = 0.f;
         // the recurrence's private terms {y_{t-1}, s_t} of the tile's own pixels, first CAPC channels: from the workspace
         // (written by x0_granule_kernel, or by the previous launch of a walk cut into several) into LDS
@@ -519,6 +525,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             psl[idx] = v;
         }
         __syncthreads();
+        if (PROF && jslot) jslot[3] = wall_clock64();
 
         // ---- the walk of this tile: a pipeline of steps (sweep t, channel c), c fastest ----
         // Step k stages x_t[c] into xs[k & 1], forms the partial sums into part[k & 1], combines and
@@ -559,7 +566,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             const bool rec2 = cheb && t > 0;                 // y_{t+1} = 2 T y_t - y_{t-1}; the first step is y_1 = T y_0
             float *xsb = xs + (k & 1) * (LH * LW);
             long long *pslot = nullptr;   // diagnostic time stamps of round 0 for two workgroups
-            if (PROF && prof && round == 0 && tid == 0 && (blockIdx.x == 0 || blockIdx.x == gridDim.x / 2) && k < 256)
+            if (PROF && prof && round == 0 && tid == 0 && (blockIdx.x == 0 || blockIdx.x == gridDim.x / 2) && k < 248)
                 pslot = prof + ((blockIdx.x == 0 ? 0 : 256) + k) * 4;
             if (PROF && pslot) pslot[0] = wall_clock64();
 
@@ -681,8 +688,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 // stores BOTH granules with one 16-byte store (8-byte sc1 stores are the expensive form, lesson 10;
                 // folding two pixels per thread instead doubled the combine's latency chain: 0.21 -> 0.40 us).
                 if constexpr (R == 10) {
-#pragma unroll
-                for (int i = tid; i < (poller ? 0 : G::SLABS * 256); i += 256) {
+                auto combine10 = [&](auto lds_tag) __attribute__((always_inline)) {
+                    constexpr bool PS_LDS = decltype(lds_tag)::value;
+                    const int i = tid;                    // G::SLABS * 256 == 256: one pixel per combining thread
                     const int s2 = i >> 8, prow = (i >> 5) & 7, x = i & 31;
                     const int py = (s2 / G::C::SL_X) * kSlabH + prow;
                     const int px = (s2 % G::C::SL_X) * kSlabW + x;
@@ -690,13 +698,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     const int yy = ty0 + py, xx = tx0 + px;
                     const bool inimg = yy < h && xx < w;
                     const unsigned o = (unsigned)(yy * w + xx);
-                    // {y_{t-1}, s_t} of this pixel: LDS for the first CAPC channels, else the workspace (asked for first:
-                    // an L2 round trip that the partial sums below cover)
+                    // {y_{t-1}, s_t} of this pixel: LDS for the first CAPC channels (read together with the partial sums),
+                    // else the workspace (asked for first: an L2 round trip that the LDS reads below cover)
                     f2a pv{0.f, 0.f};
-                    if (cheb) {
-                        if (c < G::CAPC) pv = psl[c * G::TPX + i];
-                        else if (inimg) pv = __builtin_bit_cast(f2a, __builtin_amdgcn_raw_buffer_load_b64(prs, (int)o * 8, c * ch_bytes, 0));
-                    }
+                    if constexpr (PS_LDS) pv = psl[c * G::TPX + i];
+                    else if (inimg) pv = __builtin_bit_cast(f2a, __builtin_amdgcn_raw_buffer_load_b64(prs, (int)o * 8, c * ch_bytes, 0));
                     // the Q fp32 chains of the pixel: pairwise in fp32 (as close to the exact operator as adding them in
                     // fp64: the model of tests/test_precision_model.py gives the same 1.5e-6 after 256 sweeps), then centre
                     // term and normalisation in fp64.  A chain of Q dependent fp64 conversions + additions was most of the
@@ -704,18 +710,19 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     float ps[Q];
 #pragma unroll
                     for (int q = 0; q < Q; ++q) ps[q] = pr[q * 256];
+                    const float centre = xsb[(py + H) * LW + px + HP];
+                    const double inv = invd[i];
 #pragma unroll
                     for (int span = 1; span < Q; span *= 2)
 #pragma unroll
                         for (int q = 0; q + span < Q; q += 2 * span) ps[q] = ps[q] + ps[q + span];
-                    const float centre = xsb[(py + H) * LW + px + HP];
-                    const double m = ((double)centre + (double)ps[0]) * invd[i];
+                    const double m = ((double)centre + (double)ps[0]) * inv;
                     const float res = rec2 ? (float)(2.0 * m - (double)pv.x) : (float)m;
                     float outv = res;
                     if (cheb) {
                         outv = fmaf(ck, res, pv.y);
                         const f2a nv{centre, outv};
-                        if (c < G::CAPC) psl[c * G::TPX + i] = nv;
+                        if constexpr (PS_LDS) psl[c * G::TPX + i] = nv;
                         else if (inimg && !last)
                             __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2v, nv), prs, (int)o * 8, c * ch_bytes, 0);
                     }
@@ -731,76 +738,101 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                             else st_granule(dst, (int)o * 8, c * ch_bytes, want + 1, res);
                         }
                     }
+                };
+                static_assert(R != 10 || G::SLABS * 256 == 256, "one pixel per combining thread at radius 10");
+                if (!poller) {
+                    if (!cheb || c < G::CAPC) combine10(std::true_type{});
+                    else combine10(std::false_type{});
                 }
                 } else {
                     // radius 5 (1024 pixels per tile, 4 per combining thread): a pixel PAIR per thread and iteration
                     // (0.41 vs 0.75 us for four single pixels); the sums of all iterations are formed before the
                     // first store so that their LDS reads overlap
                     constexpr int NIT = G::SLABS * 128 / 256;
-                    if (!poller) {
-                        float r0v[NIT], r1v[NIT];
+                    // Three phases, each over all iterations: every read is issued before the first dependent operation,
+                    // every write comes last (written iteration by iteration, the LDS write of one iteration's recurrence
+                    // terms kept the next iteration's reads behind it — one array to the compiler — and the phase took
+                    // 0.8 us instead of 0.46).  Two copies of the body, chosen per step: recurrence terms in LDS (the
+                    // common case, no branches inside) or in the workspace (channels beyond CAPC).
+                    auto combine5 = [&](auto lds_tag) __attribute__((always_inline)) {
+                        constexpr bool PS_LDS = decltype(lds_tag)::value;
+                        float pa[NIT][Q], pb[NIT][Q], ce0[NIT], ce1[NIT];
+                        double iv0[NIT], iv1[NIT];
+                        f4a pv[NIT];
 #pragma unroll
                         for (int it = 0; it < NIT; ++it) {
                             const int i = tid + it * 256;
                             const int s2 = i >> 7, prow = (i >> 4) & 7, x = (i & 15) * 2;
                             const int py = (s2 / G::C::SL_X) * kSlabH + prow;
                             const int px = (s2 % G::C::SL_X) * kSlabW + x;
-                            const float *pr = partf + (k & 1) * (kWaves * 256) + (s2 * Q) * 256 + (prow * 8 + (x >> 2)) * 4 + (x & 3);
-                            const float *xc = xsb + (py + H) * LW + px + HP;
                             const int ii = s2 * 256 + prow * 32 + x;
-                            const int yy = ty0 + py, xx = tx0 + px;
-                            const bool in0 = yy < h && xx < w, in1 = in0 && xx + 1 < w;
-                            const unsigned o = (unsigned)(yy * w + xx);
-                            // {y_{t-1}, s_t} of the pixel pair (see the radius-10 branch)
-                            f4a pv{0.f, 0.f, 0.f, 0.f};
-                            if (cheb) {
-                                if (c < G::CAPC) pv = *reinterpret_cast<const f4a *>(psl + c * G::TPX + ii);
-                                else if (in1) pv = __builtin_bit_cast(f4a, __builtin_amdgcn_raw_buffer_load_b128(prs, (int)o * 8, c * ch_bytes, 0));
+                            if constexpr (PS_LDS) {
+                                pv[it] = *reinterpret_cast<const f4a *>(psl + c * G::TPX + ii);
+                            } else {
+                                const int yy = ty0 + py, xx = tx0 + px;
+                                const bool in0 = yy < h && xx < w, in1 = in0 && xx + 1 < w;
+                                const unsigned o = (unsigned)(yy * w + xx);
+                                pv[it] = f4a{0.f, 0.f, 0.f, 0.f};
+                                if (in1) pv[it] = __builtin_bit_cast(f4a, __builtin_amdgcn_raw_buffer_load_b128(prs, (int)o * 8, c * ch_bytes, 0));
                                 else if (in0) {
                                     const f2a p2 = __builtin_bit_cast(f2a, __builtin_amdgcn_raw_buffer_load_b64(prs, (int)o * 8, c * ch_bytes, 0));
-                                    pv.x = p2.x;
-                                    pv.y = p2.y;
+                                    pv[it].x = p2.x;
+                                    pv[it].y = p2.y;
                                 }
                             }
-                            float ps0 = pr[0], ps1 = pr[1];
+                            const float *pr = partf + (k & 1) * (kWaves * 256) + (s2 * Q) * 256 + (prow * 8 + (x >> 2)) * 4 + (x & 3);
+                            const float *xc = xsb + (py + H) * LW + px + HP;
+#pragma unroll
+                            for (int q = 0; q < Q; ++q) {
+                                pa[it][q] = pr[q * 256];
+                                pb[it][q] = pr[q * 256 + 1];
+                            }
+                            ce0[it] = xc[0];
+                            ce1[it] = xc[1];
+                            iv0[it] = invd[ii];
+                            iv1[it] = invd[ii + 1];
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                        float r0v[NIT], r1v[NIT], s0v[NIT], s1v[NIT];
+#pragma unroll
+                        for (int it = 0; it < NIT; ++it) {
+                            float ps0 = pa[it][0], ps1 = pb[it][0];
 #pragma unroll
                             for (int q = 1; q < Q; ++q) {
-                                ps0 += pr[q * 256];
-                                ps1 += pr[q * 256 + 1];
+                                ps0 += pa[it][q];
+                                ps1 += pb[it][q];
                             }
-                            const float ce0 = xc[0], ce1 = xc[1];
-                            const double m0 = ((double)ce0 + (double)ps0) * invd[ii], m1 = ((double)ce1 + (double)ps1) * invd[ii + 1];
-                            float r0 = rec2 ? (float)(2.0 * m0 - (double)pv.x) : (float)m0;
-                            float r1 = rec2 ? (float)(2.0 * m1 - (double)pv.z) : (float)m1;
-                            if (cheb) {
-                                const float s0 = fmaf(ck, r0, pv.y), s1 = fmaf(ck, r1, pv.w);
-                                const f4a nv{ce0, s0, ce1, s1};
-                                if (c < G::CAPC) *reinterpret_cast<f4a *>(psl + c * G::TPX + ii) = nv;
-                                else if (!last) {
-                                    if (in1) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4v, nv), prs, (int)o * 8, c * ch_bytes, 0);
-                                    else if (in0) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2v, f2a{ce0, s0}), prs, (int)o * 8, c * ch_bytes, 0);
-                                }
-                                if (last) {         // the series sum is the result
-                                    r0 = s0;
-                                    r1 = s1;
-                                }
-                            }
-                            r0v[it] = r0;
-                            r1v[it] = r1;
+                            const double m0 = ((double)ce0[it] + (double)ps0) * iv0[it], m1 = ((double)ce1[it] + (double)ps1) * iv1[it];
+                            r0v[it] = rec2 ? (float)(2.0 * m0 - (double)pv[it].x) : (float)m0;
+                            r1v[it] = rec2 ? (float)(2.0 * m1 - (double)pv[it].z) : (float)m1;
+                            s0v[it] = fmaf(ck, r0v[it], pv[it].y);
+                            s1v[it] = fmaf(ck, r1v[it], pv[it].w);
                         }
+                        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                         for (int it = 0; it < NIT; ++it) {
                             const int i = tid + it * 256;
                             const int s2 = i >> 7, prow = (i >> 4) & 7, x = (i & 15) * 2;
+                            const int ii = s2 * 256 + prow * 32 + x;
                             const int yy = ty0 + (s2 / G::C::SL_X) * kSlabH + prow;
                             const int xx = tx0 + (s2 % G::C::SL_X) * kSlabW + x;
+                            const bool in0 = yy < h && xx < w, in1 = in0 && xx + 1 < w;
+                            const unsigned o = (unsigned)(yy * w + xx);
+                            if (cheb) {
+                                const f4a nv{ce0[it], s0v[it], ce1[it], s1v[it]};
+                                if constexpr (PS_LDS) {
+                                    *reinterpret_cast<f4a *>(psl + c * G::TPX + ii) = nv;
+                                } else if (!last) {
+                                    if (in1) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4v, nv), prs, (int)o * 8, c * ch_bytes, 0);
+                                    else if (in0) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2v, f2a{ce0[it], s0v[it]}), prs, (int)o * 8, c * ch_bytes, 0);
+                                }
+                            }
                             const float r0 = r0v[it], r1 = r1v[it];
-                            if (yy < h && xx < w) {
-                                const unsigned o = (unsigned)(yy * w + xx);
-                                if (last) {
-                                    ((gf_t)I.out)[(unsigned)c * n + o] = r0;
-                                    if (xx + 1 < w) ((gf_t)I.out)[(unsigned)c * n + o + 1] = r1;
-                                } else if (xx + 1 < w) {
+                            if (in0) {
+                                if (last) {         // the series sum is the result (plain powers: the state itself)
+                                    ((gf_t)I.out)[(unsigned)c * n + o] = cheb ? s0v[it] : r0;
+                                    if (in1) ((gf_t)I.out)[(unsigned)c * n + o + 1] = cheb ? s1v[it] : r1;
+                                } else if (in1) {
                                     if (plain_st) st_granule2<0>(dst, (int)o * 8, c * ch_bytes, want + 1, r0, r1);
                                     else st_granule2(dst, (int)o * 8, c * ch_bytes, want + 1, r0, r1);
                                 } else {
@@ -809,6 +841,10 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                                 }
                             }
                         }
+                    };
+                    if (!poller) {
+                        if (!cheb || c < G::CAPC) combine5(std::true_type{});
+                        else combine5(std::false_type{});
                     }
                 }
             }

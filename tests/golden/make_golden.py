@@ -383,6 +383,31 @@ def gen_nets512():
         r50.model_zoo.load_url = real_load
 
 
+def gen_nets_scales():
+    """CAM.forward (net/resnet50_cam.py:55-70) at the OTHER two scales make_cam feeds it for a 512^2 image
+    (voc12/dataloader.py:191-199 with run_sample.py:31's cam_scales): 0.5x -> [2,3,256,256] and 2.0x -> [2,3,1024,1024]
+    (nets512.npz holds 1.0x and 1.5x).  Same seeded weights; inputs regenerated by the tests from the seeds."""
+    import net.resnet50 as r50
+    from irn_amd.net import weights as wgen
+
+    real_load = r50.model_zoo.load_url
+    r50.model_zoo.load_url = lambda *a, **k: dict(wgen.random_resnet50_state(seed=0), **{
+        "fc.weight": torch.zeros(1), "fc.bias": torch.zeros(1)})
+    try:
+        import net.resnet50_cam as rc
+        out = {}
+        cam = rc.CAM()
+        cam.load_state_dict(wgen.random_cam_state(seed=1), strict=True)
+        cam.eval()
+        with torch.no_grad():
+            for size, seed in ((256, 75), (1024, 76)):
+                out["cam%d_seed" % size] = np.asarray([size, size, seed], np.int32)
+                out["cam%d_out" % size] = cam(torch.from_numpy(synth.image_pair(size, size, seed))).numpy()
+        np.savez_compressed(os.path.join(OUT, "nets_scales.npz"), **out)
+    finally:
+        r50.model_zoo.load_url = real_load
+
+
 def gen_msf():
     """Multi-scale dataset item: the reference's own VOC12ClassificationDatasetMSF.__getitem__
     (voc12/dataloader.py:185-205) on synthetic photos (imageio.imread stubbed to hand them over), i.e.
@@ -480,7 +505,7 @@ def gen_trunk_ops():
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", nargs="*", default=None,
-                    help="subset of: path affinity affinity_grad walk walk128 semseg instance cam_merge nets nets512 msf pair_disp trunk_ops; or walk case names")
+                    help="subset of: path affinity affinity_grad walk walk128 semseg instance cam_merge nets nets512 nets_scales msf pair_disp trunk_ops; or walk case names")
     a = ap.parse_args()
     _install_reference()
     torch.set_num_threads(os.cpu_count())
@@ -510,6 +535,8 @@ def main():
         gen_nets()
     if want("nets512"):
         gen_nets512()
+    if want("nets_scales"):
+        gen_nets_scales()
     if want("msf"):
         gen_msf()
     if want("pair_disp"):

@@ -68,6 +68,10 @@ def test_cam_forward_on_device_vs_reference(golden):
     for key in ("cam512", "cam768"):
         h, w, seed = (int(v) for v in g5[key + "_seed"])
         cases.append((torch.from_numpy(synth.image_pair(h, w, seed)), g5[key + "_out"]))
+    gs = golden("nets_scales")         # the other two scales of a 512^2 image: 0.5x and 2.0x (voc12/dataloader.py:191-199)
+    for key in ("cam256", "cam1024"):
+        h, w, seed = (int(v) for v in gs[key + "_seed"])
+        cases.append((torch.from_numpy(synth.image_pair(h, w, seed)), gs[key + "_out"]))
     with torch.no_grad():
         for x, ref in cases:
             y = net(x.to(_dev())).cpu().numpy()
@@ -91,6 +95,17 @@ def test_cam_forward_batched_equals_reference(golden):
     assert y.shape == (3,) + g5["cam512_out"].shape
     assert _rel(y[0], g5["cam512_out"]) <= TOL_REF and _rel(y[2], g5["cam512_out"]) <= TOL_REF
     assert np.abs(y[1] - y[0]).max() > 1.0       # the middle pair is a different image
+    # ... and at the 0.5x / 2.0x scales of make_cam (256^2 and 1024^2 inputs)
+    gs = golden("nets_scales")
+    for key in ("cam256", "cam1024"):
+        h, w, seed = (int(v) for v in gs[key + "_seed"])
+        a = torch.from_numpy(synth.image_pair(h, w, seed))
+        b = torch.from_numpy(synth.image_pair(h, w, seed + 100))
+        with torch.no_grad():
+            y = net.forward_batch(torch.cat([b, a]).to(_dev())).cpu().numpy()
+        norm = lambda t: t / (t.max(axis=(1, 2), keepdims=True) + 1e-5)
+        assert y.shape == (2,) + gs[key + "_out"].shape
+        assert _rel(y[1], gs[key + "_out"]) <= TOL_REF and np.abs(norm(y[1]) - norm(gs[key + "_out"])).max() <= TOL_REF, key
 
 
 def test_edge_displacement_on_device_vs_reference(golden):

@@ -22,14 +22,23 @@ for kv in sys.argv[4:]:
 for _ in range(2):
     wk(edges, cams, beta=10, n_sweeps=256)
 wk.check()
+n_steps = wk.steps(256) * cch
 p = wk.read_profile().astype(np.float64) * 0.01      # us
 for g in range(2):
-    q = p[g, 8:250]
+    q = p[g, 8:min(n_steps - 2, 246)]
     tot = np.diff(q[:, 0])
     print(" ".join(sys.argv[1:]), "wg %d: step period %.2f us (min %.2f max %.2f); poll+stage %.2f, first partials %.2f, reduce+store %.2f" %
           (g, tot.mean(), tot.min(), tot.max(), (q[:, 1] - q[:, 0]).mean(), (q[:, 2] - q[:, 1]).mean(), (q[:, 3] - q[:, 2]).mean()))
 
-import os
+# per-job prologue of rounds 0..: rows 248-255 = {job begin, weights + degree part in registers, 1/deg ready, first step}
+for g in range(2):
+    j = p[g, 248:248 + max(1, min(8, (nimg * (4 if r == 10 else 1) + 3) // 4 if r == 10 else 8))]
+    j = j[j[:, 0] > 0]
+    if len(j):
+        print(" ".join(sys.argv[1:]), "wg %d prologue per job (us): weights+degree %.1f, 1/deg %.1f, tables+fill %.1f; job period %s" %
+              (g, (j[:, 1] - j[:, 0]).mean(), (j[:, 2] - j[:, 1]).mean(), (j[:, 3] - j[:, 2]).mean(),
+               np.round(np.diff(j[:, 0]), 1).tolist()))
+
 if os.environ.get("RAW"):
     q = p[0, 100:124]
     base = q[0, 0]
