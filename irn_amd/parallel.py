@@ -11,7 +11,7 @@ def rank_world():
     return int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
 
 
-def init_process_group(backend=None, device=None):
+def init_process_group(backend=None, device=None, timeout_s=None):
     """Joins the job described by RANK/WORLD_SIZE/MASTER_* (torch.distributed.run).  backend 'nccl'
     is RCCL on ROCm; 'gloo' serves the CPU tests."""
     import torch.distributed as dist
@@ -22,6 +22,9 @@ def init_process_group(backend=None, device=None):
     if backend is None:
         backend = "nccl" if torch.cuda.is_available() else "gloo"
     kw = {"device_id": device} if (backend == "nccl" and device is not None) else {}
+    if timeout_s:
+        import datetime
+        kw["timeout"] = datetime.timedelta(seconds=float(timeout_s))
     dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
     return dist
 
@@ -37,7 +40,7 @@ def init_process_group_with_fallback(backend="auto", device=None):
     want = ("nccl" if torch.cuda.is_available() else "gloo") if backend == "auto" else backend
     if want == "nccl":
         try:
-            d = init_process_group("nccl", device)
+            d = init_process_group("nccl", device, timeout_s=180)     # a hanging start-up must end in the fall-back too
             t = torch.zeros(1, device=device)
             d.all_reduce(t)                       # the first collective is where a broken fabric shows
             torch.cuda.synchronize()

@@ -226,7 +226,7 @@ def test_steps_two_worker_processes_on_one_device(tmp_path):
     make_sem_seg_labels.run(one)
     make_ins_seg_labels.run(one)
     assert _common.CAM_STORE.hits - hits_before == 2 * len(names)
-    n_px = n_diff = 0
+    n_px = n_diff = ins_diff = 0
     for n in names:
         a = np.load(os.path.join(two.cam_out_dir, n + ".npy"), allow_pickle=True).item()
         b = np.load(os.path.join(one.cam_out_dir, n + ".npy"), allow_pickle=True).item()
@@ -243,11 +243,13 @@ def test_steps_two_worker_processes_on_one_device(tmp_path):
         assert os.path.exists(fa) == os.path.exists(fb), n
         if os.path.exists(fa):
             da, db = np.load(fa, allow_pickle=True).item(), np.load(fb, allow_pickle=True).item()
-            if len(da["score"]) == len(db["score"]):
-                assert np.array_equal(da["class"], db["class"]), n
-                assert int((da["mask"] != db["mask"]).sum()) <= 16, n
-    print("two-worker vs one-process label maps: %d of %d pixels differ" % (n_diff, n_px))
+            # the two runs' CAMs differ at 1e-5 (another MIOpen solver in another process): an instance fragment whose two
+            # best channels tie at that level may change hands, so the class maps the detections paint are compared
+            paint = lambda det: (np.asarray(det["mask"]).astype(np.int64) * (np.asarray(det["class"], np.int64) + 1)[:, None, None]).sum(0)
+            ins_diff += int((paint(da) != paint(db)).sum())
+    print("two-worker vs one-process: %d of %d semantic label pixels and %d instance-class pixels differ" % (n_diff, n_px, ins_diff))
     assert n_diff <= 8          # same kernels on the same inputs; MIOpen may pick another solver in another process
+    assert ins_diff <= 0.01 * n_px
 
 
 def test_cam_merge_kernel_vs_oracle_and_reference_golden(golden):

@@ -111,3 +111,35 @@ def test_gloo_world2_timing_and_gather(tmp_path):
     assert not set(r0["mine"]) & set(r1["mine"])
     assert r0["slowest"] == r1["slowest"] == 2.0
     assert r0["gathered"] == [[0, 1], [10, 11]] and r1["gathered"] is None
+
+
+def _fallback_rank(rank, world, port, out_dir):
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    from irn_amd import parallel
+    real = parallel.init_process_group
+
+    def broken_rccl(backend=None, device=None, timeout_s=None):
+        if backend == "nccl":
+            raise RuntimeError("hipIpcGetMemHandle: invalid argument (simulated RCCL start-up failure)")
+        return real(backend, device, timeout_s)
+
+    parallel.init_process_group = broken_rccl
+    torch.cuda.is_available = lambda: True             # `auto` then asks for RCCL first, as on a GPU box
+    dist, used = parallel.init_process_group_with_fallback("auto", None)
+    assert used == "gloo" and dist.get_world_size() == world and os.environ["MASTER_PORT"] == str(port + 1)
+    dist.barrier()
+    slowest = parallel.max_over_ranks(3.0 - rank, dist, device="cuda:0")     # a GPU device name must not reach gloo
+    np.save(os.path.join(out_dir, "f%d.npy" % rank), {"slowest": slowest, "backend": used})
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bench_process_group_falls_back_to_gloo(tmp_path):
+    """bench.py --gpus N needs the group only for its barrier and max-over-ranks: when RCCL cannot start, every rank
+    joins a gloo group on the next port instead and the line is still produced (with the backend recorded)."""
+    port = _free_port()
+    mp.spawn(_fallback_rank, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    for r in range(2):
+        d = np.load(tmp_path / ("f%d.npy" % r), allow_pickle=True).item()
+        assert d == {"slowest": 3.0, "backend": "gloo"}
