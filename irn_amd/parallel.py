@@ -40,7 +40,7 @@ def init_process_group_with_fallback(backend="auto", device=None):
     want = ("nccl" if torch.cuda.is_available() else "gloo") if backend == "auto" else backend
     if want == "nccl":
         try:
-            d = init_process_group("nccl", device, timeout_s=180)     # a hanging start-up must end in the fall-back too
+            d = init_process_group("nccl", device, timeout_s=600)     # a hanging start-up must end in the fall-back too
             t = torch.zeros(1, device=device)
             d.all_reduce(t)                       # the first collective is where a broken fabric shows
             torch.cuda.synchronize()

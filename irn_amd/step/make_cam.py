@@ -20,6 +20,7 @@ import torch
 
 from ..misc import torchutils
 from ..voc12 import dataloader as voc12_dataloader
+from ..net import weights
 from . import _common
 
 
@@ -113,9 +114,7 @@ def _work(process_id, model, dataset, args):
 
 
 def run(args):
-    model = getattr(_common.import_network(args.cam_network), "CAM")()
-    model.load_state_dict(torch.load(args.cam_weights_name + ".pth", map_location="cpu"), strict=True)
-    model.eval()
+    model = weights.load_checkpoint(getattr(_common.import_network(args.cam_network), "CAM"), args.cam_weights_name + ".pth", strict=True)
     n_gpus = _common.n_gpus_or_raise(args)
     scales = tuple(float(s) for s in args.cam_scales)
     dataset = voc12_dataloader.VOC12ClassificationDatasetMSF(args.train_list, voc12_root=args.voc12_root,

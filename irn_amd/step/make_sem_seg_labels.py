@@ -19,6 +19,7 @@ from PIL import Image
 from .. import ops
 from ..misc import indexing
 from ..voc12 import dataloader as voc12_dataloader
+from ..net import weights
 from . import _common
 
 RADIUS = 5   # hard-coded at the reference call site (step/make_sem_seg_labels.py:41)
@@ -129,9 +130,7 @@ def _work(process_id, model, dataset, args):
 
 
 def run(args):
-    model = getattr(_common.import_network(args.irn_network), "EdgeDisplacement")()
-    model.load_state_dict(torch.load(args.irn_weights_name, map_location="cpu"), strict=False)
-    model.eval()
+    model = weights.load_checkpoint(getattr(_common.import_network(args.irn_network), "EdgeDisplacement"), args.irn_weights_name, strict=False)
     n_gpus = _common.n_gpus_or_raise(args)
     dataset = voc12_dataloader.VOC12ClassificationDatasetMSF(args.infer_list, voc12_root=args.voc12_root,
                                                              scales=(1.0,), raw=_common.device_preprocess(args))

@@ -391,3 +391,29 @@ def test_folding_under_inference_mode():
         assert bn.folded()[0] is scale
         x = torch.randn(2, 3, 4, 4)
         assert float((bn.apply_(x, relu=False) - (x * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1))).abs().max()) < 1e-6
+
+
+def test_load_checkpoint_skips_only_what_the_checkpoint_overwrites(tmp_path):
+    """net/weights.load_checkpoint (the start of every step's run(args), reference step/make_cam.py:63-65): the random
+    initialisers are skipped, the loaded network equals the regularly built one, a partial checkpoint keeps a regular
+    initialisation for the rest, and torch.nn.init is left as it was."""
+    import torch.nn.init as init
+    from irn_amd.net import resnet50_cam, weights
+    before = init.kaiming_uniform_
+    path = str(tmp_path / "cam.pth")
+    torch.save(weights.random_cam_state(1), path)
+    fast = weights.load_checkpoint(resnet50_cam.CAM, path, strict=True)
+    ref = resnet50_cam.CAM()
+    ref.load_state_dict(torch.load(path), strict=True)
+    ref.eval()
+    x = torch.randn(2, 3, 48, 64, generator=torch.Generator().manual_seed(0))
+    with torch.no_grad():
+        assert torch.equal(fast(x), ref(x)) and not fast.training
+    sd = torch.load(path)
+    dropped = "classifier.weight"
+    sd.pop(dropped)
+    torch.save(sd, str(tmp_path / "part.pth"))
+    part = weights.load_checkpoint(resnet50_cam.CAM, str(tmp_path / "part.pth"), strict=False)
+    w = part.state_dict()[dropped]
+    assert bool(torch.isfinite(w).all()) and float(w.abs().max()) < 1.0 and float(w.std()) > 1e-4     # a real initialisation
+    assert init.kaiming_uniform_ is before
