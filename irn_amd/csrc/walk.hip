@@ -590,6 +590,7 @@ int irn::walk_schedule(irn_walk_ctx *ctx, int n_sweeps, hipStream_t stream) {
     ctx->sched_coef_f.resize(coef.size());
     for (size_t i = 0; i < coef.size(); ++i) ctx->sched_coef_f[i] = (float)coef[i];
     IRN_HIP_TRY(hipMemcpyAsync(ctx->coef_dev, ctx->sched_coef_f.data(), sizeof(float) * coef.size(), hipMemcpyHostToDevice, stream));
+    IRN_HIP_TRY(hipStreamSynchronize(stream));      // pageable source; a schedule changes once per (n_sweeps, options), not per run
     ctx->sched_coef = coef;
     ctx->sched_steps = steps;
     ctx->sched_cheb = cheb;
@@ -690,9 +691,6 @@ extern "C" int irn_walk_set_option(irn_walk_ctx *ctx, const char *name, int valu
     } else if (!strcmp(name, "accel_tol_exp")) {
         if (value < 4 || value > 12) return fail(IRN_ERR_ARG, "accel_tol_exp must be in [4,12] (truncation bound 10^-value)");
         ctx->accel_tol_exp = value;
-        return IRN_OK;
-    } else if (!strcmp(name, "c1_sync")) {
-        ctx->res_c1_sync = value ? 1 : 0;
         return IRN_OK;
     } else if (!strcmp(name, "cooperative")) {
         ctx->res_cooperative = value ? 1 : 0;

@@ -390,10 +390,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     int *plain_flag = abort_flag + 1;
     const int delay_plain = (poll_delay >> 16) & 0xffff;
     poll_delay &= 0xffff;
-    // bit 1 of `cheb` (option "c1_sync" = 0): single-channel jobs skip the barrier behind the stores; their polling waves then
-    // time the next poll from the barrier in front of the combine (poll_delay has to cover the combine as well)
-    const bool c1_nosync = (cheb & 2) != 0;
-    cheb &= 1;
+
 
     float wr[G::NS][4];
     // poll_delay: units of s_sleep(1) = 64 clocks.  Fixed on purpose: steering the delay
@@ -855,7 +852,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             fresh = false;
             // C = 1: the next poll is timed from our own stores, so every wave has to start its delay
             // behind them (the waves that do not combine would otherwise poll ~0.2 us early)
-            if (C == 1 && !c1_nosync) __syncthreads();
+            if (C == 1) __syncthreads();
             if (PROF && pslot) pslot[3] = wall_clock64();
             t = tn;
             c = cn;
@@ -1042,7 +1039,7 @@ static int launch_resident(irn_walk_ctx *ctx, int t_first, int t_count, int t_to
     long long *prof = ctx->res_prof_dev;
     int delays = ctx->res_poll_delay | (ctx->res_poll_delay_plain << 16);
     const float *coef = ctx->coef_dev;
-    int cheb = (ctx->sched_cheb ? 1 : 0) | (ctx->res_c1_sync ? 0 : 2);
+    int cheb = ctx->sched_cheb ? 1 : 0;
     if (ctx->res_cooperative && !ctx->res_coop_refused) {
         void *args[] = {&imgs, &jobs, &n_rounds, &t_first, &t_count, &t_total, &err, &ticks, &prof, &delays, &votes, &coef, &cheb};
         const hipError_t e = hipLaunchCooperativeKernel((const void *)resident_kernel<R, PROF>, dim3(ctx->res_nwg), dim3(512),
