@@ -692,10 +692,6 @@ extern "C" int irn_walk_set_option(irn_walk_ctx *ctx, const char *name, int valu
         if (value < 4 || value > 12) return fail(IRN_ERR_ARG, "accel_tol_exp must be in [4,12] (truncation bound 10^-value)");
         ctx->accel_tol_exp = value;
         return IRN_OK;
-    } else if (!strcmp(name, "early_stage")) {
-        if (value < 0 || value > 2) return fail(IRN_ERR_ARG, "early_stage must be 0, 1 or 2");
-        ctx->res_early_stage = value;
-        return IRN_OK;
     } else if (!strcmp(name, "cooperative")) {
         ctx->res_cooperative = value ? 1 : 0;
         ctx->res_coop_refused = false;

@@ -107,8 +107,6 @@ struct irn_walk_ctx {
     unsigned *res_err_dev = nullptr;       // [4] time-out diagnostics written by the kernel
     unsigned *res_err_host = nullptr;      // pinned mirror
     long long *res_prof_dev = nullptr;     // [2][256][4] time stamps (option "profile")
-    int res_early_stage = 0;   // polling waves stage the prefetched poll of the next step during the combine: 1 = jobs with >= 3
-                               // channels, 2 = >= 2 channels
     int res_poll_delay = 10;   // s_sleep(1) units (64 clocks): first poll this long after our own stores
     bool res_plain_store = false;          // radius 5: plain state stores for images whose tiles share an XCD (voted in-kernel)
     int res_poll_delay_plain = 2;          // poll delay of such jobs

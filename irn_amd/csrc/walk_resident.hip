@@ -390,10 +390,6 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     int *plain_flag = abort_flag + 1;
     const int delay_plain = (poll_delay >> 16) & 0xffff;
     poll_delay &= 0xffff;
-    // bits 1-2 of `cheb` (option "early_stage"): the polling waves consume the PREFETCHED poll of step k+1 and stage it while
-    // waves 0-3 run the combine of step k (they would idle there), for jobs with >= 3 channels (1) or >= 2 channels (2)
-    const int early_mode = (cheb >> 1) & 3;
-    cheb &= 1;
 
 
     float wr[G::NS][4];
@@ -562,7 +558,6 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         int t = t_first, c = 0;
         bool fresh = true;             // first step of the job: its input has been there since before the launch
         bool polled = false;           // the poll of the current step is already in flight
-        bool staged = false;           // ... and has already been consumed into this step's LDS buffer (early_stage)
 #pragma unroll 1
         for (int k = 0; k < n_steps; ++k) {
             const __amdgpu_buffer_rsrc_t src = state_rsrc(t), dst = state_rsrc(t + 1);
@@ -582,39 +577,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             // just after the neighbours' stores have landed.  Polling early is worse than useless
             // (delay 0: 4.3 us per sweep, delay 20: 2.6 — early loads pull stale lines that the
             // stores must then displace, and a miss costs a whole ~0.85 us round trip).
-            // consume one poll slot into an LDS state buffer: examine what came back, re-poll what is not there yet (bounded)
-            auto stage_poll = [&](float *xdst, __amdgpu_buffer_rsrc_t rs, int soff, unsigned want_tag, int t_err) __attribute__((always_inline)) {
-                unsigned pend = vmask;
-                long long t_start = 0;
-                for (;;) {
-#pragma unroll
-                    for (int kk = 0; kk < NK; ++kk) {
-                        if (((pend >> (2 * kk)) & 1u) && va[kk].y == want_tag) {
-                            xdst[btab[kk] & 0xfff] = __uint_as_float(va[kk].x);
-                            pend &= ~(1u << (2 * kk));
-                        }
-                        if (((pend >> (2 * kk)) & 2u) && va[kk].w == want_tag) {
-                            xdst[(btab[kk] & 0xfff) + 1] = __uint_as_float(va[kk].z);
-                            pend &= ~(2u << (2 * kk));
-                        }
-                    }
-                    if (!__builtin_amdgcn_ballot_w64(pend != 0)) break;
-                    issue(rs, soff);
-                    const long long now = wall_clock64();
-                    if (t_start == 0) t_start = now;
-                    else if (now - t_start > timeout_ticks ||
-                             __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
-                        if (lane == 0 && atomicCAS(err, 0u, 1u) == 0u) {
-                            err[1] = (unsigned)je.x;
-                            err[2] = (unsigned)t_err;
-                            err[3] = blockIdx.x;
-                        }
-                        *abort_flag = 1;
-                        break;
-                    }
-                }
-            };
             if (poller) {
+                unsigned pend = vmask;
+                if (!polled) {
+                    if (!fresh) nap(job_delay);
+                    issue(src, c * ch_bytes);
+                }
                 if (timeout_ticks < 0 && k > 0) {       // test hook (option inject_timeout): give up at the first hand-off
                     if (lane == 0 && atomicCAS(err, 0u, 1u) == 0u) {
                         err[1] = (unsigned)je.x;
@@ -622,12 +590,35 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                         err[3] = blockIdx.x;
                     }
                     *abort_flag = 1;
-                } else if (!staged) {                   // (staged: this step's input went into LDS during the previous combine)
-                    if (!polled) {
-                        if (!fresh) nap(job_delay);
-                        issue(src, c * ch_bytes);
+                    pend = 0;
+                }
+                long long t_start = 0;
+                for (;;) {
+#pragma unroll
+                    for (int kk = 0; kk < NK; ++kk) {
+                        if (((pend >> (2 * kk)) & 1u) && va[kk].y == want) {
+                            xsb[btab[kk] & 0xfff] = __uint_as_float(va[kk].x);
+                            pend &= ~(1u << (2 * kk));
+                        }
+                        if (((pend >> (2 * kk)) & 2u) && va[kk].w == want) {
+                            xsb[(btab[kk] & 0xfff) + 1] = __uint_as_float(va[kk].z);
+                            pend &= ~(2u << (2 * kk));
+                        }
                     }
-                    stage_poll(xsb, src, c * ch_bytes, want, t);
+                    if (!__builtin_amdgcn_ballot_w64(pend != 0)) break;
+                    issue(src, c * ch_bytes);
+                    const long long now = wall_clock64();
+                    if (t_start == 0) t_start = now;
+                    else if (now - t_start > timeout_ticks ||
+                             __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+                        if (lane == 0 && atomicCAS(err, 0u, 1u) == 0u) {
+                            err[1] = (unsigned)je.x;
+                            err[2] = (unsigned)t;
+                            err[3] = blockIdx.x;
+                        }
+                        *abort_flag = 1;
+                        break;
+                    }
                 }
             }
             __syncthreads();
@@ -693,11 +684,6 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 *reinterpret_cast<f4a *>(partf + (k & 1) * (kWaves * 256) + wv * 256 + wl * 4) = f4a{acc[0], acc[1], acc[2], acc[3]};
                 __syncthreads();
                 if (PROF && pslot) pslot[2] = wall_clock64();
-                // the polling waves have nothing to do during the combine: when the next step's poll was prefetched they
-                // consume it now into the other LDS buffer (its last readers, arithmetic and combine of step k-1, are two
-                // barriers back), and the next step starts with its input in place
-                staged = polled && ((early_mode == 1 && C >= 3) || (early_mode == 2 && C >= 2));
-                if (staged && poller) stage_poll(xs + ((k + 1) & 1) * (LH * LW), state_rsrc(tn), cn * ch_bytes, (unsigned)(tn + 1), tn);
                 // One pixel per combining thread, consecutive threads = consecutive pixels of a tile row (their
                 // partial sums are contiguous in LDS).  Neighbouring lanes then swap results and the even lane
                 // stores BOTH granules with one 16-byte store (8-byte sc1 stores are the expensive form, lesson 10;
@@ -1053,7 +1039,7 @@ static int launch_resident(irn_walk_ctx *ctx, int t_first, int t_count, int t_to
     long long *prof = ctx->res_prof_dev;
     int delays = ctx->res_poll_delay | (ctx->res_poll_delay_plain << 16);
     const float *coef = ctx->coef_dev;
-    int cheb = (ctx->sched_cheb ? 1 : 0) | ((ctx->res_early_stage & 3) << 1);
+    int cheb = ctx->sched_cheb ? 1 : 0;
     if (ctx->res_cooperative && !ctx->res_coop_refused) {
         void *args[] = {&imgs, &jobs, &n_rounds, &t_first, &t_count, &t_total, &err, &ticks, &prof, &delays, &votes, &coef, &cheb};
         const hipError_t e = hipLaunchCooperativeKernel((const void *)resident_kernel<R, PROF>, dim3(ctx->res_nwg), dim3(512),

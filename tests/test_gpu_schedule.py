@@ -171,32 +171,3 @@ def test_other_exponents_and_generic_radius():
             st = O.propagate_to_edge_stencil(cam_np, edge_np, r, 10, e)
             assert np.abs(rw.cpu().numpy() - st).max() <= TOL_F64, (r, e)
         wk.close()
-
-
-@pytest.mark.parametrize("r,shapes", [
-    (10, [(128, 128, 1), (128, 128, 2), (128, 128, 3), (94, 125, 5), (64, 64, 55), (128, 128, 2), (40, 52, 9)]),
-    (5, [(128, 128, 1), (128, 128, 2), (94, 125, 3), (130, 66, 14), (128, 128, 4)]),
-])
-def test_early_staging_is_bitwise_equal(r, shapes):
-    """Option early_stage: the polling waves consume the prefetched poll of the next step during the combine instead of at
-    the top of the step — a change of WHEN LDS is written, never of what: bit-identical results for >= 3 channels (1) and
-    >= 2 channels (2), series and plain powers, three times on one workspace."""
-    edges, cams = _inputs(shapes, 1300)
-    base = _walker(r)
-    ref = [o.clone() for o in base(edges, cams, beta=10, exp_times=8)]
-    base.check()
-    ref_plain = [o.clone() for o in base(edges, cams, beta=10, n_sweeps=24)]
-    base.check()
-    for mode in (1, 2):
-        wk = _walker(r, early_stage=mode)
-        for rep in range(3):
-            out = wk(edges, cams, beta=10, exp_times=8)
-            wk.check()
-            for i in range(len(shapes)):
-                assert torch.equal(out[i], ref[i]), (r, mode, rep, shapes[i])
-        out = wk(edges, cams, beta=10, n_sweeps=24)
-        wk.check()
-        for i in range(len(shapes)):
-            assert torch.equal(out[i], ref_plain[i]), (r, mode, shapes[i])
-        wk.close()
-    base.close()
