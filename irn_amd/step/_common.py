@@ -26,6 +26,43 @@ def import_network(dotted):
     return importlib.import_module(_NET_ALIASES.get(dotted, dotted))
 
 
+class ModelSpec:
+    """What a step hands its workers instead of a constructed network: the class and the checkpoint to build it from.
+    The reference pickles the whole model into every spawned process (`spawn(args=(model, ...))`, step/make_cam.py:74);
+    with persistent workers that would be ~270 shared-memory tensors (one file descriptor each) per worker and step.  A
+    worker builds the network itself (`net/weights.load_checkpoint`: memory-mapped file, no random initialisation) and
+    keeps it on its device for later steps that name the same checkpoint — make_sem_seg_labels and make_ins_seg_labels
+    share one EdgeDisplacement."""
+
+    def __init__(self, network, cls_name, path, strict):
+        self.network, self.cls_name, self.path, self.strict = network, cls_name, os.path.abspath(path), bool(strict)
+
+    def key(self):
+        st = os.stat(self.path)
+        return (self.network, self.cls_name, self.path, self.strict, st.st_mtime_ns, st.st_size)
+
+    def build(self):
+        from ..net import weights
+        return weights.load_checkpoint(getattr(import_network(self.network), self.cls_name), self.path, strict=self.strict)
+
+
+_MODELS = {}          # per process: ModelSpec.key() -> network (on this worker's device once a step has used it)
+
+
+def materialise(model):
+    """The network a `_work` function computes with: `model` itself, or the one a ModelSpec describes (cached per process;
+    a checkpoint file that changed on disk is a different key)."""
+    if not isinstance(model, ModelSpec):
+        return model
+    key = model.key()
+    net = _MODELS.get(key)
+    if net is None:
+        for k in [k for k in _MODELS if k[:3] == key[:3]]:      # an older version of the same checkpoint: let it go
+            del _MODELS[k]
+        net = _MODELS[key] = model.build()
+    return net
+
+
 def worker_devices(args=None):
     """Device ordinal of every worker process: one per visible GPU like the reference (`torch.cuda.device_count()`
     shards, step/make_cam.py:67), unless `args.worker_devices` (run_sample.py --worker_devices, or the environment

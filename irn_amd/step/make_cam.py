@@ -20,7 +20,6 @@ import torch
 
 from ..misc import torchutils
 from ..voc12 import dataloader as voc12_dataloader
-from ..net import weights
 from . import _common
 
 
@@ -68,6 +67,7 @@ def _flush_group(model, group, scales, args, writer, store):
 
 
 def _work(process_id, model, dataset, args):
+    model = _common.materialise(model)      # a network, or the (class, checkpoint) a worker builds it from
     databin = dataset[process_id]
     n_gpus = len(dataset)
     loader = _common.make_loader(databin, int(args.num_workers) // n_gpus)
@@ -114,7 +114,7 @@ def _work(process_id, model, dataset, args):
 
 
 def run(args):
-    model = weights.load_checkpoint(getattr(_common.import_network(args.cam_network), "CAM"), args.cam_weights_name + ".pth", strict=True)
+    model = _common.ModelSpec(args.cam_network, "CAM", args.cam_weights_name + ".pth", strict=True)   # built by the worker(s)
     n_gpus = _common.n_gpus_or_raise(args)
     scales = tuple(float(s) for s in args.cam_scales)
     dataset = voc12_dataloader.VOC12ClassificationDatasetMSF(args.train_list, voc12_root=args.voc12_root,

@@ -19,7 +19,6 @@ import torch
 from .. import ops
 from ..misc import indexing
 from ..voc12 import dataloader as voc12_dataloader
-from ..net import weights
 from . import _common, make_sem_seg_labels
 
 RADIUS = 5   # step/make_ins_seg_labels.py:135
@@ -86,6 +85,7 @@ def _flush(model, walker, pend, args, writer, in_flight):
 
 
 def _work(process_id, model, dataset, args):
+    model = _common.materialise(model)      # a network, or the (class, checkpoint) a worker builds it from
     databin = dataset[process_id]
     n_gpus = len(dataset)
     loader = _common.make_loader(databin, int(args.num_workers) // n_gpus)
@@ -118,7 +118,7 @@ def _work(process_id, model, dataset, args):
 
 
 def run(args):
-    model = weights.load_checkpoint(getattr(_common.import_network(args.irn_network), "EdgeDisplacement"), args.irn_weights_name, strict=False)
+    model = _common.ModelSpec(args.irn_network, "EdgeDisplacement", args.irn_weights_name, strict=False)   # built by the worker(s)
     n_gpus = _common.n_gpus_or_raise(args)
     dataset = voc12_dataloader.VOC12ClassificationDatasetMSF(args.infer_list, voc12_root=args.voc12_root,
                                                              scales=(1.0,), raw=_common.device_preprocess(args))

@@ -417,3 +417,23 @@ def test_load_checkpoint_skips_only_what_the_checkpoint_overwrites(tmp_path):
     w = part.state_dict()[dropped]
     assert bool(torch.isfinite(w).all()) and float(w.abs().max()) < 1.0 and float(w.std()) > 1e-4     # a real initialisation
     assert init.kaiming_uniform_ is before
+
+
+def test_model_spec_is_built_once_per_checkpoint_version(tmp_path):
+    """step/_common.ModelSpec: what a step's run(args) hands its (persistent) workers instead of a pickled network — built by
+    the worker on first use, reused by later steps naming the same checkpoint, rebuilt when the file changes."""
+    import os
+    from irn_amd.net import weights
+    from irn_amd.step import _common
+    path = str(tmp_path / "cam.pth")
+    torch.save(weights.random_cam_state(1), path)
+    spec = _common.ModelSpec("net.resnet50_cam", "CAM", path, strict=True)
+    a = _common.materialise(spec)
+    assert _common.materialise(_common.ModelSpec("net.resnet50_cam", "CAM", path, strict=True)) is a     # same key, same object
+    assert _common.materialise(a) is a                                                                   # networks pass through
+    sd = weights.random_cam_state(7)
+    torch.save(sd, path)
+    os.utime(path, ns=(os.stat(path).st_atime_ns, os.stat(path).st_mtime_ns + 10 ** 9))
+    b = _common.materialise(spec)
+    assert b is not a and torch.equal(b.state_dict()["classifier.weight"], sd["classifier.weight"])
+    assert sum(1 for k in _common._MODELS if k[2] == os.path.abspath(path)) == 1                         # the old version was dropped
