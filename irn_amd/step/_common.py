@@ -9,7 +9,6 @@ API is unchanged: `step.X.run(args)` works on its own and returns when every sha
 import atexit
 import importlib
 import os
-import sys
 import traceback
 from concurrent.futures import ThreadPoolExecutor
 
@@ -156,14 +155,14 @@ class WorkerPool:
             except Exception:            # queue.Empty: is everybody still alive?
                 dead = [i for i, p in enumerate(self._procs) if not p.is_alive()]
                 if dead:
+                    codes = [self._procs[i].exitcode for i in dead]
                     self.close(force=True)
-                    raise RuntimeError("step worker(s) %s died without reporting (exit codes %s)" %
-                                       (dead, [self._procs[i].exitcode for i in dead]))
+                    raise RuntimeError("step worker(s) %s died without reporting (exit codes %s)" % (dead, codes))
                 continue
             if status == "error":        # fail fast like spawn(join=True): the other workers are stopped, the error surfaces
                 self.close(force=True)
                 raise RuntimeError("step worker %d failed:\n%s" % (rank, payload))
-            if status == want or (want == "ok" and status == "ok"):
+            if status == want:
                 if payload:
                     self.stats[rank] = payload
                 done += 1

@@ -143,3 +143,21 @@ def test_bench_process_group_falls_back_to_gloo(tmp_path):
     for r in range(2):
         d = np.load(tmp_path / ("f%d.npy" % r), allow_pickle=True).item()
         assert d == {"slowest": 3.0, "backend": "gloo"}
+
+
+def _dying_work(process_id, model, shards, args):
+    if process_id == 0:
+        os._exit(7)                      # a worker that disappears (segfault, OOM kill) instead of raising
+
+
+def test_worker_pool_reports_a_worker_that_dies(tmp_path):
+    from irn_amd.step import _common
+    pool = _common.WorkerPool([-1, -1])
+    try:
+        try:
+            pool.run(_dying_work, None, torchutils.split_dataset(list(range(4)), 2), {})
+            raise AssertionError("a dead worker must raise in the parent")
+        except RuntimeError as e:
+            assert "died without reporting" in str(e) and "7" in str(e)
+    finally:
+        pool.close(force=True)
