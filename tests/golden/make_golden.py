@@ -170,6 +170,13 @@ WALK_BIG_CASES = [
     ("r5_b10_e8_128", 128, 128, 2, 5, 10, 8, 22),
 ]
 
+# ragged grids of real VOC images (500x375 and 334x500 photos -> 94x125 and 84x125 stride-4 grids), the reference's own
+# call-site setting (radius 5, step/make_sem_seg_labels.py:41) and the headline one (radius 10); round 3
+WALK_VOC_CASES = [
+    ("r5_b10_e8_voc", 94, 125, 3, 5, 10, 8, 31),
+    ("r10_b10_e8_voc", 84, 125, 2, 10, 10, 8, 32),
+]
+
 
 def gen_walk(only=None, cases=None, fname="walk.npz"):
     from misc import indexing
@@ -525,6 +532,8 @@ def main():
         gen_walk(only=(sel & walk_names) if sel and not want("walk") else None)
     if sel and "walk128" in sel:                      # never part of the default run (10 minutes)
         gen_walk(cases=WALK_BIG_CASES, fname="walk128.npz")
+    if sel and "walk_voc" in sel:                     # never part of the default run (minutes of dense matmul each)
+        gen_walk(cases=WALK_VOC_CASES, fname="walk_voc.npz")
     if want("semseg"):
         gen_semseg()
     if want("instance"):

@@ -166,6 +166,38 @@ def test_walk_128_vs_reference_golden(golden, variant):
         walker.close()
 
 
+@pytest.mark.parametrize("variant", [2, 1, 0])
+def test_walk_voc_grids_vs_reference_golden(golden, variant):
+    """Ragged grids of real VOC images (94x125 at radius 5, 84x125 at radius 10; tests/golden/walk_voc.npz, the reference's own
+    dense runs): every kernel variant <= 1e-4, identical grid argmax, and the label map through the epilogue against the
+    reference's walk + the oracle's epilogue with every differing pixel checked to be a tie."""
+    from _parity import label_mismatches
+    from irn_amd import ops
+    wk = golden("walk_voc")
+    names = sorted(k[:-3] for k in wk.files if k.endswith("_rw"))
+    assert len(names) == 2
+    for n in names:
+        h, w, c, r, b, e = (int(v) for v in wk[n + "_params"])
+        walker = _walker(r, variant)
+        rw_t = walker([torch.from_numpy(wk[n + "_edge"])[None].to(_dev())], [torch.from_numpy(wk[n + "_cam"]).to(_dev())],
+                      beta=b, exp_times=e)
+        walker.sync()
+        rw = rw_t[0].cpu().numpy()
+        ref = wk[n + "_rw"]
+        assert rw.shape == ref.shape
+        assert np.abs(rw - ref).max() <= TOL_REF, (n, variant, np.abs(rw - ref).max())
+        assert np.array_equal(np.argmax(rw[:, 0], 0), np.argmax(ref[:, 0], 0)), (n, variant)
+        keys = np.arange(c) * 3 + 1
+        size = (4 * h - 1, 4 * w - 3)
+        lab = ops.label_epilogue(rw_t, [size], 0.25, keys=[torch.from_numpy(keys).to(_dev())])["labels"][0].cpu().numpy()
+        up, want, _ = O.sem_seg_epilogue(ref, size, keys, 0.25)
+        n_diff, gap = label_mismatches(lab, want, up, 0.25, lut=np.concatenate([[0], keys + 1]), what=n)
+        print("%s variant %d: max |gpu - reference| %.2e, %d of %d label pixels differ (largest top-2 gap %.2e)" %
+              (n, variant, np.abs(rw - ref).max(), n_diff, lab.size, gap))
+        assert n_diff <= 16
+        walker.close()
+
+
 def test_walk_128_labels_vs_reference_epilogue(golden):
     """Headline config end to end on the reference's numbers: the label map from OUR walk + epilogue equals the label
     map the reference's epilogue (step/make_sem_seg_labels.py:43-49, run by the oracle on the REFERENCE's rw) gives."""

@@ -49,3 +49,24 @@ def test_c_oracle_matches_reference_at_the_headline_grid(golden):
         ref = wk[n + "_rw"]
         assert np.abs(rw - ref).max() <= 1e-4, (n, np.abs(rw - ref).max())
         assert np.array_equal(np.argmax(rw[:, 0], 0), np.argmax(ref[:, 0], 0)), n
+
+
+def test_c_oracle_matches_reference_at_voc_grids(golden):
+    """Ragged grids of real VOC images (94x125 at the reference's call-site radius 5, 84x125 at radius 10), 2^8 sweeps: the
+    reference's own dense run (tests/golden/walk_voc.npz, round 3), and the label map through the reference's epilogue."""
+    from oracle import irn_oracle as O
+    lib = build_oracle.load()
+    wk = golden("walk_voc")
+    names = sorted(k[:-3] for k in wk.files if k.endswith("_rw"))
+    assert len(names) == 2
+    for n in names:
+        h, w, c, r, b, e = (int(v) for v in wk[n + "_params"])
+        rw = build_oracle.walk_batch(lib, [wk[n + "_cam"]], [wk[n + "_edge"]], r, b, 2 ** e)[0]
+        ref = wk[n + "_rw"]
+        assert np.abs(rw - ref).max() <= 1e-4, (n, np.abs(rw - ref).max())
+        assert np.array_equal(np.argmax(rw[:, 0], 0), np.argmax(ref[:, 0], 0)), n
+        keys = np.arange(c) * 3 + 1
+        size = (4 * h - 1, 4 * w - 3)                 # a crop like a 375x497 photo gives
+        _, lab, _ = O.sem_seg_epilogue(rw, size, keys, 0.25)
+        _, want, _ = O.sem_seg_epilogue(ref, size, keys, 0.25)
+        assert (lab != want).sum() <= 4, (n, int((lab != want).sum()))

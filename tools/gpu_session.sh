@@ -1,7 +1,7 @@
 #!/bin/bash
 # One gpurun call of round 3 (results land in gpurun_out/r3_sN/; copy what should be judged into profiles/).
 # usage: tools/gpu_session.sh <N> [what...]
-#   what: tests tests_all testsel bench ab abopt prof pmc pmcsq steps2 default
+#   what: tests tests_all testsel smoke bench default ab abopt prof pmc pmcsq <script under tools/>
 #   env:  TESTSEL="-k expr or paths" (testsel), AB_LIBS="libirn_hip.so other.so", AB_WL="walk coco walk_r5",
 #         AB_OPTS="accel=1 accel=0" (abopt: one bench run per option string; "+" joins several options of one run)
 set -u
@@ -97,9 +97,6 @@ pmcsq)
   cd $R
   python tools/reduce_prof.py $OUT > $OUT/sq_summary.txt 2>&1; grep -E "resident_kernel|affinity_" $OUT/sq_summary.txt | cut -c1-40,96-200
   find $OUT -name "walk_counter_collection.csv" -delete ;;
-steps2)
-  # the step API with two worker processes on GPU 0 (the N > 1 path on a one-GPU box), timed
-  timeout 600 python tools/steps_two_workers.py > $OUT/steps2.log 2>&1; echo "steps2 rc=$?"; tail -8 $OUT/steps2.log ;;
 *)
   # anything else: a script under tools/ taking the output directory
   if [ -f tools/$w ]; then timeout ${RAW_TIMEOUT:-600} python tools/$w $OUT > $OUT/${w%.py}.log 2>&1; echo "$w rc=$?"; tail -${RAW_TAIL:-30} $OUT/${w%.py}.log; else echo "unknown: $w"; fi ;;
