@@ -3,6 +3,11 @@ import sys
 
 import pytest
 
+# two OpenMP runtimes live in the test process (torch's and the C oracle's libgomp): idle threads that spin make each other's
+# parallel regions several times slower on a small host
+os.environ.setdefault("OMP_WAIT_POLICY", "passive")
+os.environ.setdefault("GOMP_SPINCOUNT", "0")
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
