@@ -373,6 +373,7 @@ def make_loader(databin, num_workers, prefetch=4):
     2-3 s per loader on the GPU box (the parent's address space is large) — more than a 1 000-image shard takes."""
     from torch.utils.data import default_collate
     n = len(databin)
+    num_workers = min(int(num_workers), MAX_LOADER_THREADS)     # threads, not processes: more of them only fight over the GIL
     if num_workers <= 0:
         for i in range(n):
             yield default_collate([databin[i]])
@@ -423,6 +424,16 @@ class PinnedPool:
 
 
 PINNED = PinnedPool()
+
+
+def writer_threads(args, n_workers):
+    """Encoder / writer threads of a worker.  Measured on the `steps` leg (128 images, `tools/steps_threads_probe.py`, round 3
+    session 13): 4 loader + 4 writer threads 69.4 images/s, 8 + 8 69.0, 16 + 16 64.4, 32 + 16 56.5 — beyond a handful the
+    threads only contend for the interpreter lock with the thread that drives the GPU."""
+    return 4
+
+
+MAX_LOADER_THREADS = 8      # same measurement: `--num_workers` defaults to half the host's cores (reference run_sample.py:11)
 
 
 class AsyncWriter:

@@ -71,7 +71,7 @@ def _work(process_id, model, dataset, args):
     databin = dataset[process_id]
     n_gpus = len(dataset)
     loader = _common.make_loader(databin, int(args.num_workers) // n_gpus)
-    writer = _common.AsyncWriter()
+    writer = _common.AsyncWriter(threads=_common.writer_threads(args, n_gpus))
     scales = tuple(float(s) for s in args.cam_scales)
     # images per trunk pass (the reference runs batch 2 = one image + flip, step/make_cam.py:32-33); images of one size
     # are stacked per scale — VOC is mostly 500x375 / 375x500 — and every size group is flushed at the end

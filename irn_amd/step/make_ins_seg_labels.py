@@ -90,7 +90,7 @@ def _work(process_id, model, dataset, args):
     n_gpus = len(dataset)
     loader = _common.make_loader(databin, int(args.num_workers) // n_gpus)
     batch = int(getattr(args, "walk_batch", 0) or 32)   # images per walk launch (results per image unchanged)
-    writer = _common.AsyncWriter()
+    writer = _common.AsyncWriter(threads=_common.writer_threads(args, n_gpus))
     try:
         dev_id = _common.worker_device(process_id, args)
         with torch.no_grad(), torch.cuda.device(dev_id):

@@ -98,7 +98,7 @@ def _work(process_id, model, dataset, args):
     n_gpus = len(dataset)
     loader = _common.make_loader(databin, int(args.num_workers) // n_gpus)
     batch = int(getattr(args, "walk_batch", 0) or 64)   # 64 VOC-size images = 3-4 rounds of the resident walk
-    writer = _common.AsyncWriter()
+    writer = _common.AsyncWriter(threads=_common.writer_threads(args, n_gpus))
     try:
         dev_id = _common.worker_device(process_id, args)
         with torch.no_grad(), torch.cuda.device(dev_id):
