@@ -252,6 +252,39 @@ def test_steps_two_worker_processes_on_one_device(tmp_path):
     assert ins_diff <= 0.01 * n_px
 
 
+def test_run_sample_cli_end_to_end(tmp_path):
+    """`python run_sample.py ...` itself (reference run_sample.py:8-137): an existing command line of the reference — its
+    training / CRF hyper-parameter flags included — runs the three label-generation passes and writes every output."""
+    import sys
+    import run_sample
+    from irn_amd.misc import pyutils
+    from irn_amd.net import weights
+    root, names, labels = _make_voc(tmp_path, n=2)
+    torch.save(weights.random_cam_state(1), tmp_path / "res50_cam.pth")
+    torch.save(weights.random_irn_state(2), tmp_path / "res50_irn.pth")
+    lst = str(tmp_path / "lists" / "train.txt")
+    stdout = sys.stdout
+    try:
+        run_sample.main(["--voc12_root", str(root), "--train_list", lst, "--infer_list", lst, "--num_workers", "2",
+                         "--cam_weights_name", str(tmp_path / "res50_cam"), "--irn_weights_name", str(tmp_path / "res50_irn.pth"),
+                         "--cam_out_dir", str(tmp_path / "cam"), "--sem_seg_out_dir", str(tmp_path / "sem"),
+                         "--ins_seg_out_dir", str(tmp_path / "ins"), "--ir_label_out_dir", str(tmp_path / "ir"),
+                         "--log_name", str(tmp_path / "log"), "--cam_scales", "1.0", "0.5",
+                         "--cam_learning_rate", "0.05", "--irn_batch_size", "16", "--conf_fg_thres", "0.3", "--beta", "10",
+                         "--exp_times", "8", "--train_cam_pass", "False", "--eval_cam_pass", "False"])
+    finally:
+        if isinstance(sys.stdout, pyutils.Logger):
+            sys.stdout.close()
+        sys.stdout = stdout
+    for n in names:
+        assert os.path.exists(tmp_path / "cam" / (n + ".npy")) and os.path.exists(tmp_path / "sem" / (n + ".png"))
+        W, H = Image.open(root / "JPEGImages" / (n + ".jpg")).size
+        assert np.asarray(Image.open(tmp_path / "sem" / (n + ".png"))).shape == (H, W)
+    assert any(os.path.exists(tmp_path / "ins" / (n + ".npy")) for n in names)
+    with pytest.raises(SystemExit):                      # a pass this build does not implement refuses loudly
+        run_sample.main(["--voc12_root", str(root), "--train_irn_pass", "True", "--log_name", str(tmp_path / "log2")])
+
+
 def test_cam_merge_kernel_vs_oracle_and_reference_golden(golden):
     """irn_cam_merge (step/make_cam.py:38-52) bit for bit against the oracle's restatement, against the
     reference's own output (1e-6; bar 1e-4) and against the torch-op mirror on the GPU."""
