@@ -580,11 +580,8 @@ def main(argv=None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
-    # IRN_BENCH_FORCE_DEVICE: every rank on this one device — lets a one-GPU box exercise the N > 1 launch path (RCCL then
-    # refuses two ranks on one GPU and the group falls back to gloo); never set by the driver
-    dev_index = int(os.environ.get("IRN_BENCH_FORCE_DEVICE", local_rank))
-    torch.cuda.set_device(dev_index)
-    device = torch.device("cuda", dev_index)
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
     from irn_amd import parallel
     # nccl == RCCL on ROCm.  The data path has no collective — the group only serves the contract's barrier and
     # max-over-ranks — so a failing RCCL start-up must not cost the line: `auto` falls back to gloo and says so
