@@ -1,6 +1,6 @@
 // Weights-stationary persistent random walk (gfx950) — "variant 2" of irn_walk_run.
 //
-// The transition operator of an image is the same in every one of the 2^exp_times sweeps
+// The transition operator of an image is the same in every application of the walk
 // (reference misc/indexing.py:136-137 squares ONE matrix).  The streaming sweeps of walk.hip re-read
 // its |S| weight planes from HBM every sweep (4*|S|*N bytes: the HBM roofline of SURVEY.md §8d).
 // This kernel reads them ONCE per image: every workgroup keeps the 2|S| directed weights of its
@@ -15,12 +15,12 @@
 //     neighbours x 4 px = 152 weight registers per lane; radius 5: Q = 2 x 34, four slabs per
 //     workgroup).  Each wave's part of the disc is a different, fully expanded instruction stream
 //     (wave-uniform switch), so every weight has a fixed register;
-//   * a step = (sweep t, channel c), c fastest.  Waves 4-7 poll and stage x_t[c] of the tile + halo into
-//     LDS (double-buffered); every wave forms, per neighbour row, an fp32 FMA chain (<= 19 terms) over
-//     a register window of the staged state and folds it into fp64; the Q partial sums of a pixel meet
-//     in LDS; waves 0-3 add the centre term, multiply by 1/deg in fp64 and store x_{t+1}[c] (same
-//     numerics contract as walk.hip).  Channels are independent chains: with C >= 2 the poll of the
-//     next step flies during the arithmetic of this one.
+//   * a step = (operator application t, channel c), c fastest.  Waves 4-7 poll and stage y_t[c] of the tile + halo into
+//     LDS (double-buffered); every wave runs ONE fp32 FMA chain per pixel over its part of the disc (38 terms at radius
+//     10), reading the staged state through 16-byte-aligned register windows; the Q chains of a pixel meet in LDS; waves
+//     0-3 add them pairwise in fp32, add the centre term and multiply by 1/deg in fp64, apply the recurrence of the
+//     schedule (below) and store y_{t+1}[c] (numerics: tests/test_precision_model.py).  Channels are
+//     independent chains: with C >= 2 the poll of the next step flies during the arithmetic of this one.
 //
 // Exchange between workgroups (tiles of one image; no kernel boundary between sweeps)
 //   state buffers hold one 8-byte granule {tag = sweep + 1, fp32 value} per pixel and channel, written
