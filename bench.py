@@ -75,7 +75,13 @@ def parse(argv=None):
                     help="grid sizes at which the reference's dense algorithm is timed on the host (the last one is reported; 128 = "
                          "the workload's own grid, ~3 minutes of CPU; '64' alone = quick runs, extrapolated)")
     ap.add_argument("--backend", default="auto", help="process group of the barrier / max-over-ranks: nccl (= RCCL), gloo, or auto = "
-                                                      "nccl with a fall-back to gloo (the data path has no collective)")
+                                                      "RCCL when every rank's start-up probe completes inside its deadline, else gloo "
+                                                      "(the data path has no collective; irn_amd/parallel.py)")
+    ap.add_argument("--rank-devices", default="", metavar="D0,D1,...",
+                    help="device ordinal of every local rank (default: LOCAL_RANK).  '0,0' = two ranks sharing GPU 0: the N > 1 path "
+                         "on a one-GPU box (RCCL needs one device per rank, so `auto` then uses gloo)")
+    ap.add_argument("--launch-timeout-s", type=float, default=0.0,
+                    help="self-launched N > 1 runs: kill the launcher's process group after this many seconds (0 = no limit)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-legs", action="store_true", help="skip the short secondary runs (cam, e2e, steps, walk_r5, ins, coco)")
     ap.add_argument("--legs", default="walk_r5,walk_plain,ins,ins_r10,coco,cam,e2e,steps")
@@ -162,6 +168,12 @@ def cpu_baseline(a, workload, n_images, seed0, gpu_labels=None):
     res = {"value": n_images / dt, "unit": "images/s", "cores": threads, "kind": "port",
            "sample": "%d images of the same workload (walk only: oracle/walk_oracle.c irn_oracle_walk_batch, fp64 stencil port of "
                      "misc/indexing.py:141-165, one image per OpenMP thread, rows vectorised; %.1f s)" % (n_images, dt)}
+    res["which_is_which"] = {
+        "value": "kind 'port': the SAME stencil algorithm the GPU runs, restated for the CPU (oracle/walk_oracle.c, fp64, plain "
+                 "2^exp_times iteration) - the fair-algorithm baseline the >= 50x target is checked against",
+        "reference_algorithm.value": "the north star's 'reference PyTorch CPU path': the reference's own dense algorithm "
+                                     "(misc/indexing.py:91-165 restated op for op on torch CPU tensors, oracle/dense_ref.py, pinned "
+                                     "bit-for-bit on outputs of /root/reference), timed in full at the workload's grid"}
     if gpu_labels:
         # by-product: the label maps the GPU wrote in the timed run against the port's walk + the oracle's epilogue
         # (step/make_sem_seg_labels.py:43-49) for the first images of the batch — measured, not a tolerance
@@ -404,15 +416,17 @@ def run_backbone(a, workload, rank, world, device, dist, parallel, steps, warmup
 
 
 def run_steps(a, rank, world, device, dist, parallel, steps, warmup, batch=0):
-    """The drop-in step API itself (run_sample.py's make_cam -> make_sem_seg_labels on a synthetic VOC-shaped directory
-    of 512x512 JPEGs, random-init checkpoints): DataLoader + JPEG decode, multi-scale CAM, CAM hand-off, IRNet, walk
-    (args.radius 10 = configs[2]), PNG writing.  One "step" = the two passes over `batch` images."""
+    """The drop-in step API itself, in run_sample.py's order (reference run_sample.py:91-131): make_cam.run(args) ->
+    make_ins_seg_labels.run(args) -> make_sem_seg_labels.run(args) on a synthetic VOC-shaped directory of 512x512 JPEGs
+    with random-init checkpoints: DataLoader + JPEG decode, multi-scale CAM, CAM hand-off, IRNet, walk, detections, PNG /
+    .npy writing.  The semantic step walks at radius 10 (= BASELINE configs[2]), the instance step at the reference's own
+    radius 5 (step/make_ins_seg_labels.py:135).  One "step" = the three passes over `batch` images."""
     import shutil
     import tempfile
     from PIL import Image
     from irn_amd import synth
     from irn_amd.net import weights
-    from irn_amd.step import _common, make_cam, make_sem_seg_labels
+    from irn_amd.step import _common, make_cam, make_ins_seg_labels, make_sem_seg_labels
     os.environ.setdefault("MIOPEN_FIND_MODE", "2")
     batch = batch or 32
     t_setup = time.perf_counter()
@@ -439,9 +453,10 @@ def run_steps(a, rank, world, device, dist, parallel, steps, warmup, batch=0):
             infer_list=os.path.join(tmp, "train.txt"), cam_network="net.resnet50_cam",
             cam_weights_name=os.path.join(tmp, "res50_cam"), cam_scales=(1.0, 0.5, 1.5, 2.0), irn_network="net.resnet50_irn",
             irn_weights_name=os.path.join(tmp, "res50_irn.pth"), beta=10, exp_times=8, sem_seg_bg_thres=0.25,
-            cam_out_dir=os.path.join(tmp, "cam"), sem_seg_out_dir=os.path.join(tmp, "sem"), radius=10, walk_batch=64)
-        os.makedirs(args.cam_out_dir)
-        os.makedirs(args.sem_seg_out_dir)
+            ins_seg_bg_thres=0.25, cam_out_dir=os.path.join(tmp, "cam"), sem_seg_out_dir=os.path.join(tmp, "sem"),
+            ins_seg_out_dir=os.path.join(tmp, "ins"), radius=10, walk_batch=64)
+        for d in (args.cam_out_dir, args.sem_seg_out_dir, args.ins_seg_out_dir):
+            os.makedirs(d)
         # the steps shard over the visible GPUs by themselves (one worker process per GPU); inside a torch.distributed job
         # every rank must stay on its own device, so each rank runs the steps with a one-entry device list (in-process)
         args.worker_devices = str(device.index or 0)
@@ -453,7 +468,7 @@ def run_steps(a, rank, world, device, dist, parallel, steps, warmup, batch=0):
             def flush(self):
                 pass
 
-        pass_s = {"make_cam": 0.0, "make_sem_seg_labels": 0.0}
+        passes = []
 
         def step():
             real = sys.stdout
@@ -463,8 +478,13 @@ def run_steps(a, rank, world, device, dist, parallel, steps, warmup, batch=0):
                 t0 = time.perf_counter()
                 make_cam.run(args)
                 t1 = time.perf_counter()
+                args.radius, args.walk_batch = 5, 32       # the reference's instance call site
+                make_ins_seg_labels.run(args)
+                t2 = time.perf_counter()
+                args.radius, args.walk_batch = 10, 64      # configs[2]
                 make_sem_seg_labels.run(args)
-                pass_s["make_cam"], pass_s["make_sem_seg_labels"] = t1 - t0, time.perf_counter() - t1
+                t3 = time.perf_counter()
+                passes.append({"make_cam": t1 - t0, "make_ins_seg_labels": t2 - t1, "make_sem_seg_labels": t3 - t2})
             finally:
                 sys.stdout = real
 
@@ -472,12 +492,14 @@ def run_steps(a, rank, world, device, dist, parallel, steps, warmup, batch=0):
         hits0, misses0 = _common.CAM_STORE.hits, _common.CAM_STORE.misses
         elapsed, _ = timed_loop(step, steps, warmup, dist, parallel, device)
         n_png = len([f for f in os.listdir(args.sem_seg_out_dir) if f.endswith(".png")])
+        n_ins = len([f for f in os.listdir(args.ins_seg_out_dir) if f.endswith(".npy")])
         if n_png != batch:
             raise RuntimeError("steps leg: %d label maps written for %d images" % (n_png, batch))
         return {"value": steps * batch * world / elapsed, "ms_per_step": 1e3 * elapsed / steps, "batch": batch,
                 "cam_store_hits": _common.CAM_STORE.hits - hits0, "cam_store_misses": _common.CAM_STORE.misses - misses0,
-                "loader_workers": args.num_workers, "through": "make_cam.run(args) + make_sem_seg_labels.run(args)",
-                "last_pass_seconds": dict(pass_s), "setup_seconds": t_setup}
+                "loader_workers": args.num_workers, "instance_files": n_ins,
+                "through": "make_cam.run(args) + make_ins_seg_labels.run(args) + make_sem_seg_labels.run(args)",
+                "pass_seconds": [{k: round(v, 3) for k, v in p.items()} for p in passes[warmup:]], "setup_seconds": t_setup}
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
 
@@ -496,8 +518,8 @@ def describe(workload, r):
                 "host; edge / displacement / CAM tensors resident in HBM" %
                 (r["out_hw"][0], r["out_hw"][1], r["h"], r["w"], r["radius"], r["beta"], r["exp_times"]))
     if workload == "steps":
-        return ("steps: run_sample.py step API (make_cam -> make_sem_seg_labels, radius 10) on a synthetic VOC directory of "
-                "512x512 JPEGs, random-init checkpoints, files written")
+        return ("steps: run_sample.py step API (make_cam -> make_ins_seg_labels at radius 5 -> make_sem_seg_labels at radius 10) "
+                "on a synthetic VOC directory of 512x512 JPEGs, random-init checkpoints, files written")
     return ("%s: synthetic 512x512 uint8 images resident in HBM, multi-scale inputs built on the GPU (irn_msf_pack), ResNet-50 CAM "
             "at scales %s + flip (random-init weights, fp32, MIOpen)%s" %
             (workload, r.get("scales"), "" if workload == "cam" else "; EdgeDisplacement forward; walk radius 10 beta 10 2^8; label epilogue"))
@@ -514,8 +536,8 @@ def run_workload(a, workload, rank, world, device, dist, parallel, steps, warmup
 
 
 LEG_RUNS = {   # short runs for the `legs` object of the default line: (steps, warmup, batch)
-    "cam": (8, 1, 8), "e2e": (8, 1, 8), "steps": (1, 1, 128), "walk_r5": (3, 1, 256), "walk_plain": (3, 1, 192),
-    "ins": (8, 2, 64), "ins_r10": (6, 2, 64), "coco": (3, 1, 2),
+    "cam": (12, 1, 8), "e2e": (12, 1, 8), "steps": (2, 1, 256), "walk_r5": (10, 2, 256), "walk_plain": (4, 1, 192),
+    "ins": (10, 2, 64), "ins_r10": (8, 2, 64), "coco": (10, 2, 2),
 }
 
 
@@ -573,19 +595,61 @@ def roofline_object(a, workload, r):
     return top
 
 
+def self_launch(a, argv):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: start the N ranks ourselves, exactly the way the
+    driver does (`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P
+    bench.py <same arguments>`), pass rank 0's JSON line through and return the launcher's exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC: what RCCL needs on these hosts
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // a.gpus)))
+    proc = subprocess.Popen(cmd, env=env, start_new_session=True)
+    try:
+        return proc.wait(timeout=a.launch_timeout_s if a.launch_timeout_s > 0 else None)
+    except subprocess.TimeoutExpired:
+        import signal
+        os.killpg(proc.pid, signal.SIGKILL)              # exactly the process group started above
+        proc.wait()
+        print("bench.py: the %d-rank run did not finish within %.0f s and was killed" % (a.gpus, a.launch_timeout_s), file=sys.stderr)
+        return 124
+    except KeyboardInterrupt:
+        import signal
+        os.killpg(proc.pid, signal.SIGTERM)
+        raise
+
+
 def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
     a = parse(argv)
+    if a.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        raise SystemExit(self_launch(a, argv))            # N ranks, one per GPU; this process only waits for them
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != a.gpus:
+        # the line's n_gpus is the world that ran; a launcher and a --gpus that disagree would mislabel it
+        raise SystemExit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks" % (a.gpus, world))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
     from irn_amd import parallel
+    ordinal = parallel.rank_device_ordinal(local_rank, a.rank_devices)
+    if ordinal >= torch.cuda.device_count():
+        raise SystemExit("bench.py: rank %d wants device %d, %d visible (--rank-devices maps ranks to devices, e.g. 0,0)" %
+                         (rank, ordinal, torch.cuda.device_count()))
+    torch.cuda.set_device(ordinal)
+    device = torch.device("cuda", ordinal)
     # nccl == RCCL on ROCm.  The data path has no collective — the group only serves the contract's barrier and
-    # max-over-ranks — so a failing RCCL start-up must not cost the line: `auto` falls back to gloo and says so
-    dist, backend_used = parallel.init_process_group_with_fallback(a.backend, device)
+    # max-over-ranks — so an RCCL start-up that fails or hangs must not cost the line: `auto` probes it under a deadline,
+    # the ranks agree over a gloo control group, and the line says which backend served it
+    dist, backend_used = parallel.init_process_group_with_fallback(a.backend, device, rank_devices=a.rank_devices)
 
     r = run_workload(a, a.workload, rank, world, device, dist, parallel, a.steps, a.warmup, a.batch)
     if rank == 0:
@@ -594,7 +658,7 @@ def main(argv=None):
                  "coco": "random-walk label generation stage, COCO shape", "ins": "instance label generation stage",
                  "ins_r10": "instance label generation stage, radius 10",
                  "cam": "multi-scale CAM inference stage", "e2e": "CAM + IRNet + walk + labels, end to end",
-                 "steps": "run_sample.py step API, make_cam + make_sem_seg_labels"}[a.workload]
+                 "steps": "run_sample.py step API, make_cam + make_ins_seg_labels + make_sem_seg_labels"}[a.workload]
         res = {
             "metric": "%s (%s)" % (METRIC, stage),
             "value": r["value"], "unit": "images/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
@@ -603,13 +667,15 @@ def main(argv=None):
             "config": {"workload": describe(a.workload, r), "images_per_gpu_per_step": r["batch"],
                        "sharding": "images strided over ranks, no collective",
                        "process_group": {"backend": backend_used, "ranks": world,
+                                         "devices": (a.rank_devices or "one per rank (LOCAL_RANK)"),
+                                         "note": getattr(dist, "note", None),
                                          "used_for": "barrier + max-over-ranks of the timed region only"}},
             "roofline": roofline_object(a, a.workload, r),
         }
         if "shapes" in r:
             res["config"].update({"variant": a.variant, "mean_channels": float(np.mean([s[2] for s in r["shapes"]]))})
             res["label_checksum"] = r["label_checksum"]
-        for k in ("detections_per_image", "fallback_runs", "cam_store_hits", "cam_store_misses", "loader_workers", "last_pass_seconds", "through"):
+        for k in ("detections_per_image", "fallback_runs", "cam_store_hits", "cam_store_misses", "loader_workers", "pass_seconds", "instance_files", "through"):
             if k in r:
                 res["config"][k] = r[k]
         res["cpu_baseline"] = None
@@ -633,7 +699,7 @@ def main(argv=None):
                     if "shapes" in lr:
                         ro = roofline_object(a, name, lr)
                         legs[name]["fp32_vector_frac"] = ro["frac"] if ro.get("bound") == "fp32_vector" else ro["fp32_vector"]["frac"]
-                    for k in ("detections_per_image", "cam_store_hits", "cam_store_misses", "loader_workers", "last_pass_seconds", "setup_seconds", "through", "n_applied"):
+                    for k in ("detections_per_image", "cam_store_hits", "cam_store_misses", "loader_workers", "pass_seconds", "instance_files", "setup_seconds", "through", "n_applied"):
                         if k in lr:
                             legs[name][k] = lr[k]
                 except Exception as e:                      # a leg must never cost the headline line
@@ -647,7 +713,12 @@ def main(argv=None):
             with open(a.json_out, "w") as f:
                 f.write(line + "\n")
     if dist:
-        dist.destroy_process_group()
+        stuck = getattr(dist, "stuck", False)
+        dist.close()
+        if stuck:                      # an RCCL probe thread that never returned would block interpreter shutdown
+            sys.stdout.flush()
+            sys.stderr.flush()
+            os._exit(0)
 
 
 if __name__ == "__main__":
