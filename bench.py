@@ -284,6 +284,8 @@ def run_walk(a, workload, rank, world, device, dist, parallel, steps, warmup, ba
     walker.set_option("merged", a.merged)
     walker.set_option("probe", a.probe)
     walker.set_option("accel", 0 if workload == "walk_plain" else a.accel)
+    if warmup == 0:
+        walker.set_option("poll_delay_auto", 0)          # no untimed step for the start-up probe to run in (profiler passes)
     for kv in a.walk_option:
         name, value = kv.split("=")
         walker.set_option(name, int(value))
@@ -302,6 +304,7 @@ def run_walk(a, workload, rank, world, device, dist, parallel, steps, warmup, ba
     n_sweeps = 2 ** exp_times
     n_applied = walker.steps(n_sweeps)                     # operator applications the schedule spends on T^n_sweeps
     head = [(labels[i].cpu().numpy(), keys[i].cpu().numpy()) for i in range(min(8, n_unique))]   # for cpu_baseline.label_parity
+    tuning = walker.tuning()
     walker.close()
     n_dirs = N_DIRS[radius]
     avg_sweep_ms = sweep_ms / max(sweep_launches, 1)
@@ -316,7 +319,7 @@ def run_walk(a, workload, rank, world, device, dist, parallel, steps, warmup, ba
             "avg_launch_ms": avg_launch_ms, "sweeps_per_launch": sweeps_per_launch, "n_applied": n_applied, "n_sweeps": n_sweeps,
             "launches_timed": sweep_launches // max(sweeps_per_launch, 1), "flops_per_launch": flops_per_launch,
             "bytes_per_launch": bytes_per_launch, "sweep_share_of_step": sweep_ms / (1e3 * elapsed),
-            "label_checksum": checksum, "head_labels": head}
+            "label_checksum": checksum, "head_labels": head, "tuning": tuning}
 
 
 def run_ins(a, workload, rank, world, device, dist, parallel, steps, warmup, batch=0):
@@ -673,7 +676,8 @@ def main(argv=None):
             "roofline": roofline_object(a, a.workload, r),
         }
         if "shapes" in r:
-            res["config"].update({"variant": a.variant, "mean_channels": float(np.mean([s[2] for s in r["shapes"]]))})
+            res["config"].update({"variant": a.variant, "mean_channels": float(np.mean([s[2] for s in r["shapes"]])),
+                                  "walk_self_checks": r.get("tuning")})
             res["label_checksum"] = r["label_checksum"]
         for k in ("detections_per_image", "fallback_runs", "cam_store_hits", "cam_store_misses", "loader_workers", "pass_seconds", "instance_files", "through"):
             if k in r:

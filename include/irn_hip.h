@@ -119,7 +119,7 @@ int irn_walk_run(irn_walk_ctx *ctx, const float *const *edge_dev, const float *c
  * operator applications instead of n (84 instead of 256 at exp_times = 8), accumulating s = sum_k c_k y_k.  Measured
  * against the fp64 oracle the result is as close as that of the plain iteration (tests/test_gpu_schedule.py).
  *   option "accel" = 1 (default) / 0: truncated Chebyshev series / plain powers (n applications, bit-identical to the
- *   recurrence-free kernels of rounds 1-2); "accel_tol_exp" = e: tol = 10^-e (default 7).
+ *   recurrence-free kernels of rounds 1-2); "accel_tol_exp" = e: tol = 10^-e (default 6: 78 applications for n = 256; 7: 84).
  *   irn_walk_steps reports the operator applications a run with `n_sweeps` would execute (for flop accounting).
  * The caller's edge / cam / inst_map device buffers must stay valid and unmodified until irn_walk_sync (or the next
  * irn_walk_run) returns: a run that irn_walk_sync has to repeat reads them again. */
@@ -150,6 +150,17 @@ int irn_walk_set_option(irn_walk_ctx *ctx, const char *name, int value);
 int irn_walk_sync(irn_walk_ctx *ctx, int *fell_back);
 int irn_walk_check(irn_walk_ctx *ctx);
 int irn_walk_fallback_runs(irn_walk_ctx *ctx);
+
+/* Start-up self-checks of the weights-stationary walk's two measured assumptions (speed only, never results; the
+ * reference has no counterpart — its walk is dense sgemm, misc/indexing.py:132-139):
+ *   placement   0 not checked yet, 1 "block b of a launch runs on XCD b % 8" holds on this device (the tiles of an image are
+ *               then packed onto one XCD), 2 it does not (tiles keep launch order; one line on stderr says so);
+ *   poll_delay  the delay (units of 64 clocks) between a single-channel tile's stores and its first poll in use now;
+ *   probe_ms3   launch times in ms the start-up probe measured for delays 8, 10, 12 on this context's first representative
+ *               batch (zeros: this context did not probe — too small a batch, another context of the process probed
+ *               before, or option "poll_delay" pinned the value; "poll_delay_auto" = 0 switches the probe off).
+ * Any pointer may be null. */
+int irn_walk_tuning(irn_walk_ctx *ctx, int *poll_delay, int *placement, float *probe_ms3);
 
 /* Diagnostic (option "profile" = 1, resident walk only): per-sweep time stamps of two workgroups of
  * the first round — host_out is int64 [2][256][4] = {sweep start, state staged, first partial sums

@@ -685,6 +685,11 @@ extern "C" int irn_walk_set_option(irn_walk_ctx *ctx, const char *name, int valu
     } else if (!strcmp(name, "poll_delay")) {
         if (value < 0 || value > 1000) return fail(IRN_ERR_ARG, "poll_delay must be in [0,1000]");
         ctx->res_poll_delay = value;
+        ctx->res_poll_auto = 0;                         // pinned by the caller: no start-up probe
+        return IRN_OK;
+    } else if (!strcmp(name, "poll_delay_auto")) {
+        ctx->res_poll_auto = value ? 1 : 0;
+        return IRN_OK;
     } else if (!strcmp(name, "accel")) {
         ctx->accel = value ? 1 : 0;
         return IRN_OK;                                  // the schedule is rebuilt by the next run; no re-configure
@@ -1128,6 +1133,15 @@ extern "C" int irn_walk_sync(irn_walk_ctx *ctx, int *fell_back) {
 }
 
 extern "C" int irn_walk_fallback_runs(irn_walk_ctx *ctx) { return ctx ? ctx->fallback_runs : 0; }
+
+extern "C" int irn_walk_tuning(irn_walk_ctx *ctx, int *poll_delay, int *placement, float *probe_ms3) {
+    if (!ctx) return fail(IRN_ERR_ARG, "irn_walk_tuning: null ctx");
+    if (poll_delay) *poll_delay = ctx->res_poll_delay;
+    if (placement) *placement = ctx->res_placement;
+    if (probe_ms3)
+        for (int k = 0; k < 3; ++k) probe_ms3[k] = ctx->res_poll_probe_ms[k];
+    return IRN_OK;
+}
 
 extern "C" int irn_walk_read_profile(irn_walk_ctx *ctx, long long *host_out) {
     if (!ctx || !host_out) return fail(IRN_ERR_ARG, "null argument");

@@ -108,6 +108,9 @@ struct irn_walk_ctx {
     unsigned *res_err_host = nullptr;      // pinned mirror
     long long *res_prof_dev = nullptr;     // [2][256][4] time stamps (option "profile")
     int res_poll_delay = 10;   // s_sleep(1) units (64 clocks): first poll this long after our own stores
+    int res_poll_auto = 1;     // 1: the first representative batch of the process probes 8 / 10 / 12 (walk_resident.hip); 0: pinned
+    float res_poll_probe_ms[3] = {0.f, 0.f, 0.f};   // launch times the probe measured for delays 8, 10, 12 (0 = not probed by this context)
+    int res_placement = 0;     // block -> XCD round robin: 0 not checked, 1 holds, 2 does not (resident_check_placement)
     bool res_plain_store = false;          // radius 5: plain state stores for images whose tiles share an XCD (voted in-kernel)
     int res_poll_delay_plain = 2;          // poll delay of such jobs
     unsigned long long *res_votes_dev = nullptr;   // [n] per-image XCD vote words
@@ -127,7 +130,8 @@ struct irn_walk_ctx {
     int fallback_runs = 0;                 // batches re-run on the streaming sweeps after a resident time-out
     // polynomial schedule of the walk (walk.hip: irn::walk_schedule)
     int accel = 1;                         // 1: T^n as a truncated Chebyshev series when that needs fewer operator applications
-    int accel_tol_exp = 7;                 // truncation bound 10^-accel_tol_exp on the series' dropped coefficients
+    int accel_tol_exp = 6;                 // truncation bound 10^-accel_tol_exp on the series' dropped coefficients (round 4: 6 = 78 applications
+                                           // for n = 256; measured 2.8e-6 from the fp64 oracle, 0 label flips: profiles/r03_s5_series_tolerance.txt)
     int sched_n = -1, sched_accel = -1, sched_tol = -1;   // what coef_dev currently holds
     int sched_steps = 0;                   // operator applications of the schedule
     bool sched_cheb = false;               // three-term recurrence (else plain powers)

@@ -66,11 +66,16 @@ template <>
 struct RCfg<10> {
     static constexpr int Q = 8, SL_Y = 1, SL_X = 1;
     static constexpr bool PREFETCH_ROWS = true;     // read the next neighbour row's window ahead of this row's FMAs
+    static constexpr bool PROLOGUE_OVERLAP = false; // (see the job prologue: spills at this radius)
 };
 template <>
 struct RCfg<5> {
     static constexpr int Q = 2, SL_Y = 2, SL_X = 2;
     static constexpr bool PREFETCH_ROWS = true;     // fits since the fp32 chains freed the fp64 accumulators (250 VGPRs)
+#ifndef IRN_R5_PROLOGUE_OVERLAP
+#define IRN_R5_PROLOGUE_OVERLAP 1
+#endif
+    static constexpr bool PROLOGUE_OVERLAP = IRN_R5_PROLOGUE_OVERLAP != 0;   // LDS fill under the weight loads
 };
 
 // The neighbour disc (dy,dx) != (0,0), dx^2 + dy^2 < R^2, in raster order: the union of the
@@ -358,6 +363,11 @@ __global__ __launch_bounds__(256) void x0_granule_kernel(const WalkImg *__restri
     }
 }
 
+// Which XCD does block b run on?  (start-up self-check of the slot -> block mapping, resident_check_placement)
+__global__ __launch_bounds__(64) void xcc_probe_kernel(unsigned char *__restrict__ out) {
+    if (threadIdx.x == 0) out[blockIdx.x] = (unsigned char)((unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 20) & 7u);   // HW_REG_XCC_ID
+}
+
 // PROF: per-step time stamps for tools/resident_profile.py (its own instantiation: the stamp pointer would
 // cost the production kernel two live VGPRs per lane, and it sits exactly at the 256-register limit)
 template <int R, bool PROF>
@@ -439,6 +449,54 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         }
 
         double dsum[4];
+        if constexpr (RCfg<R>::PROLOGUE_OVERLAP) {
+            // The weight loads (~7.5 us per job from HBM) are issued first; the part of the prologue that does not need
+            // them — the LDS clear, the carried terms — runs under their latency instead of behind the degree (1.2 us of a
+            // 9.4 us prologue, profiles/r03_s4_resident_step_profile.txt).  Radius 5 only: at radius 10 keeping all 152
+            // weight registers in flight across that code costs two spilled registers that are reloaded inside the step loop.
+#define IRN_LOAD_W(QI) load_weights<R, (QI) % Q>(wr, I, gy, gx)
+            switch (qi) {
+                case 0: IRN_LOAD_W(0); break;
+                case 1: IRN_LOAD_W(1); break;
+                case 2: IRN_LOAD_W(2); break;
+                case 3: IRN_LOAD_W(3); break;
+                case 4: IRN_LOAD_W(4); break;
+                case 5: IRN_LOAD_W(5); break;
+                case 6: IRN_LOAD_W(6); break;
+                default: IRN_LOAD_W(7); break;
+            }
+#undef IRN_LOAD_W
+            __syncthreads();   // previous job's readers of part / invd / xs / psl are done
+            for (int i = tid; i < 2 * LH * LW; i += 512) xs[i] = 0.f;
+            {
+                const __amdgpu_buffer_rsrc_t prs0 =
+                    __builtin_amdgcn_make_buffer_rsrc((void *)I.xc, 0, (int)(8u * n * (unsigned)I.C), 0x00020000);
+                const int c_lds0 = cheb ? (I.C < G::CAPC ? I.C : G::CAPC) : 0;
+                for (int idx = tid; idx < c_lds0 * G::TPX; idx += 512) {
+                    const int cc = idx / G::TPX, i = idx - cc * G::TPX;
+                    const int s2 = i >> 8, prow = (i >> 5) & 7, x = i & 31;
+                    const int yy = ty0 + (s2 / G::C::SL_X) * kSlabH + prow;
+                    const int xx = tx0 + (s2 % G::C::SL_X) * kSlabW + x;
+                    f2a v{0.f, 0.f};
+                    if (yy < h && xx < w)
+                        v = __builtin_bit_cast(f2a, __builtin_amdgcn_raw_buffer_load_b64(prs0, (yy * w + xx) * 8, cc * (int)(8u * n), 0));
+                    psl[idx] = v;
+                }
+            }
+#define IRN_DEG_PART(QI) degree_partial<R, (QI) % Q>(wr, I, gy, gx, dsum)
+            switch (qi) {
+                case 0: IRN_DEG_PART(0); break;
+                case 1: IRN_DEG_PART(1); break;
+                case 2: IRN_DEG_PART(2); break;
+                case 3: IRN_DEG_PART(3); break;
+                case 4: IRN_DEG_PART(4); break;
+                case 5: IRN_DEG_PART(5); break;
+                case 6: IRN_DEG_PART(6); break;
+                default: IRN_DEG_PART(7); break;
+            }
+#undef IRN_DEG_PART
+            if (PROF && jslot) jslot[1] = wall_clock64();
+        } else {
 #define IRN_LOAD_PART(QI)                          \
     load_weights<R, (QI) % Q>(wr, I, gy, gx);      \
     degree_partial<R, (QI) % Q>(wr, I, gy, gx, dsum)
@@ -456,6 +514,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         // 1/deg of the tile: the waves' parts meet in LDS (the combine's partial-sum buffer), fp64 throughout
         __syncthreads();   // previous job's readers of part / invd / xs are done
         if (PROF && jslot) jslot[1] = wall_clock64();
+        }
         {
             double *pw = part + wv * 256 + lane * 4;
 #pragma unroll
@@ -509,12 +568,14 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             if (ok1) vmask |= 2u << (2 * k);
         }
         if (PROF && jslot) jslot[2] = wall_clock64();
-        for (int i = tid; i < 2 * LH * LW; i += 512) xs[i] = 0.f;
+        if constexpr (!RCfg<R>::PROLOGUE_OVERLAP)
+            for (int i = tid; i < 2 * LH * LW; i += 512) xs[i] = 0.f;
         // the recurrence's private terms {y_{t-1}, s_t} of the tile's own pixels, first CAPC channels: from the workspace
         // (written by x0_granule_kernel, or by the previous launch of a walk cut into several) into LDS
         const __amdgpu_buffer_rsrc_t prs =
             __builtin_amdgcn_make_buffer_rsrc((void *)I.xc, 0, (int)(8u * n * (unsigned)I.C), 0x00020000);
         const int c_lds = cheb ? (I.C < G::CAPC ? I.C : G::CAPC) : 0;
+        if constexpr (!RCfg<R>::PROLOGUE_OVERLAP)
         for (int idx = tid; idx < c_lds * G::TPX; idx += 512) {
             const int cc = idx / G::TPX, i = idx - cc * G::TPX;
             const int s2 = i >> 8, prow = (i >> 5) & 7, x = i & 31;
@@ -901,6 +962,43 @@ void resident_destroy(irn_walk_ctx *ctx) {
     ctx->res_err_host = nullptr;
 }
 
+// The slot -> block mapping below puts the tiles of an image on consecutive slots of ONE XCD under the assumption that
+// block b of a launch runs on XCD b % 8.  HIP promises nothing of the kind (it is what this driver does on an idle
+// MI355X), so the assumption is CHECKED once per device and process: a 64-thread probe launch of the same grid size
+// reads HW_REG_XCC_ID per block.  When it does not hold the mapping falls back to slot = block (still correct: the
+// exchange is placement-independent, only the share of same-XCD hand-offs changes) and a line on stderr says so.
+// g_placement[dev]: 0 = not checked, 1 = round robin holds, 2 = it does not.
+static int g_placement[64] = {};
+
+int resident_check_placement(irn_walk_ctx *ctx) {
+    int dev = 0;
+    IRN_HIP_TRY(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 64) return IRN_OK;
+    if (g_placement[dev] == 0) {
+        const int n_wg = ctx->res_nwg;
+        unsigned char *d = nullptr;
+        std::vector<unsigned char> hst((size_t)n_wg, 0xff);
+        IRN_HIP_TRY(hipMalloc((void **)&d, (size_t)n_wg));
+        IRN_HIP_TRY(hipMemset(d, 0xff, (size_t)n_wg));
+        int votes_ok = 0;
+        for (int rep = 0; rep < 2; ++rep) {           // twice: the first launch of a context may be placed differently
+            hipLaunchKernelGGL(xcc_probe_kernel, dim3(n_wg), dim3(64), 0, nullptr, d);
+            IRN_LAUNCH_CHECK("xcc_probe_kernel");
+            IRN_HIP_TRY(hipMemcpy(hst.data(), d, (size_t)n_wg, hipMemcpyDeviceToHost));
+            bool ok = n_wg % 8 == 0;
+            for (int b = 0; ok && b < n_wg; ++b) ok = hst[(size_t)b] == (unsigned char)(b % 8);
+            votes_ok += ok ? 1 : 0;
+        }
+        (void)hipFree(d);
+        g_placement[dev] = votes_ok == 2 ? 1 : 2;
+        if (g_placement[dev] == 2)
+            fprintf(stderr, "irn_hip: device %d: block b -> XCD b %% 8 does not hold here (first blocks on XCDs %d %d %d %d %d %d %d %d); "
+                            "tiles keep their launch order (speed only)\n", dev, hst[0], hst[1], hst[2], hst[3], hst[4], hst[5], hst[6], hst[7]);
+    }
+    ctx->res_placement = g_placement[dev];
+    return IRN_OK;
+}
+
 // Pack the batch into rounds of at most n_wg tiles.  Sets ctx->res_ok = false (not an error) when an
 // image does not fit one round or is narrower than the radius (then irn_walk_run falls back to the
 // streaming sweeps).
@@ -915,6 +1013,10 @@ int resident_configure(irn_walk_ctx *ctx) {
         ctx->res_nwg = prop.multiProcessorCount;
     }
     const int n_wg = ctx->res_nwg;
+    if (ctx->res_placement == 0) {
+        const int rc_p = resident_check_placement(ctx);
+        if (rc_p) return rc_p;
+    }
     int th, tw;
     tile_shape(ctx->radius, &th, &tw);
     const int n = (int)ctx->h.size();
@@ -948,10 +1050,10 @@ int resident_configure(irn_walk_ctx *ctx) {
         for (int ty = 0; ty < ctx->h[i]; ty += th)
             for (int tx = 0; tx < ctx->w[i]; tx += tw) {
                 const int slot = used[r]++;
-                // consecutive slots share an XCD: block b is dispatched to XCD b % 8 (observed)
+                // consecutive slots share an XCD: block b is dispatched to XCD b % 8 (checked: resident_check_placement)
                 const int per = (n_wg + 7) / 8;
                 int b = (slot % per) * 8 + slot / per;
-                if (n_wg % 8 != 0 || b >= n_wg) b = slot;
+                if (n_wg % 8 != 0 || b >= n_wg || ctx->res_placement == 2) b = slot;
                 rounds[r][b] = make_int4(i, ty, tx, tiles[i]);
             }
     }
@@ -1054,14 +1156,10 @@ static int launch_resident(irn_walk_ctx *ctx, int t_first, int t_count, int t_to
     return IRN_OK;
 }
 
-// x_0 and all sweeps of the configured batch.  The descriptors (imgs_dev) are already uploaded.
-int resident_run(irn_walk_ctx *ctx, int n_sweeps, hipStream_t stream) {
+// x_0 and all operator applications of the configured batch, enqueued on `stream` (the schedule is already set).
+static int resident_enqueue(irn_walk_ctx *ctx, hipStream_t stream) {
     const int n = ctx->n;
-    {
-        const int rc_s = walk_schedule(ctx, n_sweeps, stream);     // operator applications of x . T^n_sweeps (walk.hip)
-        if (rc_s) return rc_s;
-    }
-    n_sweeps = ctx->sched_steps;
+    const int n_sweeps = ctx->sched_steps;
     IRN_HIP_TRY(hipMemsetAsync(ctx->res_err_dev, 0, 4 * sizeof(unsigned), stream));
     hipLaunchKernelGGL(x0_granule_kernel, dim3(cdiv(ctx->max_n, 256), n), dim3(256), 0, stream, ctx->imgs_dev,
                        ctx->sched_cheb ? 1 : 0, ctx->sched_cheb ? (float)ctx->sched_coef[0] : 0.f);
@@ -1080,6 +1178,74 @@ int resident_run(irn_walk_ctx *ctx, int n_sweeps, hipStream_t stream) {
     }
     IRN_HIP_TRY(hipMemcpyAsync(ctx->res_err_host, ctx->res_err_dev, 4 * sizeof(unsigned), hipMemcpyDeviceToHost, stream));
     return IRN_OK;
+}
+
+// The poll delay of single-channel jobs (units of 64 clocks between a tile's own stores and its first poll of the
+// neighbours') was tuned by hand on one box: 8 / 10 / 12 within 2 % of each other there, 20 before the stores were
+// widened.  It is a property of the fabric's store -> load latency at this clock, so instead of trusting the constant the
+// first representative batch of a process (radius 10, >= 4 rounds, at least a third of its images single-channel) is
+// run with 8, 10 and 12 — twice each, the walk writes the same bits whatever the delay — and the fastest wins if it
+// beats the default by more than 2 %; cached per device.  Option "poll_delay" (or IRN_POLL_DELAY) pins the value and
+// switches the probe off.  g_poll_delay[dev]: 0 = not probed yet.
+static int g_poll_delay[64] = {};
+
+static int resident_probe_poll_delay(irn_walk_ctx *ctx, hipStream_t stream) {
+    int dev = 0;
+    IRN_HIP_TRY(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 64 || ctx->radius != 10 || !ctx->res_poll_auto) return IRN_OK;
+    if (g_poll_delay[dev]) {
+        ctx->res_poll_delay = g_poll_delay[dev];
+        return IRN_OK;
+    }
+    if (ctx->res_prof_dev || ctx->res_sweeps_per_launch > 0 || ctx->res_inject_timeout || ctx->res_rounds < 4 ||
+        ctx->sched_steps < 32)
+        return IRN_OK;
+    int single = 0;
+    for (int i = 0; i < ctx->n; ++i) single += ctx->c[i] == 1 ? 1 : 0;
+    if (3 * single < ctx->n) return IRN_OK;
+    hipEvent_t e0, e1;
+    IRN_HIP_TRY(hipEventCreate(&e0));
+    IRN_HIP_TRY(hipEventCreate(&e1));
+    const int cand[3] = {10, 8, 12};
+    float best_ms[3] = {1e30f, 1e30f, 1e30f};
+    int rc = IRN_OK;
+    for (int rep = 0; rep < 2 && !rc; ++rep)
+        for (int k = 0; k < 3 && !rc; ++k) {
+            ctx->res_poll_delay = cand[k];
+            (void)hipEventRecord(e0, stream);
+            rc = resident_enqueue(ctx, stream);
+            (void)hipEventRecord(e1, stream);
+            if (rc) break;
+            if (hipEventSynchronize(e1) != hipSuccess) { rc = fail(IRN_ERR_HIP, "poll-delay probe: synchronisation failed"); break; }
+            float ms = 0.f;
+            (void)hipEventElapsedTime(&ms, e0, e1);
+            if (ctx->res_err_host[0] != 0) ms = 1e30f;       // a launch that gave up says nothing about the delay
+            best_ms[k] = std::min(best_ms[k], ms);
+        }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    int pick = 0;
+    for (int k = 1; k < 3; ++k)
+        if (best_ms[k] < 0.98f * best_ms[0] && best_ms[k] < best_ms[pick]) pick = k;
+    ctx->res_poll_delay = cand[pick];
+    ctx->res_poll_probe_ms[0] = best_ms[1];      // 8, 10, 12 in that order
+    ctx->res_poll_probe_ms[1] = best_ms[0];
+    ctx->res_poll_probe_ms[2] = best_ms[2];
+    if (!rc && best_ms[0] < 1e29f) g_poll_delay[dev] = cand[pick];
+    return rc;
+}
+
+// x_0 and all sweeps of the configured batch.  The descriptors (imgs_dev) are already uploaded.
+int resident_run(irn_walk_ctx *ctx, int n_sweeps, hipStream_t stream) {
+    {
+        const int rc_s = walk_schedule(ctx, n_sweeps, stream);     // operator applications of x . T^n_sweeps (walk.hip)
+        if (rc_s) return rc_s;
+    }
+    {
+        const int rc_p = resident_probe_poll_delay(ctx, stream);   // first representative batch of the process only
+        if (rc_p) return rc_p;
+    }
+    return resident_enqueue(ctx, stream);
 }
 
 }  // namespace irn

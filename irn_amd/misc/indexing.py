@@ -13,6 +13,7 @@ plus the batched form the steps and bench use (``RandomWalk``).  Tensors must li
 is no CPU implementation here (the CPU restatement is test infrastructure under ``oracle/``).
 """
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -244,6 +245,19 @@ class RandomWalk:
         self._ws = None
         self._ws_bytes = 0
         self._live = None      # inputs of the last run: the re-run of `sync()` reads them again (include/irn_hip.h)
+        # The schedule is a deliberate deviation from the reference's computation (misc/indexing.py:136-137 squares the
+        # matrix exp_times times; this applies a polynomial of the operator): the user-reachable switch.  IRN_WALK_ACCEL=0
+        # restores the plain 2^exp_times applications everywhere (run_sample.py --walk_accel 0 sets it for the steps and
+        # their worker processes), IRN_WALK_ACCEL_TOL_EXP = e moves the series' truncation bound to 10^-e.
+        env = os.environ.get("IRN_WALK_ACCEL")
+        if env not in (None, ""):
+            self.set_option("accel", 1 if int(env) else 0)
+        env = os.environ.get("IRN_WALK_ACCEL_TOL_EXP")
+        if env not in (None, ""):
+            self.set_option("accel_tol_exp", int(env))
+        env = os.environ.get("IRN_POLL_DELAY")            # pins the single-channel poll delay (no start-up probe)
+        if env not in (None, ""):
+            self.set_option("poll_delay", int(env))
 
     def close(self):
         if self._ctx:
@@ -280,6 +294,15 @@ class RandomWalk:
     @property
     def fallback_runs(self):
         return int(lib.irn_walk_fallback_runs(self._ctx))
+
+    def tuning(self):
+        """{'poll_delay', 'placement' (0 unchecked / 1 block -> XCD round robin holds / 2 it does not), 'probe_ms' (launch
+        times the start-up probe measured for poll delays 8, 10, 12, or None)} — irn_walk_tuning."""
+        d, pl = C.c_int(), C.c_int()
+        ms = (C.c_float * 3)()
+        check(lib.irn_walk_tuning(self._ctx, C.byref(d), C.byref(pl), ms))
+        probed = any(v > 0 for v in ms)
+        return {"poll_delay": int(d.value), "placement": int(pl.value), "probe_ms": [float(v) for v in ms] if probed else None}
 
     def check(self):
         """Raise if a weights-stationary launch (option variant=2) gave up waiting for a neighbouring

@@ -9,7 +9,9 @@ API is unchanged: `step.X.run(args)` works on its own and returns when every sha
 import atexit
 import importlib
 import os
+import pickle
 import traceback
+from multiprocessing.reduction import ForkingPickler
 from concurrent.futures import ThreadPoolExecutor
 
 import numpy as np
@@ -117,8 +119,9 @@ def _pool_worker(rank, device, n_workers, cmd_q, res_q):
             cmd = cmd_q.get()
             if cmd is None:
                 break
-            mod, fn, model, shards, args = cmd
+            res_q.put((rank, "ack", None))          # the command arrived: the parent tells "never received" from "never finished"
             try:
+                mod, fn, model, shards, args = pickle.loads(cmd)
                 work = getattr(importlib.import_module(mod), fn)
                 work(rank, model, shards, args)
                 if int(device) >= 0:
@@ -145,32 +148,51 @@ class WorkerPool:
             p = ctx.Process(target=_pool_worker, args=(rank, dev, len(self.devices), self._cmd_qs[rank], self._res_q), daemon=True)
             p.start()
             self._procs.append(p)
-        self._collect("ready")
+        self._collect("ready", float(os.environ.get("IRN_WORKER_START_TIMEOUT_S", "900")), "worker start-up")
 
-    def _collect(self, want):
-        done = 0
-        while done < len(self._procs):
+    def _collect(self, want, timeout_s=0.0, what="step"):
+        """Wait until every worker has answered `want`.  Fail fast on a worker's exception or death (like
+        spawn(join=True)); with `timeout_s` > 0 also on a worker that is alive but silent — wedged in a GPU or RCCL call,
+        stuck behind another tenant of its device: the pool is stopped and the error names the ranks that never answered
+        (and whether the command had reached them)."""
+        import time
+        answered, acked = set(), set()
+        t0 = time.monotonic()
+        while len(answered) < len(self._procs):
             try:
-                rank, status, payload = self._res_q.get(timeout=5.0)
-            except Exception:            # queue.Empty: is everybody still alive?
+                rank, status, payload = self._res_q.get(timeout=1.0 if timeout_s > 0 else 5.0)
+            except Exception:            # queue.Empty: is everybody still alive, and inside the deadline?
                 dead = [i for i, p in enumerate(self._procs) if not p.is_alive()]
                 if dead:
                     codes = [self._procs[i].exitcode for i in dead]
                     self.close(force=True)
                     raise RuntimeError("step worker(s) %s died without reporting (exit codes %s)" % (dead, codes))
+                if timeout_s > 0 and time.monotonic() - t0 > timeout_s:
+                    silent = sorted(set(range(len(self._procs))) - answered)
+                    self.close(force=True)
+                    raise RuntimeError("%s: worker(s) %s (device(s) %s) did not answer within %.0f s; the command had reached %s; "
+                                       "all workers were stopped" % (what, silent, [self.devices[i] for i in silent], timeout_s,
+                                                                     sorted(acked & set(silent)) or "none of them"))
                 continue
             if status == "error":        # fail fast like spawn(join=True): the other workers are stopped, the error surfaces
                 self.close(force=True)
                 raise RuntimeError("step worker %d failed:\n%s" % (rank, payload))
-            if status == want:
+            if status == "ack":
+                acked.add(rank)
+            elif status == want:
                 if payload:
                     self.stats[rank] = payload
-                done += 1
+                answered.add(rank)
 
-    def run(self, work, model, shards, args):
-        for q in self._cmd_qs:
-            q.put((work.__module__, work.__name__, model, shards, args))
-        self._collect("ok")
+    def run(self, work, model, shards, args, timeout_s=0.0):
+        # pickled HERE, not by the queue's feeder thread: an unpicklable model / shard / argument (a lambda, an open handle)
+        # raises in the caller like the reference's spawn() does, instead of being printed by the feeder while the parent
+        # waits for workers that never got a command
+        # (once per worker: a pickled tensor carries a one-shot handle of its shared-memory file)
+        blobs = [bytes(ForkingPickler.dumps((work.__module__, work.__name__, model, shards, args))) for _ in self._cmd_qs]
+        for q, blob in zip(self._cmd_qs, blobs):
+            q.put(blob)
+        self._collect("ok", timeout_s, "%s.%s" % (work.__module__, work.__name__))
 
     def alive(self):
         return bool(self._procs) and all(p.is_alive() for p in self._procs)
@@ -235,7 +257,16 @@ def spawn_workers(work, model, shards, args):
     if n == 1 and not getattr(args, "always_use_workers", False):
         work(0, model, shards, args)        # same code path, no second process needed for a single GPU
         return
-    get_pool(devs).run(work, model, shards, args)
+    get_pool(devs).run(work, model, shards, args, timeout_s=step_timeout(args))
+
+
+def step_timeout(args=None):
+    """Seconds a step may spend in its workers before the pool is stopped (0 = no limit, the reference's behaviour):
+    `args.step_timeout` (run_sample.py --step_timeout) or the environment variable IRN_STEP_TIMEOUT_S."""
+    v = getattr(args, "step_timeout", None) if args is not None and not isinstance(args, dict) else None
+    if v in (None, "", 0, 0.0):
+        v = os.environ.get("IRN_STEP_TIMEOUT_S", 0)
+    return max(0.0, float(v or 0))
 
 
 def split_by_owner(dataset, n_splits, names, owners, slack=0.25):
@@ -363,6 +394,22 @@ def walk_radius(args, default):
     step/make_ins_seg_labels.py:135); `args.radius` (run_sample.py --radius) overrides it, e.g. 10 for BASELINE
     configs[2]."""
     return int(getattr(args, "radius", 0) or default)
+
+
+def make_walker(args, default_radius):
+    """The steps' random walk: radius as `walk_radius`, and the schedule switch — `args.walk_accel` (run_sample.py
+    --walk_accel {0,1}; None = the environment variable IRN_WALK_ACCEL, else the library default 1) chooses between the
+    truncated Chebyshev series of the operator and the reference's own count of 2^exp_times applications
+    (misc/indexing.py:136-137); `args.walk_accel_tol_exp` = e moves the series' truncation bound to 10^-e."""
+    from ..misc import indexing
+    walker = indexing.RandomWalk(walk_radius(args, default_radius))
+    accel = getattr(args, "walk_accel", None)
+    if accel not in (None, ""):
+        walker.set_option("accel", 1 if int(accel) else 0)
+    tol = getattr(args, "walk_accel_tol_exp", None)
+    if tol not in (None, "", 0):
+        walker.set_option("accel_tol_exp", int(tol))
+    return walker
 
 
 def make_loader(databin, num_workers, prefetch=4):

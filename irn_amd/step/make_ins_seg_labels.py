@@ -17,7 +17,6 @@ import numpy as np
 import torch
 
 from .. import ops
-from ..misc import indexing
 from ..voc12 import dataloader as voc12_dataloader
 from . import _common, make_sem_seg_labels
 
@@ -96,7 +95,7 @@ def _work(process_id, model, dataset, args):
         with torch.no_grad(), torch.cuda.device(dev_id):
             model.cuda()
             dev = torch.device("cuda", dev_id)
-            walker = indexing.RandomWalk(_common.walk_radius(args, RADIUS))
+            walker = _common.make_walker(args, RADIUS)
             pend, in_flight = [], [None]
             for it, pack in enumerate(loader):
                 name = pack["name"][0]

@@ -17,7 +17,6 @@ import torch
 from PIL import Image
 
 from .. import ops
-from ..misc import indexing
 from ..voc12 import dataloader as voc12_dataloader
 from . import _common
 
@@ -104,7 +103,7 @@ def _work(process_id, model, dataset, args):
         with torch.no_grad(), torch.cuda.device(dev_id):
             model.cuda()
             dev = torch.device("cuda", dev_id)
-            walker = indexing.RandomWalk(_common.walk_radius(args, RADIUS))
+            walker = _common.make_walker(args, RADIUS)
             # a batch is enqueued and left running while the loop gathers the next one (decoded images from the loader
             # threads, their uploads, the CAMs); it is collected just before the next batch is enqueued
             pend, running = [], None

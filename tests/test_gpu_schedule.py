@@ -1,16 +1,22 @@
 """GPU parity of the walk's polynomial schedule (round 3): x . T^n evaluated as a truncated Chebyshev series
-(84 operator applications instead of 256 at exp_times = 8; irn_amd/csrc/walk.hip header, include/irn_hip.h).
+(78 operator applications instead of 256 at exp_times = 8 with the default truncation bound 1e-6, 84 at 1e-7; irn_amd/csrc/walk.hip header, include/irn_hip.h).
 
 What has to hold: (a) the accelerated walk is as close to the fp64 oracle of the reference's operator
 (misc/indexing.py:141-165) as the plain iteration — both far inside the 1e-4 bar — with identical argmax, on every
 kernel variant; (b) "accel" = 0 is the plain iteration; (c) the recurrence's private terms survive every storage
 path — LDS for the first channels of a job, the workspace for the rest, and the write-back between the launches of a
 walk cut into several; (d) the reference's own 128x128 outputs."""
+import os
+import sys
+
 import numpy as np
 import pytest
 import torch
 
 from oracle import irn_oracle as O
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import _stress  # noqa: E402
 
 pytestmark = pytest.mark.gpu
 
@@ -41,13 +47,16 @@ def _inputs(shapes, seed0):
 
 def test_schedule_lengths():
     wk = _walker(10)
-    assert wk.steps(256) == 84 and wk.steps(16) == 16 and wk.steps(0) == 0
+    assert wk.steps(256) == 78 and wk.steps(16) == 16 and wk.steps(0) == 0
     assert wk.steps(128) < 70 and wk.steps(1024) < 200
+    wk.set_option("accel_tol_exp", 7)
+    assert wk.steps(256) == 84
     wk.set_option("accel", 0)
     assert wk.steps(256) == 256
     wk.set_option("accel", 1)
     wk.set_option("accel_tol_exp", 9)
     assert 84 < wk.steps(256) <= 100
+    wk.set_option("accel_tol_exp", 6)
     wk.close()
 
 
@@ -74,10 +83,10 @@ def test_accelerated_walk_vs_fp64_oracle_and_plain_iteration(r, shapes, variant)
         eb = np.abs(b[i].cpu().numpy() - st).max()
         worst = (max(worst[0], ea), max(worst[1], eb))
         assert ea <= TOL_F64 and eb <= TOL_F64, (shapes[i], ea, eb)
-        assert (a[i] - b[i]).abs().max().item() <= 4e-6, shapes[i]
+        assert (a[i] - b[i]).abs().max().item() <= 6e-6, shapes[i]
         assert np.array_equal(np.argmax(a[i].cpu().numpy()[:, 0], 0), np.argmax(st[:, 0], 0)), shapes[i]
     print("variant %d radius %d: max |series - fp64| %.2e, max |plain - fp64| %.2e" % (variant, r, worst[0], worst[1]))
-    assert worst[0] <= 2.0 * worst[1] + 5e-7
+    assert worst[0] <= 2.0 * worst[1] + 1.5e-6       # rounding + the series' truncation bound (1e-6)
     fast.close()
     plain.close()
 
@@ -171,3 +180,69 @@ def test_other_exponents_and_generic_radius():
             st = O.propagate_to_edge_stencil(cam_np, edge_np, r, 10, e)
             assert np.abs(rw.cpu().numpy() - st).max() <= TOL_F64, (r, e)
         wk.close()
+
+
+_STRESS_EXACT = {}
+
+
+def _stress_exact(r):
+    """fp64 oracle of every adversarial case at radius r (computed once per session: ~1 s each at radius 10)."""
+    if r not in _STRESS_EXACT:
+        out = []
+        for ci, (name, beta, make) in enumerate(_stress.cases()):
+            h, w, c = (40, 52, 2) if ci % 2 else (56, 72, 3)
+            edge, cam = make(h, w, c, 500 + ci)
+            out.append((name, beta, edge, cam, O.propagate_to_edge_stencil(cam, edge, r, beta, 8)))
+        _STRESS_EXACT[r] = out
+    return _STRESS_EXACT[r]
+
+
+@pytest.mark.parametrize("r", [10, 5])
+@pytest.mark.parametrize("variant", [2, 1, 0])
+def test_schedule_on_adversarial_fields(r, variant):
+    """Where the series' maths is stressed (tests/_stress.py: edge = 0, edge = 0.999, Bernoulli 0/1 edges, a one-pixel wall,
+    beta 1 / 8 / 10 / 20, white-noise CAMs), every kernel variant, default truncation bound, the tighter one (1e-7) and
+    the plain iteration: <= 1e-5 from the fp64 oracle, <= 1e-4 after division by the maximum (the epilogue's scale, the
+    north star's bar), argmax equal except at ties.  The measured triples are printed: on flat-spectrum operators the
+    series is several times FURTHER from the exact product than the plain iteration (3e-7 against 5e-8 with no edges at
+    all), on the structured ones closer; both are two orders inside the bar."""
+    cases = _stress_exact(r)
+    rows = []
+    for opts in ({}, {"accel_tol_exp": 7}, {"accel": 0}):
+        wk = _walker(r, variant, **opts)
+        for beta in sorted({b for _, b, _, _, _ in cases}):
+            sel = [c for c in cases if c[1] == beta]
+            outs = wk([torch.from_numpy(c[2]).to(_dev()) for c in sel], [torch.from_numpy(c[3]).to(_dev()) for c in sel],
+                      beta=beta, exp_times=8)
+            wk.check()
+            for (name, _, edge, cam, exact), o in zip(sel, outs):
+                got = o.cpu().numpy()
+                err = float(np.abs(got - exact).max())
+                scale = max(float(exact.max()), 1e-30)
+                assert err <= TOL_F64, (name, opts, err)
+                assert err / scale <= TOL_REF, (name, opts, err / scale)
+                n_tie = _stress.argmax_mismatch_is_tie(got[:, 0], exact[:, 0], 2e-5)
+                rows.append((name, tuple(opts.items()), err, err / scale, n_tie))
+        wk.close()
+    for name in [c[0] for c in cases]:
+        e = {k: (a, b, t) for n, k, a, b, t in rows if n == name}
+        print("variant %d radius %2d %-20s series(1e-6) %.2e  series(1e-7) %.2e  plain %.2e   normalised %.2e / %.2e / %.2e   argmax ties %d/%d/%d" % (
+            variant, r, name, e[()][0], e[(("accel_tol_exp", 7),)][0], e[(("accel", 0),)][0],
+            e[()][1], e[(("accel_tol_exp", 7),)][1], e[(("accel", 0),)][1], e[()][2], e[(("accel_tol_exp", 7),)][2], e[(("accel", 0),)][2]))
+
+
+def test_walk_accel_switch_of_the_wrapper(monkeypatch):
+    """IRN_WALK_ACCEL / IRN_WALK_ACCEL_TOL_EXP (what run_sample.py --walk_accel / --walk_accel_tol_exp set for the steps)
+    reach the context; explicit options still win."""
+    from irn_amd.misc import indexing
+    monkeypatch.setenv("IRN_WALK_ACCEL", "0")
+    wk = indexing.RandomWalk(5, _dev())
+    assert wk.steps(256) == 256
+    wk.set_option("accel", 1)
+    assert wk.steps(256) == 78
+    wk.close()
+    monkeypatch.setenv("IRN_WALK_ACCEL", "1")
+    monkeypatch.setenv("IRN_WALK_ACCEL_TOL_EXP", "7")
+    wk = indexing.RandomWalk(5, _dev())
+    assert wk.steps(256) == 84
+    wk.close()

@@ -272,3 +272,46 @@ def test_worker_pool_reports_a_worker_that_dies(tmp_path):
             assert "died without reporting" in str(e) and "7" in str(e)
     finally:
         pool.close(force=True)
+
+
+def _sleepy_work(process_id, model, shards, args):
+    import time
+    if process_id == 1:
+        time.sleep(3600)                 # alive but silent: a wedged GPU / RCCL call, a launch stuck behind another tenant
+
+
+def test_worker_pool_deadline_and_unpicklable_commands(tmp_path):
+    """A worker that hangs without dying is bounded by the step's time-out (the pool is stopped, the error names the silent
+    rank and says the command had reached it); a command that cannot be pickled raises in the CALLER, like the reference's
+    spawn() does, instead of leaving the parent waiting for workers that never got it."""
+    import time
+    from irn_amd.step import _common
+    pool = _common.WorkerPool([-1, -1])
+    try:
+        t0 = time.monotonic()
+        try:
+            pool.run(_sleepy_work, None, torchutils.split_dataset(list(range(4)), 2), {}, timeout_s=3.0)
+            raise AssertionError("a silent worker must raise once the deadline has passed")
+        except RuntimeError as e:
+            assert "worker(s) [1]" in str(e) and "did not answer within 3 s" in str(e) and "had reached [1]" in str(e), str(e)
+        assert time.monotonic() - t0 < 30.0 and not pool.alive()
+    finally:
+        pool.close(force=True)
+    pool = _common.WorkerPool([-1])
+    try:
+        try:
+            pool.run(_fake_work, None, torchutils.split_dataset([1], 1), {"out": str(tmp_path), "bad": (lambda: 0)})
+            raise AssertionError("an unpicklable argument must raise in the caller")
+        except Exception as e:
+            assert "pickle" in repr(e).lower() or "lambda" in repr(e).lower(), repr(e)
+        pool.run(_fake_work, None, torchutils.split_dataset([1], 1), {"out": str(tmp_path)})       # the pool is still usable
+        assert os.path.exists(tmp_path / "00001.npy")
+    finally:
+        pool.close()
+    assert _common.step_timeout(None) == 0.0
+    os.environ["IRN_STEP_TIMEOUT_S"] = "7.5"
+    try:
+        import argparse
+        assert _common.step_timeout(argparse.Namespace()) == 7.5 and _common.step_timeout(argparse.Namespace(step_timeout=2)) == 2.0
+    finally:
+        del os.environ["IRN_STEP_TIMEOUT_S"]
