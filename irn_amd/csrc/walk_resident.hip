@@ -75,6 +75,9 @@ struct RCfg<5> {
 #ifndef IRN_R5_PROLOGUE_OVERLAP
 #define IRN_R5_PROLOGUE_OVERLAP 1
 #endif
+#ifndef IRN_R5_COMBINE_PIN
+#define IRN_R5_COMBINE_PIN 1
+#endif
     static constexpr bool PROLOGUE_OVERLAP = IRN_R5_PROLOGUE_OVERLAP != 0;   // LDS fill under the weight loads
 };
 
@@ -870,6 +873,16 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                             s0v[it] = fmaf(ck, r0v[it], pv[it].y);
                             s1v[it] = fmaf(ck, r1v[it], pv[it].w);
                         }
+#if IRN_R5_COMBINE_PIN
+                        // The results of BOTH iterations exist here, before the first (branchy) store: without this the
+                        // compiler sinks the second iteration's whole dependent chain (~60 instructions at ~10 cycles
+                        // each for a lone wave on its SIMD) behind the first iteration's stores, and the phase takes two
+                        // chains back to back instead of two interleaved ones (the asm of round 3's build showed exactly
+                        // that; `sched_barrier` only orders instructions inside one basic block).
+#pragma unroll
+                        for (int it = 0; it < NIT; ++it)
+                            asm volatile("" : "+v"(r0v[it]), "+v"(r1v[it]), "+v"(s0v[it]), "+v"(s1v[it]));
+#endif
                         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                         for (int it = 0; it < NIT; ++it) {

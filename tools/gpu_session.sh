@@ -1,5 +1,5 @@
 #!/bin/bash
-# One gpurun call of round 3 (results land in gpurun_out/r3_sN/; copy what should be judged into profiles/).
+# One gpurun call of round 4 (results land in gpurun_out/r3_sN/; copy what should be judged into profiles/).
 # usage: tools/gpu_session.sh <N> [what...]
 #   what: tests tests_all testsel smoke bench default ab abopt prof pmc pmcsq <script under tools/>
 #   env:  TESTSEL="-k expr or paths" (testsel), AB_LIBS="libirn_hip.so other.so", AB_WL="walk coco walk_r5",
@@ -7,7 +7,7 @@
 set -u
 S=${1:-1}; shift || true
 WHAT=${*:-tests bench prof}
-OUT=gpurun_out/r3_s$S
+OUT=gpurun_out/r4_s$S
 mkdir -p $OUT
 export TMPDIR=/tmp MIOPEN_FIND_MODE=${MIOPEN_FIND_MODE:-2}
 report() {   # report <json> <label>
@@ -97,6 +97,13 @@ pmcsq)
   cd $R
   python tools/reduce_prof.py $OUT > $OUT/sq_summary.txt 2>&1; grep -E "resident_kernel|affinity_" $OUT/sq_summary.txt | cut -c1-40,96-200
   find $OUT -name "walk_counter_collection.csv" -delete ;;
+stepprof)
+  for lib in ${AB_LIBS:-libirn_hip.so}; do echo "== $lib"; bash tools/r4_profile.sh $OUT $lib; done > $OUT/step_profile.txt 2>&1; cat $OUT/step_profile.txt ;;
+ranks)
+  # the N > 1 bench path on this one-GPU box: two ranks on device 0 (gloo), then what RCCL does with a shared device
+  timeout 600 python -m pytest tests/test_gpu_bench_ranks.py -m gpu -q -s --durations=5 > $OUT/pytest_ranks.log 2>&1; echo "ranks pytest rc=$?"
+  grep -E "two ranks|passed|failed|rc=|Error" $OUT/pytest_ranks.log | tail -8
+  bash tools/rccl_shared_probe.sh $OUT ;;
 *)
   # anything else: a script under tools/ taking the output directory
   if [ -f tools/$w ]; then timeout ${RAW_TIMEOUT:-600} python tools/$w $OUT > $OUT/${w%.py}.log 2>&1; echo "$w rc=$?"; tail -${RAW_TAIL:-30} $OUT/${w%.py}.log; else echo "unknown: $w"; fi ;;
