@@ -378,7 +378,8 @@ def run_backbone(a, workload, rank, world, device, dist, parallel, steps, warmup
     from irn_amd.net import resnet50_cam, resnet50_irn, weights
     from irn_amd.step import make_cam
 
-    os.environ.setdefault("MIOPEN_FIND_MODE", "2")
+    from irn_amd.step import _common
+    _common.miopen_setup(device.index or 0)     # what the steps run with: find mode 2, the stable / shipped find database
     batch = batch or 8
     H = W = 512
     scales = (1.0, 0.5, 1.5, 2.0)
@@ -430,7 +431,7 @@ def run_steps(a, rank, world, device, dist, parallel, steps, warmup, batch=0):
     from irn_amd import synth
     from irn_amd.net import weights
     from irn_amd.step import _common, make_cam, make_ins_seg_labels, make_sem_seg_labels
-    os.environ.setdefault("MIOPEN_FIND_MODE", "2")
+    _common.miopen_setup(device.index or 0)
     batch = batch or 32
     t_setup = time.perf_counter()
     tmp = tempfile.mkdtemp(prefix="irn_steps_%d_" % rank)

@@ -119,7 +119,7 @@ int irn_walk_run(irn_walk_ctx *ctx, const float *const *edge_dev, const float *c
  * operator applications instead of n (84 instead of 256 at exp_times = 8), accumulating s = sum_k c_k y_k.  Measured
  * against the fp64 oracle the result is as close as that of the plain iteration (tests/test_gpu_schedule.py).
  *   option "accel" = 1 (default) / 0: truncated Chebyshev series / plain powers (n applications, bit-identical to the
- *   recurrence-free kernels of rounds 1-2); "accel_tol_exp" = e: tol = 10^-e (default 6: 78 applications for n = 256; 7: 84).
+ *   recurrence-free kernels of rounds 1-2); "accel_tol_exp" = e: tol = 10^-e (default 7: 84 applications for n = 256; 6: 78).
  *   irn_walk_steps reports the operator applications a run with `n_sweeps` would execute (for flop accounting).
  * The caller's edge / cam / inst_map device buffers must stay valid and unmodified until irn_walk_sync (or the next
  * irn_walk_run) returns: a run that irn_walk_sync has to repeat reads them again. */

@@ -66,19 +66,11 @@ template <>
 struct RCfg<10> {
     static constexpr int Q = 8, SL_Y = 1, SL_X = 1;
     static constexpr bool PREFETCH_ROWS = true;     // read the next neighbour row's window ahead of this row's FMAs
-    static constexpr bool PROLOGUE_OVERLAP = false; // (see the job prologue: spills at this radius)
 };
 template <>
 struct RCfg<5> {
     static constexpr int Q = 2, SL_Y = 2, SL_X = 2;
     static constexpr bool PREFETCH_ROWS = true;     // fits since the fp32 chains freed the fp64 accumulators (250 VGPRs)
-#ifndef IRN_R5_PROLOGUE_OVERLAP
-#define IRN_R5_PROLOGUE_OVERLAP 1
-#endif
-#ifndef IRN_R5_COMBINE_PIN
-#define IRN_R5_COMBINE_PIN 1
-#endif
-    static constexpr bool PROLOGUE_OVERLAP = IRN_R5_PROLOGUE_OVERLAP != 0;   // LDS fill under the weight loads
 };
 
 // The neighbour disc (dy,dx) != (0,0), dx^2 + dy^2 < R^2, in raster order: the union of the
@@ -452,54 +444,6 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         }
 
         double dsum[4];
-        if constexpr (RCfg<R>::PROLOGUE_OVERLAP) {
-            // The weight loads (~7.5 us per job from HBM) are issued first; the part of the prologue that does not need
-            // them — the LDS clear, the carried terms — runs under their latency instead of behind the degree (1.2 us of a
-            // 9.4 us prologue, profiles/r03_s4_resident_step_profile.txt).  Radius 5 only: at radius 10 keeping all 152
-            // weight registers in flight across that code costs two spilled registers that are reloaded inside the step loop.
-#define IRN_LOAD_W(QI) load_weights<R, (QI) % Q>(wr, I, gy, gx)
-            switch (qi) {
-                case 0: IRN_LOAD_W(0); break;
-                case 1: IRN_LOAD_W(1); break;
-                case 2: IRN_LOAD_W(2); break;
-                case 3: IRN_LOAD_W(3); break;
-                case 4: IRN_LOAD_W(4); break;
-                case 5: IRN_LOAD_W(5); break;
-                case 6: IRN_LOAD_W(6); break;
-                default: IRN_LOAD_W(7); break;
-            }
-#undef IRN_LOAD_W
-            __syncthreads();   // previous job's readers of part / invd / xs / psl are done
-            for (int i = tid; i < 2 * LH * LW; i += 512) xs[i] = 0.f;
-            {
-                const __amdgpu_buffer_rsrc_t prs0 =
-                    __builtin_amdgcn_make_buffer_rsrc((void *)I.xc, 0, (int)(8u * n * (unsigned)I.C), 0x00020000);
-                const int c_lds0 = cheb ? (I.C < G::CAPC ? I.C : G::CAPC) : 0;
-                for (int idx = tid; idx < c_lds0 * G::TPX; idx += 512) {
-                    const int cc = idx / G::TPX, i = idx - cc * G::TPX;
-                    const int s2 = i >> 8, prow = (i >> 5) & 7, x = i & 31;
-                    const int yy = ty0 + (s2 / G::C::SL_X) * kSlabH + prow;
-                    const int xx = tx0 + (s2 % G::C::SL_X) * kSlabW + x;
-                    f2a v{0.f, 0.f};
-                    if (yy < h && xx < w)
-                        v = __builtin_bit_cast(f2a, __builtin_amdgcn_raw_buffer_load_b64(prs0, (yy * w + xx) * 8, cc * (int)(8u * n), 0));
-                    psl[idx] = v;
-                }
-            }
-#define IRN_DEG_PART(QI) degree_partial<R, (QI) % Q>(wr, I, gy, gx, dsum)
-            switch (qi) {
-                case 0: IRN_DEG_PART(0); break;
-                case 1: IRN_DEG_PART(1); break;
-                case 2: IRN_DEG_PART(2); break;
-                case 3: IRN_DEG_PART(3); break;
-                case 4: IRN_DEG_PART(4); break;
-                case 5: IRN_DEG_PART(5); break;
-                case 6: IRN_DEG_PART(6); break;
-                default: IRN_DEG_PART(7); break;
-            }
-#undef IRN_DEG_PART
-            if (PROF && jslot) jslot[1] = wall_clock64();
-        } else {
 #define IRN_LOAD_PART(QI)                          \
     load_weights<R, (QI) % Q>(wr, I, gy, gx);      \
     degree_partial<R, (QI) % Q>(wr, I, gy, gx, dsum)
@@ -517,7 +461,6 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         // 1/deg of the tile: the waves' parts meet in LDS (the combine's partial-sum buffer), fp64 throughout
         __syncthreads();   // previous job's readers of part / invd / xs are done
         if (PROF && jslot) jslot[1] = wall_clock64();
-        }
         {
             double *pw = part + wv * 256 + lane * 4;
 #pragma unroll
@@ -571,14 +514,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             if (ok1) vmask |= 2u << (2 * k);
         }
         if (PROF && jslot) jslot[2] = wall_clock64();
-        if constexpr (!RCfg<R>::PROLOGUE_OVERLAP)
-            for (int i = tid; i < 2 * LH * LW; i += 512) xs[i] = 0.f;
+        for (int i = tid; i < 2 * LH * LW; i += 512) xs[i] = 0.f;
         // the recurrence's private terms {y_{t-1}, s_t} of the tile's own pixels, first CAPC channels: from the workspace
         // (written by x0_granule_kernel, or by the previous launch of a walk cut into several) into LDS
         const __amdgpu_buffer_rsrc_t prs =
             __builtin_amdgcn_make_buffer_rsrc((void *)I.xc, 0, (int)(8u * n * (unsigned)I.C), 0x00020000);
         const int c_lds = cheb ? (I.C < G::CAPC ? I.C : G::CAPC) : 0;
-        if constexpr (!RCfg<R>::PROLOGUE_OVERLAP)
         for (int idx = tid; idx < c_lds * G::TPX; idx += 512) {
             const int cc = idx / G::TPX, i = idx - cc * G::TPX;
             const int s2 = i >> 8, prow = (i >> 5) & 7, x = i & 31;
@@ -687,7 +628,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             }
             __syncthreads();
             if (*abort_flag) return;
+#ifndef IRN_PROF_COMBINE
             if (PROF && pslot) pslot[1] = wall_clock64();
+#endif
 
             // ---- [B] prefetch: the next step's poll is issued as soon as its input can be there ----
             // chain cn was stored C-1 steps ago: long ago for C >= 3 (issue before the arithmetic), at the
@@ -747,7 +690,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 asm volatile("" : "+v"(wl));
                 *reinterpret_cast<f4a *>(partf + (k & 1) * (kWaves * 256) + wv * 256 + wl * 4) = f4a{acc[0], acc[1], acc[2], acc[3]};
                 __syncthreads();
+#ifndef IRN_PROF_COMBINE
                 if (PROF && pslot) pslot[2] = wall_clock64();
+#else
+                if (PROF && pslot) pslot[1] = wall_clock64();          // diagnostic build: [1] = combine entry
+#endif
                 // One pixel per combining thread, consecutive threads = consecutive pixels of a tile row (their
                 // partial sums are contiguous in LDS).  Neighbouring lanes then swap results and the even lane
                 // stores BOTH granules with one 16-byte store (8-byte sc1 stores are the expensive form, lesson 10;
@@ -777,6 +724,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     for (int q = 0; q < Q; ++q) ps[q] = pr[q * 256];
                     const float centre = xsb[(py + H) * LW + px + HP];
                     const double inv = invd[i];
+#ifdef IRN_PROF_COMBINE
+                    if (PROF && pslot) {
+                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                        pslot[2] = wall_clock64();
+                    }
+#endif
 #pragma unroll
                     for (int span = 1; span < Q; span *= 2)
 #pragma unroll
@@ -791,6 +744,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                         else if (inimg && !last)
                             __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2v, nv), prs, (int)o * 8, c * ch_bytes, 0);
                     }
+#ifdef IRN_PROF_COMBINE
+                    if (PROF && pslot) {
+                        asm volatile("" : "+v"(outv));
+                        pslot[3] = wall_clock64();
+                    }
+#endif
                     // neighbour lane's result through a DPP quad permute (lanes 2n <-> 2n+1) instead of an LDS round trip
                     const float other = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(res), 0xB1, 0xF, 0xF, true));
                     if (inimg) {
@@ -857,6 +816,12 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                             iv0[it] = invd[ii];
                             iv1[it] = invd[ii + 1];
                         }
+#ifdef IRN_PROF_COMBINE
+                        if (PROF && pslot) {                                   // [2] = every LDS read of the phase has landed
+                            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                            pslot[2] = wall_clock64();
+                        }
+#endif
                         __builtin_amdgcn_sched_barrier(0);
                         float r0v[NIT], r1v[NIT], s0v[NIT], s1v[NIT];
 #pragma unroll
@@ -873,15 +838,13 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                             s0v[it] = fmaf(ck, r0v[it], pv[it].y);
                             s1v[it] = fmaf(ck, r1v[it], pv[it].w);
                         }
-#if IRN_R5_COMBINE_PIN
-                        // The results of BOTH iterations exist here, before the first (branchy) store: without this the
-                        // compiler sinks the second iteration's whole dependent chain (~60 instructions at ~10 cycles
-                        // each for a lone wave on its SIMD) behind the first iteration's stores, and the phase takes two
-                        // chains back to back instead of two interleaved ones (the asm of round 3's build showed exactly
-                        // that; `sched_barrier` only orders instructions inside one basic block).
+#ifdef IRN_PROF_COMBINE
+                        if (PROF && pslot) {                                   // [3] = the arithmetic of both iterations is done
 #pragma unroll
-                        for (int it = 0; it < NIT; ++it)
-                            asm volatile("" : "+v"(r0v[it]), "+v"(r1v[it]), "+v"(s0v[it]), "+v"(s1v[it]));
+                            for (int it = 0; it < NIT; ++it)
+                                asm volatile("" : "+v"(r0v[it]), "+v"(r1v[it]), "+v"(s0v[it]), "+v"(s1v[it]));
+                            pslot[3] = wall_clock64();
+                        }
 #endif
                         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -927,7 +890,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             // C = 1: the next poll is timed from our own stores, so every wave has to start its delay
             // behind them (the waves that do not combine would otherwise poll ~0.2 us early)
             if (C == 1) __syncthreads();
+#ifndef IRN_PROF_COMBINE
             if (PROF && pslot) pslot[3] = wall_clock64();
+#endif
             t = tn;
             c = cn;
         }

@@ -99,6 +99,70 @@ def worker_device(process_id, args=None):
     return devs[process_id] if process_id < len(devs) else process_id
 
 
+def miopen_cache_key():
+    """(device name, HIP version) as a directory name: MIOpen's find results are only valid for the chip and library
+    build that measured them."""
+    try:
+        name = torch.cuda.get_device_name(0).replace(" ", "_").replace("/", "_")
+    except Exception:
+        name = "unknown_device"
+    return "%s-hip%s" % (name, (torch.version.hip or "none").replace("/", "_"))
+
+
+_MIOPEN_LOCKS = []           # lock files held for the life of the process
+
+
+def miopen_setup(device_ordinal):
+    """MIOpen's settings for the process that is about to run the backbones on `device_ordinal` — the SAME for a pool
+    worker and for the in-process single-GPU path, so that one-GPU and N-GPU runs pick their convolution solvers the
+    same way: find mode 2 ("fast": the find database first, the immediate-mode heuristic on a miss)
+    unless the user chose one, and a user database directory that is
+      * stable across runs — `$IRN_MIOPEN_CACHE` or `~/.cache/irn_amd/miopen`, / (device name, HIP version) / dev<ordinal>
+        — so that what one run's workers found the next run's workers reuse (each worker process used to start with
+        a cold database named after its rank);
+      * seeded, when empty, from the database shipped with the package for this (device, HIP) pair
+        (`irn_amd/data/miopen/<key>/`, written on a GPU box by `tools/miopen_warmup.py`);
+      * never shared by two live processes: the directory is claimed with an advisory lock, and a process that finds
+        it taken (a second job on the same host and GPU) works on a private copy `dev<ordinal>-pid<pid>` instead
+        (eight workers appending to one database collided in round 2).
+    A `MIOPEN_USER_DB_PATH` the user exported is respected as the base.  Must run before the process's first
+    convolution; returns the directory."""
+    import fcntl
+    import shutil
+    os.environ.setdefault("MIOPEN_FIND_MODE", "2")
+    marker = os.environ.get("IRN_MIOPEN_DB_SET")
+    if marker and os.environ.get("MIOPEN_USER_DB_PATH") == marker:
+        return marker                                    # this process (or the parent it inherited from, if it holds no lock itself) did it
+    # (IRN_MIOPEN_BASE: the base the first caller of this job resolved — a worker must not take its parent's claimed
+    # directory, which it inherits in MIOPEN_USER_DB_PATH, for the user's base)
+    base = os.environ.get("IRN_MIOPEN_BASE") or os.environ.get("IRN_MIOPEN_CACHE") or os.environ.get("MIOPEN_USER_DB_PATH") or \
+        os.path.join(os.path.expanduser("~"), ".cache", "irn_amd", "miopen")
+    os.environ["IRN_MIOPEN_BASE"] = base
+    key = miopen_cache_key()
+    stable = os.path.join(base, key, "dev%d" % int(device_ordinal))
+    os.makedirs(stable, exist_ok=True)
+    seed = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "data", "miopen", key)
+    if os.environ.get("IRN_MIOPEN_SEED", "1") != "0" and os.path.isdir(seed) and not any(f.endswith(".txt") or f.endswith(".db") for f in os.listdir(stable)):
+        for f in os.listdir(seed):
+            if os.path.isfile(os.path.join(seed, f)):
+                shutil.copy2(os.path.join(seed, f), os.path.join(stable, f))
+    use = stable
+    try:
+        fh = open(os.path.join(stable, ".lock"), "w")
+        fcntl.flock(fh, fcntl.LOCK_EX | fcntl.LOCK_NB)
+        _MIOPEN_LOCKS.append(fh)
+    except OSError:                                      # another live process owns it: private copy
+        use = os.path.join(base, key, "dev%d-pid%d" % (int(device_ordinal), os.getpid()))
+        os.makedirs(use, exist_ok=True)
+        for f in os.listdir(stable):
+            if f != ".lock" and os.path.isfile(os.path.join(stable, f)):
+                shutil.copy2(os.path.join(stable, f), os.path.join(use, f))
+        atexit.register(shutil.rmtree, use, True)
+    os.environ["MIOPEN_USER_DB_PATH"] = use
+    os.environ["IRN_MIOPEN_DB_SET"] = use
+    return use
+
+
 _WORKER_DEVICE = [None]      # set inside a pool worker process
 _POOL = [None]               # the parent's pool
 
@@ -106,13 +170,10 @@ _POOL = [None]               # the parent's pool
 def _pool_worker(rank, device, n_workers, cmd_q, res_q):
     """Main loop of a pool worker: bound to one device for its whole life, runs the `_work` functions the parent names."""
     try:
-        # every worker searches MIOpen's solvers on its own: eight processes appending to one user database collide
-        base = os.environ.get("MIOPEN_USER_DB_PATH") or os.path.join(os.path.expanduser("~"), ".config", "miopen")
-        os.environ["MIOPEN_USER_DB_PATH"] = os.path.join(base, "irn_worker_%d" % rank)
-        os.makedirs(os.environ["MIOPEN_USER_DB_PATH"], exist_ok=True)
-        os.environ.setdefault("MIOPEN_FIND_MODE", "2")
         _WORKER_DEVICE[0] = int(device)
         if int(device) >= 0:                  # negative ordinals: workers without a GPU (the pool's own CPU tests)
+            os.environ.pop("IRN_MIOPEN_DB_SET", None)    # the parent's claim is the parent's: this process makes its own
+            miopen_setup(int(device))                    # stable per-device database, never shared by two live processes
             torch.cuda.set_device(int(device))
         res_q.put((rank, "ready", None))
         while True:
@@ -255,6 +316,7 @@ def spawn_workers(work, model, shards, args):
             multiprocessing.spawn(work, nprocs=n, args=(model, shards, args), join=True)
         return
     if n == 1 and not getattr(args, "always_use_workers", False):
+        miopen_setup(devs[0])               # the same MIOpen settings a pool worker would run with
         work(0, model, shards, args)        # same code path, no second process needed for a single GPU
         return
     get_pool(devs).run(work, model, shards, args, timeout_s=step_timeout(args))
@@ -342,7 +404,7 @@ class CamStore:
     def _key(name, cam_out_dir):
         return (os.path.abspath(cam_out_dir) if cam_out_dir else "", name)
 
-    def put(self, name, keys_cpu, keys_dev, cam, cam_out_dir=None):
+    def put(self, name, keys_cpu, keys_dev, cam, cam_out_dir=None, run_id=None):
         key = self._key(name, cam_out_dir)
         nbytes = cam.numel() * cam.element_size()
         old = self._items.pop(key, None)
@@ -353,15 +415,19 @@ class CamStore:
             self._bytes -= dropped[2].numel() * dropped[2].element_size()
         if nbytes > self._max:
             return
-        self._items[key] = (keys_cpu, keys_dev, cam)
+        self._items[key] = (keys_cpu, keys_dev, cam, run_id)
         self._bytes += nbytes
 
-    def get(self, name, cam_out_dir, device):
-        """-> (keys int64 on the CPU, keys on the device, cam fp32 [K,h,w] on the device)."""
-        hit = self._items.get(self._key(name, cam_out_dir))
-        if hit is not None and hit[2].device == device:
+    def get(self, name, cam_out_dir, device, run_id=None, use_store=True):
+        """-> (keys int64 on the CPU, keys on the device, cam fp32 [K,h,w] on the device).  An entry is served only when
+        the caller allows it (`use_store`: args.keep_cams_on_device) and it was made by the make_cam run whose stamp the
+        output directory carries now (`run_id` = `current_cam_run(cam_out_dir)`): a later make_cam of the same directory —
+        in this process, in another pool, with another worker layout — rewrote the files, and this worker's older CAMs
+        must not answer for them."""
+        hit = self._items.get(self._key(name, cam_out_dir)) if use_store else None
+        if hit is not None and hit[2].device == device and hit[3] is not None and hit[3] == run_id:
             self.hits += 1
-            return hit
+            return hit[:3]
         self.misses += 1
         d = np.load(os.path.join(cam_out_dir, name + ".npy"), allow_pickle=True).item()
         keys = torch.as_tensor(d["keys"])
@@ -383,6 +449,29 @@ class CamStore:
 
 
 CAM_STORE = CamStore()
+_RUN_STAMP = ".irn_cam_run"
+
+
+def new_cam_run(cam_out_dir):
+    """make_cam.run: stamp the output directory with a fresh run id (and return it); the CAMs kept on the device carry
+    it, the label steps compare it with the directory's."""
+    import uuid
+    run_id = uuid.uuid4().hex
+    os.makedirs(cam_out_dir, exist_ok=True)
+    tmp = os.path.join(cam_out_dir, _RUN_STAMP + ".tmp%d" % os.getpid())
+    with open(tmp, "w") as f:
+        f.write(run_id)
+    os.replace(tmp, os.path.join(cam_out_dir, _RUN_STAMP))
+    return run_id
+
+
+def current_cam_run(cam_out_dir):
+    """The run id make_cam last stamped `cam_out_dir` with, or None (CAM files written by something else)."""
+    try:
+        with open(os.path.join(cam_out_dir, _RUN_STAMP)) as f:
+            return f.read().strip() or None
+    except OSError:
+        return None
 
 
 def keep_cams(args):

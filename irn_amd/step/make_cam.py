@@ -53,7 +53,7 @@ def _flush_group(model, group, scales, args, writer, store):
         keys_cpu = torch.nonzero(g["label"])[:, 0]
         keys, cam, high_res = merge_scales([o[i] for o in outs], g["size"], g["label"])
         if store is not None:
-            store.put(g["name"], keys_cpu, keys, cam, cam_out_dir=args.cam_out_dir)
+            store.put(g["name"], keys_cpu, keys, cam, cam_out_dir=args.cam_out_dir, run_id=getattr(args, "cam_run_id", None))
         n_cam, n_hi = cam.numel() * 4, high_res.numel() * 4
         staging = _common.PINNED.take(n_cam + n_hi)
         cam_view = staging[:n_cam].view(torch.float32).view(cam.shape)
@@ -122,6 +122,7 @@ def run(args):
     names = [voc12_dataloader.decode_int_filename(v) for v in dataset.img_name_list]
     dataset = torchutils.split_dataset(dataset, n_gpus)
     os.makedirs(args.cam_out_dir, exist_ok=True)
+    args.cam_run_id = _common.new_cam_run(args.cam_out_dir)      # device-held CAMs of earlier runs of this directory go stale
     print("[ ", end="")
     _common.spawn_workers(_work, model, dataset, args)
     print("]")

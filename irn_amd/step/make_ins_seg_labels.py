@@ -97,12 +97,13 @@ def _work(process_id, model, dataset, args):
             dev = torch.device("cuda", dev_id)
             walker = _common.make_walker(args, RADIUS)
             pend, in_flight = [], [None]
+            cam_run, use_store = _common.current_cam_run(args.cam_out_dir), _common.keep_cams(args)
             for it, pack in enumerate(loader):
                 name = pack["name"][0]
                 if not isinstance(name, str):
                     name = voc12_dataloader.decode_int_filename(name)
                 size = (int(pack["size"][0]), int(pack["size"][1]))
-                keys, _keys_dev, cam = _common.CAM_STORE.get(name, args.cam_out_dir, dev)
+                keys, _keys_dev, cam = _common.CAM_STORE.get(name, args.cam_out_dir, dev, cam_run, use_store)
                 pend.append({"name": name, "size": size, "img": _common.device_images(pack, (1.0,))[0],
                              "cam": cam, "keys": keys})
                 if len(pend) == batch:

@@ -107,13 +107,14 @@ def _work(process_id, model, dataset, args):
             # a batch is enqueued and left running while the loop gathers the next one (decoded images from the loader
             # threads, their uploads, the CAMs); it is collected just before the next batch is enqueued
             pend, running = [], None
+            cam_run, use_store = _common.current_cam_run(args.cam_out_dir), _common.keep_cams(args)
             for it, pack in enumerate(loader):
                 name = pack["name"][0]
                 if not isinstance(name, str):
                     name = voc12_dataloader.decode_int_filename(name)
                 size = (int(pack["size"][0]), int(pack["size"][1]))
                 # CAM of this image: still on the device when make_cam ran in this process, else from its file
-                _keys, keys_dev, cam = _common.CAM_STORE.get(name, args.cam_out_dir, dev)
+                _keys, keys_dev, cam = _common.CAM_STORE.get(name, args.cam_out_dir, dev, cam_run, use_store)
                 pend.append({"name": name, "size": size, "img": _common.device_images(pack, (1.0,))[0],
                              "cam": cam, "keys_dev": keys_dev})
                 if len(pend) == batch:

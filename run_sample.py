@@ -61,10 +61,10 @@ def build_parser():
                    help="images per random-walk launch (not in the reference); 0 = the step's default (64 sem-seg, 32 ins-seg)")
     p.add_argument("--walk_accel", default=None, type=int, choices=(0, 1),
                    help="random-walk schedule (not in the reference): 1 = x.T^(2^exp_times) as a truncated Chebyshev series of the "
-                        "operator (78 applications at exp_times 8; the default), 0 = the reference's own 2^exp_times applications "
+                        "operator (84 applications at exp_times 8; the default), 0 = the reference's own 2^exp_times applications "
                         "(misc/indexing.py:136-137).  Unset: the environment variable IRN_WALK_ACCEL, else 1")
     p.add_argument("--walk_accel_tol_exp", default=0, type=int,
-                   help="truncation bound 10^-e of the series (0 = the library default, e = 6; 7 = 84 applications)")
+                   help="truncation bound 10^-e of the series (0 = the library default, e = 7; 6 = 78 applications: +7 %, may flip an argmax at an exact tie)")
     p.add_argument("--step_timeout", default=0.0, type=float,
                    help="seconds a step may take in its worker processes before the pool is stopped and the step raises "
                         "(0 = no limit; also IRN_STEP_TIMEOUT_S)")

@@ -1,5 +1,5 @@
 """GPU parity of the walk's polynomial schedule (round 3): x . T^n evaluated as a truncated Chebyshev series
-(78 operator applications instead of 256 at exp_times = 8 with the default truncation bound 1e-6, 84 at 1e-7; irn_amd/csrc/walk.hip header, include/irn_hip.h).
+(84 operator applications instead of 256 at exp_times = 8 with the default truncation bound 1e-7, 78 at 1e-6; irn_amd/csrc/walk.hip header, include/irn_hip.h).
 
 What has to hold: (a) the accelerated walk is as close to the fp64 oracle of the reference's operator
 (misc/indexing.py:141-165) as the plain iteration — both far inside the 1e-4 bar — with identical argmax, on every
@@ -47,16 +47,15 @@ def _inputs(shapes, seed0):
 
 def test_schedule_lengths():
     wk = _walker(10)
-    assert wk.steps(256) == 78 and wk.steps(16) == 16 and wk.steps(0) == 0
+    assert wk.steps(256) == 84 and wk.steps(16) == 16 and wk.steps(0) == 0
     assert wk.steps(128) < 70 and wk.steps(1024) < 200
-    wk.set_option("accel_tol_exp", 7)
-    assert wk.steps(256) == 84
+    wk.set_option("accel_tol_exp", 6)
+    assert wk.steps(256) == 78
     wk.set_option("accel", 0)
     assert wk.steps(256) == 256
     wk.set_option("accel", 1)
     wk.set_option("accel_tol_exp", 9)
     assert 84 < wk.steps(256) <= 100
-    wk.set_option("accel_tol_exp", 6)
     wk.close()
 
 
@@ -83,12 +82,26 @@ def test_accelerated_walk_vs_fp64_oracle_and_plain_iteration(r, shapes, variant)
         eb = np.abs(b[i].cpu().numpy() - st).max()
         worst = (max(worst[0], ea), max(worst[1], eb))
         assert ea <= TOL_F64 and eb <= TOL_F64, (shapes[i], ea, eb)
-        assert (a[i] - b[i]).abs().max().item() <= 6e-6, shapes[i]
+        assert (a[i] - b[i]).abs().max().item() <= 4e-6, shapes[i]
         assert np.array_equal(np.argmax(a[i].cpu().numpy()[:, 0], 0), np.argmax(st[:, 0], 0)), shapes[i]
     print("variant %d radius %d: max |series - fp64| %.2e, max |plain - fp64| %.2e" % (variant, r, worst[0], worst[1]))
-    assert worst[0] <= 2.0 * worst[1] + 1.5e-6       # rounding + the series' truncation bound (1e-6)
+    assert worst[0] <= 2.0 * worst[1] + 5e-7
+    # the looser truncation bound (option accel_tol_exp = 6: 78 applications, +7 %): inside every numeric bar, but its grid
+    # argmax may differ from the oracle's at exact-tie level (one pixel of the 128x128 two-class image at radius 5 in
+    # round 4's session 1) — counted here, and the reason it is an option and not the default
+    loose = _walker(r, variant, accel_tol_exp=6)
+    c6 = loose(edges, cams, beta=10, exp_times=8)
+    loose.check()
+    flips = 0
+    for i, (h, w, c) in enumerate(shapes):
+        st = O.propagate_to_edge_stencil(synth.cam_blobs(c, h, w, seed=900 + i), synth.edge_field(h, w, seed=900 + i), r, 10, 8)
+        got = c6[i].cpu().numpy()
+        assert np.abs(got - st).max() <= TOL_F64, shapes[i]
+        flips += _stress.argmax_mismatch_is_tie(got[:, 0], st[:, 0], 2e-5)
+    print("variant %d radius %d, truncation bound 1e-6: %d grid-argmax pixel(s) differ from the oracle's, all ties below 2e-5" % (variant, r, flips))
     fast.close()
     plain.close()
+    loose.close()
 
 
 @pytest.mark.parametrize("r,shapes", [
@@ -201,14 +214,14 @@ def _stress_exact(r):
 @pytest.mark.parametrize("variant", [2, 1, 0])
 def test_schedule_on_adversarial_fields(r, variant):
     """Where the series' maths is stressed (tests/_stress.py: edge = 0, edge = 0.999, Bernoulli 0/1 edges, a one-pixel wall,
-    beta 1 / 8 / 10 / 20, white-noise CAMs), every kernel variant, default truncation bound, the tighter one (1e-7) and
-    the plain iteration: <= 1e-5 from the fp64 oracle, <= 1e-4 after division by the maximum (the epilogue's scale, the
+    beta 1 / 8 / 10 / 20, white-noise CAMs), every kernel variant, default truncation bound (1e-7), the looser option (1e-6)
+    and the plain iteration: <= 1e-5 from the fp64 oracle, <= 1e-4 after division by the maximum (the epilogue's scale, the
     north star's bar), argmax equal except at ties.  The measured triples are printed: on flat-spectrum operators the
     series is several times FURTHER from the exact product than the plain iteration (3e-7 against 5e-8 with no edges at
     all), on the structured ones closer; both are two orders inside the bar."""
     cases = _stress_exact(r)
     rows = []
-    for opts in ({}, {"accel_tol_exp": 7}, {"accel": 0}):
+    for opts in ({}, {"accel_tol_exp": 6}, {"accel": 0}):
         wk = _walker(r, variant, **opts)
         for beta in sorted({b for _, b, _, _, _ in cases}):
             sel = [c for c in cases if c[1] == beta]
@@ -226,9 +239,9 @@ def test_schedule_on_adversarial_fields(r, variant):
         wk.close()
     for name in [c[0] for c in cases]:
         e = {k: (a, b, t) for n, k, a, b, t in rows if n == name}
-        print("variant %d radius %2d %-20s series(1e-6) %.2e  series(1e-7) %.2e  plain %.2e   normalised %.2e / %.2e / %.2e   argmax ties %d/%d/%d" % (
-            variant, r, name, e[()][0], e[(("accel_tol_exp", 7),)][0], e[(("accel", 0),)][0],
-            e[()][1], e[(("accel_tol_exp", 7),)][1], e[(("accel", 0),)][1], e[()][2], e[(("accel_tol_exp", 7),)][2], e[(("accel", 0),)][2]))
+        print("variant %d radius %2d %-20s series(1e-7) %.2e  series(1e-6) %.2e  plain %.2e   normalised %.2e / %.2e / %.2e   argmax ties %d/%d/%d" % (
+            variant, r, name, e[()][0], e[(("accel_tol_exp", 6),)][0], e[(("accel", 0),)][0],
+            e[()][1], e[(("accel_tol_exp", 6),)][1], e[(("accel", 0),)][1], e[()][2], e[(("accel_tol_exp", 6),)][2], e[(("accel", 0),)][2]))
 
 
 def test_walk_accel_switch_of_the_wrapper(monkeypatch):
@@ -239,10 +252,10 @@ def test_walk_accel_switch_of_the_wrapper(monkeypatch):
     wk = indexing.RandomWalk(5, _dev())
     assert wk.steps(256) == 256
     wk.set_option("accel", 1)
-    assert wk.steps(256) == 78
+    assert wk.steps(256) == 84
     wk.close()
     monkeypatch.setenv("IRN_WALK_ACCEL", "1")
-    monkeypatch.setenv("IRN_WALK_ACCEL_TOL_EXP", "7")
+    monkeypatch.setenv("IRN_WALK_ACCEL_TOL_EXP", "6")
     wk = indexing.RandomWalk(5, _dev())
-    assert wk.steps(256) == 84
+    assert wk.steps(256) == 78
     wk.close()

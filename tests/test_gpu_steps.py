@@ -343,11 +343,11 @@ def test_bench_contract_one_json_line():
     assert rf["bound"] == "fp32_vector" and rf["unit"] == "TFLOP/s" and rf["peak"] == 157.3
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9 and 0 < rf["frac"] < 1 and "traffic" in rf
     assert rf["hbm_equivalent"]["unit"] == "GB/s" and rf["hbm_equivalent"]["peak"] == 8000.0
-    # `achieved` counts the flops the kernel executes (78 applications of the operator for T^256 at the default truncation bound); 8(d)'s F beside it
+    # `achieved` counts the flops the kernel executes (84 applications of the operator for T^256 at the default truncation bound); 8(d)'s F beside it
     sch = rf["schedule"]
-    assert sch["n_sweeps"] == 256 and sch["operator_applications"] == 78 and rf["sweeps_per_launch"] == 78
+    assert sch["n_sweeps"] == 256 and sch["operator_applications"] == 84 and rf["sweeps_per_launch"] == 84
     pe = rf["power_equivalent"]
-    assert abs(pe["achieved"] / rf["achieved"] - 256.0 / 78.0) < 1e-6 and abs(pe["flops"] / rf["flops_per_launch"] - 256.0 / 78.0) < 1e-6
+    assert abs(pe["achieved"] / rf["achieved"] - 256.0 / 84.0) < 1e-6 and abs(pe["flops"] / rf["flops_per_launch"] - 256.0 / 84.0) < 1e-6
     lp = r["label_parity"]
     assert lp["images"] == 2 and lp["not_a_tie"] == 0 and lp["pixels_differing"] <= 16 * lp["images"] and lp["max_top2_gap"] < 1e-4
     assert abs(r["value"] - 2 * 8 / (r["ms_per_step"] * 2e-3)) / r["value"] < 1e-6

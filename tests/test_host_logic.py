@@ -1,5 +1,7 @@
 """Host-side mirrors: backbones reproduce the reference's forward on the same seeded weights,
 sharding partitions the dataset, small helpers match."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -274,37 +276,51 @@ def test_thread_loader_collates_like_dataloader(tmp_path):
 def test_cam_store_hit_and_file_fallback(tmp_path):
     """step/_common.CamStore: a CAM put by make_cam is handed to the label steps from memory; anything else comes from the
     `.npy` the reference's make_cam writes (step/make_cam.py:55-56) — same values either way.  Entries belong to ONE
-    output directory and a later put replaces an earlier one (a second make_cam run must never be answered with the
-    first run's CAMs)."""
+    output directory AND to one make_cam run: a later put replaces an earlier one, and an entry of a run the directory
+    no longer carries the stamp of (make_cam ran again somewhere else) is never served."""
     from irn_amd.step import _common
     store = _common.CamStore(max_bytes=1 << 20)
     dev = torch.device("cpu")
     keys = torch.tensor([3, 7])
     cam = torch.rand(2, 8, 9)
     np.save(tmp_path / "2008_000001.npy", {"keys": keys, "cam": cam, "high_res": np.zeros((2, 32, 36), np.float32)})
-    store.put("2008_000001", keys, keys.clone(), cam.clone(), cam_out_dir=str(tmp_path))
-    k_cpu, k_dev, c = store.get("2008_000001", str(tmp_path), dev)
+    run1 = _common.new_cam_run(str(tmp_path))
+    assert _common.current_cam_run(str(tmp_path)) == run1 and _common.current_cam_run(str(tmp_path / "nowhere")) is None
+    store.put("2008_000001", keys, keys.clone(), cam.clone(), cam_out_dir=str(tmp_path), run_id=run1)
+    k_cpu, k_dev, c = store.get("2008_000001", str(tmp_path), dev, run1)
     assert store.hits == 1 and store.misses == 0 and torch.equal(k_cpu, keys) and torch.equal(c, cam)
+    # keep_cams_on_device off: the store is not consulted
+    store.get("2008_000001", str(tmp_path), dev, run1, use_store=False)
+    assert store.hits == 1 and store.misses == 1
     # a second run with other weights: same name, new values -> the new ones are served
     cam2 = torch.rand(2, 8, 9)
-    store.put("2008_000001", keys, keys.clone(), cam2.clone(), cam_out_dir=str(tmp_path))
-    assert torch.equal(store.get("2008_000001", str(tmp_path), dev)[2], cam2) and len(store) == 1
+    store.put("2008_000001", keys, keys.clone(), cam2.clone(), cam_out_dir=str(tmp_path), run_id=run1)
+    assert torch.equal(store.get("2008_000001", str(tmp_path), dev, run1)[2], cam2) and len(store) == 1
     assert store._bytes == cam2.numel() * 4
+    # make_cam ran again for this directory in ANOTHER process (new stamp, new file): this store's entry is stale
+    run2 = _common.new_cam_run(str(tmp_path))
+    assert run2 != run1
+    cam_new = torch.rand(2, 8, 9)
+    np.save(tmp_path / "2008_000001.npy", {"keys": keys, "cam": cam_new, "high_res": np.zeros((2, 32, 36), np.float32)})
+    got = store.get("2008_000001", str(tmp_path), dev, _common.current_cam_run(str(tmp_path)))
+    assert torch.equal(got[2], cam_new) and store.misses == 2
+    # an entry without a stamp (or a directory without one) is never a hit
+    assert torch.equal(store.get("2008_000001", str(tmp_path), dev, None)[2], cam_new) and store.misses == 3
     # the same name under another output directory is another entry: served from ITS file
     other = tmp_path / "other"
     other.mkdir()
     cam3 = torch.rand(2, 8, 9)
     np.save(other / "2008_000001.npy", {"keys": keys, "cam": cam3, "high_res": np.zeros((2, 32, 36), np.float32)})
-    assert torch.equal(store.get("2008_000001", str(other), dev)[2], cam3) and store.misses == 1
+    assert torch.equal(store.get("2008_000001", str(other), dev, run2)[2], cam3) and store.misses == 4
     store.drop_dir(str(tmp_path))
     assert len(store) == 0 and store._bytes == 0
-    k_cpu, k_dev, c = store.get("2008_000001", str(tmp_path), dev)
-    assert store.misses == 2 and torch.equal(k_cpu, keys) and torch.equal(k_dev, keys) and torch.equal(c, cam)
+    k_cpu, k_dev, c = store.get("2008_000001", str(tmp_path), dev, run2)
+    assert store.misses == 5 and torch.equal(k_cpu, keys) and torch.equal(k_dev, keys) and torch.equal(c, cam_new)
     big = torch.zeros(1, 1024, 1024)                       # 4 MB > the 1 MB cap: not kept, never an error
-    store.put("big", keys[:1], keys[:1], big, cam_out_dir=str(tmp_path))
+    store.put("big", keys[:1], keys[:1], big, cam_out_dir=str(tmp_path), run_id=run2)
     assert len(store) == 0
     for i in range(40):                                    # 40 x 36 KB > 1 MB: the oldest entries leave
-        store.put("n%d" % i, keys, keys, torch.zeros(1, 96, 96), cam_out_dir=str(tmp_path))
+        store.put("n%d" % i, keys, keys, torch.zeros(1, 96, 96), cam_out_dir=str(tmp_path), run_id=run2)
     assert store._bytes <= 1 << 20 and ("%s" % tmp_path, "n39") in store._items and ("%s" % tmp_path, "n0") not in store._items
 
 
@@ -437,3 +453,33 @@ def test_model_spec_is_built_once_per_checkpoint_version(tmp_path):
     b = _common.materialise(spec)
     assert b is not a and torch.equal(b.state_dict()["classifier.weight"], sd["classifier.weight"])
     assert sum(1 for k in _common._MODELS if k[2] == os.path.abspath(path)) == 1                         # the old version was dropped
+
+
+def test_miopen_setup_is_stable_seeded_and_exclusive(tmp_path, monkeypatch):
+    """One MIOpen user database per (device, HIP version, device ordinal), stable across runs, seeded from the package's
+    shipped database when empty, and never shared by two live processes (a second claimant gets a private copy)."""
+    import subprocess
+    import sys
+    from irn_amd.step import _common
+    for k in ("IRN_MIOPEN_DB_SET", "IRN_MIOPEN_BASE", "MIOPEN_USER_DB_PATH", "MIOPEN_FIND_MODE"):
+        monkeypatch.delenv(k, raising=False)
+    monkeypatch.setenv("IRN_MIOPEN_CACHE", str(tmp_path))
+    monkeypatch.setattr(_common, "_MIOPEN_LOCKS", [])
+    d0 = _common.miopen_setup(0)
+    key = _common.miopen_cache_key()
+    assert d0 == os.path.join(str(tmp_path), key, "dev0") and os.environ["MIOPEN_USER_DB_PATH"] == d0
+    assert os.environ["MIOPEN_FIND_MODE"] == "2" and _common.miopen_setup(0) == d0
+    open(os.path.join(d0, "gfx950_256.ufdb.txt"), "w").write("found")
+    # a second live process on the same device: private copy of what the first one has, removed when it exits
+    code = ("import os, sys; sys.path.insert(0, %r); from irn_amd.step import _common; d = _common.miopen_setup(0); "
+            "print(d); print(sorted(os.listdir(d)))" % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    env = {k: v for k, v in os.environ.items() if k not in ("IRN_MIOPEN_DB_SET",)}
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-1500:]
+    d1, files = out.stdout.strip().splitlines()[-2:]
+    assert d1 == os.path.join(str(tmp_path), key, "dev0-pid%s" % d1.rsplit("pid", 1)[1]) and "gfx950_256.ufdb.txt" in files
+    assert not os.path.exists(d1)
+    # another ordinal is another directory; a user-chosen find mode survives
+    monkeypatch.delenv("IRN_MIOPEN_DB_SET")
+    monkeypatch.setenv("MIOPEN_FIND_MODE", "1")
+    assert _common.miopen_setup(3).endswith(os.path.join(key, "dev3")) and os.environ["MIOPEN_FIND_MODE"] == "1"

@@ -107,7 +107,7 @@ def test_recurrence_model_on_adversarial_fields(case):
     assert e_s <= 2e-6 and e_p <= 5e-6
     assert e_s / scale <= 1e-4
     _stress.argmax_mismatch_is_tie(s, exact, 2e-5)
-    # the looser truncation bound of the product's default (tol 1e-6, 78 applications at n = 256)
+    # the looser truncation bound offered as an option (tol 1e-6, 78 applications at n = 256)
     _, _, s6 = _model(edge, cam, 5, beta, tol_exp=6) if case in (0, 3, 6) else (None, None, None)
     if s6 is not None:
         e6 = np.abs(s6 - exact).max()

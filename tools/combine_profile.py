@@ -1,0 +1,32 @@
+"""Diagnostic (library built with -DIRN_PROF_COMBINE, e.g. IRN_HIP_LIB=irn_amd/lib/libirn_hip_diag.so): where the combine
+phase of a resident-walk step goes.  Stamps: [0] step start, [1] combine entry (behind the barrier that follows the partial
+sums), [2] every LDS read of the combine has landed, [3] its arithmetic is done; the next step's [0] closes the stores.
+usage: python tools/combine_profile.py <radius> <images> <channels>"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from irn_amd import synth
+from irn_amd.misc import indexing
+
+dev = torch.device("cuda", 0)
+r, nimg, cch = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
+h = w = 128
+edges = [torch.from_numpy(synth.edge_field(h, w, seed=i)).to(dev) for i in range(nimg)]
+cams = [torch.from_numpy(synth.cam_blobs(cch, h, w, seed=i)).to(dev) for i in range(nimg)]
+wk = indexing.RandomWalk(r, dev)
+wk.set_option("profile", 1)
+for _ in range(2):
+    wk(edges, cams, beta=10, n_sweeps=256)
+wk.check()
+n_steps = wk.steps(256) * cch
+p = wk.read_profile().astype(np.float64) * 0.01      # us
+for g in range(2):
+    q = p[g, 8:min(n_steps - 2, 246)]
+    period = np.diff(q[:, 0])
+    print("radius %d C=%d wg %d: step %.2f us = up to the combine %.2f + LDS reads %.2f + arithmetic %.2f + writes/stores (to next step start) %.2f" % (
+        r, cch, g, period.mean(), (q[:-1, 1] - q[:-1, 0]).mean(), (q[:-1, 2] - q[:-1, 1]).mean(), (q[:-1, 3] - q[:-1, 2]).mean(),
+        (q[1:, 0] - q[:-1, 3]).mean()))

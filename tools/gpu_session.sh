@@ -97,6 +97,10 @@ pmcsq)
   cd $R
   python tools/reduce_prof.py $OUT > $OUT/sq_summary.txt 2>&1; grep -E "resident_kernel|affinity_" $OUT/sq_summary.txt | cut -c1-40,96-200
   find $OUT -name "walk_counter_collection.csv" -delete ;;
+combineprof)
+  for cfg in "5 32 1" "5 32 2" "10 8 1" "10 8 3"; do IRN_HIP_LIB=$PWD/irn_amd/lib/libirn_hip_diag.so timeout 120 python tools/combine_profile.py $cfg 2>&1 | tail -2; done > $OUT/combine_profile.txt 2>&1; cat $OUT/combine_profile.txt ;;
+miopen)
+  bash tools/r4_miopen_ab.sh $OUT ${MIOPEN_ARGS:-} ;;
 stepprof)
   for lib in ${AB_LIBS:-libirn_hip.so}; do echo "== $lib"; bash tools/r4_profile.sh $OUT $lib; done > $OUT/step_profile.txt 2>&1; cat $OUT/step_profile.txt ;;
 ranks)

@@ -1,0 +1,79 @@
+#!/usr/bin/env python3
+"""Fill MIOpen's find database for the shape set of the label-generation steps and ship it with the package.
+
+    python tools/miopen_warmup.py [--out irn_amd/data/miopen] [--batch 8] [--sizes 512x512,375x500] [--find-mode 1]
+
+Runs the CAM network at the four scales (image + flip pairs, `--batch` pairs per trunk pass like make_cam) and the IRNet
+forward (`--batch` padded images per pass like the label steps) with MIOpen's FIND api enabled (PyTorch's
+`cudnn.benchmark`, MIOPEN_FIND_MODE = `--find-mode`: 1 = normal find, every applicable solver is timed) into a fresh
+user database, then copies that database to `<out>/<device name>-hip<version>/`.  `irn_amd/step/_common.py:miopen_setup`
+seeds every worker's database from there, so a fresh process finds measured solvers instead of the immediate-mode
+heuristic without paying the find itself (MIOPEN_FIND_MODE=2 in the steps: database first).  The backbones stay on
+PyTorch-ROCm / MIOpen (reference net/resnet50_cam.py:55-70); this only persists what MIOpen measured."""
+import argparse
+import os
+import shutil
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--out", default=os.path.join(ROOT, "irn_amd", "data", "miopen"))
+    ap.add_argument("--batch", type=int, default=8)
+    ap.add_argument("--sizes", default="512x512")
+    ap.add_argument("--find-mode", default="1")
+    ap.add_argument("--channels-last", type=int, default=0)
+    a = ap.parse_args()
+    db = tempfile.mkdtemp(prefix="irn_miopen_warm_")
+    os.environ["MIOPEN_USER_DB_PATH"] = db
+    os.environ["MIOPEN_FIND_MODE"] = a.find_mode
+    os.environ["IRN_MIOPEN_DB_SET"] = db                      # keep miopen_setup out of the way
+    import torch
+    from irn_amd.net import resnet50_cam, resnet50_irn, weights
+    from irn_amd.step import _common
+    torch.backends.cudnn.benchmark = True
+    dev = torch.device("cuda", 0)
+    cam = resnet50_cam.CAM()
+    cam.load_state_dict(weights.random_cam_state(1))
+    cam = cam.to(dev).eval()
+    irn = resnet50_irn.EdgeDisplacement()
+    irn.load_state_dict(weights.random_irn_state(2), strict=False)
+    irn = irn.to(dev).eval()
+    t0 = time.time()
+    with torch.no_grad():
+        for size in a.sizes.split(","):
+            h, w = (int(v) for v in size.split("x"))
+            for s in (1.0, 0.5, 1.5, 2.0):
+                hs, ws = int(round(h * s)), int(round(w * s))
+                for b in sorted({a.batch, 1}):
+                    x = torch.randn(2 * b, 3, hs, ws, device=dev)
+                    t1 = time.time()
+                    cam.forward_batch(x)
+                    torch.cuda.synchronize()
+                    print("cam   %4dx%-4d pairs %d: %.1f s" % (hs, ws, b, time.time() - t1), flush=True)
+            for b in sorted({a.batch, 1}):
+                imgs = [torch.randn(2, 3, h, w, device=dev) for _ in range(b)]
+                t1 = time.time()
+                irn.forward_batch(imgs)
+                torch.cuda.synchronize()
+                print("irnet %4dx%-4d images %d: %.1f s" % (h, w, b, time.time() - t1), flush=True)
+    key = _common.miopen_cache_key()
+    dst = os.path.join(a.out, key)
+    os.makedirs(dst, exist_ok=True)
+    n = 0
+    for f in os.listdir(db):
+        if os.path.isfile(os.path.join(db, f)) and not f.startswith("."):
+            shutil.copy2(os.path.join(db, f), os.path.join(dst, f))
+            n += 1
+            print("  %s  %d bytes" % (f, os.path.getsize(os.path.join(dst, f))))
+    print("find database of %s: %d file(s) -> %s (%.0f s)" % (key, n, dst, time.time() - t0))
+    shutil.rmtree(db, ignore_errors=True)
+
+
+if __name__ == "__main__":
+    main()
