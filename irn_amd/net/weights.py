@@ -44,40 +44,45 @@ def random_irn_state(seed=2):
     return _fill(EdgeDisplacement(), seed).state_dict()
 
 
-class skip_param_init:
-    """Context manager: build a network without running the random initialisers of its parameters (0.2-0.3 s per ResNet-50 on
-    the host) — for modules whose every parameter is about to be overwritten by a checkpoint.  Buffers and constant
-    initialisers run as usual.  `load_checkpoint` below falls back to the normal construction when a checkpoint turns out
-    not to cover every parameter."""
-    _NAMES = ("kaiming_uniform_", "kaiming_normal_", "uniform_", "normal_", "xavier_uniform_", "xavier_normal_", "trunc_normal_")
-
-    def __enter__(self):
-        import torch.nn.init as init
-        self._saved = {n: getattr(init, n) for n in self._NAMES}
-        for n in self._NAMES:
-            setattr(init, n, lambda tensor, *a, **k: tensor)
-        return self
-
-    def __exit__(self, *exc):
-        import torch.nn.init as init
-        for n, f in self._saved.items():
-            setattr(init, n, f)
-        return False
+def _meta_build_covered(factory, state):
+    """factory() on the `meta` device (no storage, no initialiser runs, nothing global is patched — safe beside other
+    threads that build modules) and whether `state` covers every parameter and buffer of it."""
+    with torch.device("meta"):
+        model = factory()
+    own = dict(model.state_dict())
+    covered = all(k in state and tuple(state[k].shape) == tuple(v.shape) for k, v in own.items())
+    return model, covered
 
 
 def load_checkpoint(factory, path, strict):
     """`factory()` with the state dict at `path` loaded — what the steps do at the start of `run(args)` (reference
-    step/make_cam.py:63-65: construct, torch.load, load_state_dict, eval) without paying for an initialisation that the
-    checkpoint overwrites, and reading the file through a memory map when its format allows."""
+    step/make_cam.py:63-65: construct, torch.load, load_state_dict, eval) without paying for a random initialisation
+    that the checkpoint overwrites (0.2-0.3 s per ResNet-50 on the host), and reading the file through a memory map when
+    its format allows.  The network is built on the `meta` device and materialised from the checkpoint's tensors
+    (`load_state_dict(assign=True)`); a checkpoint that does not cover every parameter and buffer (a partial one, or
+    another architecture) goes through the regular construction + `load_state_dict`, errors and all."""
     try:
         state = torch.load(path, map_location="cpu", mmap=True, weights_only=True)
-    except Exception:
-        state = torch.load(path, map_location="cpu")
-    with skip_param_init():
+    except (RuntimeError, ValueError, TypeError) as e:      # a legacy (non-zip) file cannot be memory-mapped
+        if "mmap" not in str(e).lower():
+            raise
+        state = torch.load(path, map_location="cpu", weights_only=True)
+    model, covered = _meta_build_covered(factory, state)
+    if covered:
+        # assign=True makes the checkpoint's own tensors the parameters (clone: a memory-mapped file must be releasable,
+        # and aliased entries of the reference's state dicts — stage1.0 == resnet50.conv1 — must stay ONE parameter)
+        seen = {}
+        own = {}
+        for k, v in state.items():
+            key = (v.data_ptr(), tuple(v.shape))
+            if key not in seen:
+                seen[key] = v.clone()
+            own[k] = seen[key]
+        model.load_state_dict(own, strict=strict, assign=True)
+        if any(p.is_meta for p in model.parameters()) or any(b.is_meta for b in model.buffers()):
+            covered = False                                  # something the state dict does not name (non-persistent buffer)
+    if not covered:
         model = factory()
-    result = model.load_state_dict(state, strict=strict)
-    if getattr(result, "missing_keys", None):
-        model = factory()                                   # a partial checkpoint: the rest keeps its regular initialisation
         model.load_state_dict(state, strict=strict)
     model.eval()
     return model
