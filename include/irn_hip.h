@@ -251,6 +251,13 @@ int irn_msf_pack(const uint8_t *img_dev, int h, int w, int n_scales, const int32
 int irn_bn_act(float *x_dev, const float *res_dev, const float *scale_dev, const float *shift_dev, const float *res_scale_dev,
                const float *res_shift_dev, int64_t n_images, int n_channels, int64_t plane_elems, int relu, void *stream);
 
+/* The same pass over a channels-last tensor: x dev fp32 [n_pixels, n_channels] (= an [N, C, H, W] tensor in
+ * torch.channels_last memory format, n_pixels = N*H*W), n_channels a multiple of 4, constants 16-byte aligned.  Same
+ * arithmetic (one fmaf per element), same reference lines (net/resnet50.py:11-14, :34-54); for a trunk whose convolutions
+ * run on MIOpen's NHWC solvers (IRN_CHANNELS_LAST=1). */
+int irn_bn_act_nhwc(float *x_dev, const float *res_dev, const float *scale_dev, const float *shift_dev, const float *res_scale_dev,
+                    const float *res_shift_dev, int64_t n_pixels, int n_channels, int relu, void *stream);
+
 /* Stem: batch norm + ReLU + max pool 3x3 / stride 2 / pad 1 in one pass (reference net/resnet50.py:94-97; the nets'
  * stage1, net/resnet50_cam.py:14, net/resnet50_irn.py:15).
  *   x dev fp32 [n_images, n_channels, h, w] (conv1's output) -> out dev fp32 [n_images, n_channels, (h-1)/2+1, (w-1)/2+1]

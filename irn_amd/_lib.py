@@ -57,6 +57,7 @@ _SIGS = {
     "irn_bicubic_resize_u8": (i32, [vp, i32, i32, i32, i32, i32, vp, vp, vp]),
     "irn_msf_pack": (i32, [vp, i32, i32, i32, pi32, pi32, vp, ppv, vp, vp]),
     "irn_bn_act": (i32, [vp, vp, vp, vp, vp, vp, i64, i32, i64, i32, vp]),
+    "irn_bn_act_nhwc": (i32, [vp, vp, vp, vp, vp, vp, i64, i32, i32, vp]),
     "irn_stem_pool": (i32, [vp, vp, vp, i64, i32, i32, i32, vp, vp]),
     "irn_upsample_bilinear": (i32, [vp, i64, i32, i32, i32, i32, vp, vp]),
     "irn_find_centroids": (i32, [vp, i32, i32, i32, vp, vp]),

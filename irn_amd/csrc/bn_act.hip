@@ -122,6 +122,61 @@ __global__ void bn_act_tail_kernel(float *__restrict__ x, const float *__restric
     x[e] = y;
 }
 
+// The same pass over a channels-last tensor ([n_pixels, n_ch] in memory, n_ch a multiple of 4): the four elements of a
+// 16-byte piece are four consecutive channels of one pixel, so the constants come as 16-byte loads too and no piece
+// straddles anything.  (For the trunk run with `IRN_CHANNELS_LAST=1`: MIOpen's NHWC solvers.)
+template <int RES, bool RELU>
+__global__ __launch_bounds__(kThreads) void bn_act_nhwc_kernel(float *__restrict__ x, const float *__restrict__ res,
+                                                               const float *__restrict__ scale, const float *__restrict__ shift,
+                                                               const float *__restrict__ res_scale, const float *__restrict__ res_shift,
+                                                               unsigned n_pieces, unsigned n_ch, Div by_ch) {
+    constexpr bool HAS_RES = RES != 0;
+    const unsigned base = blockIdx.x * (unsigned)(kThreads * kPieces) + threadIdx.x;
+    f4v v[kPieces], r[kPieces];
+#pragma unroll
+    for (int j = 0; j < kPieces; ++j) {
+        const unsigned p = base + j * kThreads;
+        if (p < n_pieces) {
+            v[j] = load_piece(x, p);
+            if (HAS_RES) r[j] = load_piece(res, p);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < kPieces; ++j) {
+        const unsigned p = base + j * kThreads;
+        if (p >= n_pieces) continue;
+        const unsigned e = p * 4u;
+        const unsigned c0 = e - div_by(e, by_ch) * n_ch;          // multiple of 4
+        const f4v s = load_piece(scale, c0 >> 2), b = load_piece(shift, c0 >> 2);
+        f4v rs, rb;
+        if (RES == 2) {
+            rs = load_piece(res_scale, c0 >> 2);
+            rb = load_piece(res_shift, c0 >> 2);
+        }
+        f4v o;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float y = fmaf(v[j][k], s[k], b[k]);
+            if (RES == 1) y += r[j][k];
+            if (RES == 2) y += fmaf(r[j][k], rs[k], rb[k]);
+            if (RELU) y = y < 0.f ? 0.f : y;
+            o[k] = y;
+        }
+        reinterpret_cast<f4v *>(x)[p] = o;
+    }
+}
+
+template <int RES, bool RELU>
+int launch_nhwc(float *x, const float *res, const float *scale, const float *shift, const float *res_scale, const float *res_shift,
+                unsigned numel, unsigned n_ch, hipStream_t stream) {
+    const unsigned n_pieces = numel / 4u;
+    const unsigned blocks = (n_pieces + kThreads * kPieces - 1) / (kThreads * kPieces);
+    hipLaunchKernelGGL((bn_act_nhwc_kernel<RES, RELU>), dim3(blocks), dim3(kThreads), 0, stream, x, res, scale, shift, res_scale,
+                       res_shift, n_pieces, n_ch, make_div(n_ch));
+    IRN_LAUNCH_CHECK("bn_act_nhwc_kernel");
+    return IRN_OK;
+}
+
 template <int RES, bool RELU>
 int launch(float *x, const float *res, const float *scale, const float *shift, const float *res_scale, const float *res_shift,
            unsigned numel, unsigned hw, unsigned n_ch, hipStream_t stream) {
@@ -163,6 +218,32 @@ extern "C" int irn_bn_act(float *x_dev, const float *res_dev, const float *scale
 #define IRN_BN_ACT_CASE(RES_MODE)                                                                                                   \
     return relu ? launch<RES_MODE, true>(x_dev, res_dev, scale_dev, shift_dev, res_scale_dev, res_shift_dev, n, hw, n_ch, s)       \
                 : launch<RES_MODE, false>(x_dev, res_dev, scale_dev, shift_dev, res_scale_dev, res_shift_dev, n, hw, n_ch, s)
+    if (mode == 0) IRN_BN_ACT_CASE(0);
+    if (mode == 1) IRN_BN_ACT_CASE(1);
+    IRN_BN_ACT_CASE(2);
+#undef IRN_BN_ACT_CASE
+}
+
+extern "C" int irn_bn_act_nhwc(float *x_dev, const float *res_dev, const float *scale_dev, const float *shift_dev,
+                               const float *res_scale_dev, const float *res_shift_dev, int64_t n_pixels, int n_channels, int relu,
+                               void *stream) {
+    using namespace irn;
+    if (!x_dev || !scale_dev || !shift_dev) return fail(IRN_ERR_ARG, "irn_bn_act_nhwc: null pointer");
+    if ((res_scale_dev != nullptr) != (res_shift_dev != nullptr) || (res_scale_dev && !res_dev))
+        return fail(IRN_ERR_ARG, "irn_bn_act_nhwc: res_scale and res_shift come together, and only with a residual");
+    if (n_pixels < 0 || n_channels <= 0 || (n_channels & 3)) return fail(IRN_ERR_ARG, "irn_bn_act_nhwc: n_channels must be a positive multiple of 4");
+    if (((uintptr_t)x_dev | (uintptr_t)res_dev | (uintptr_t)scale_dev | (uintptr_t)shift_dev | (uintptr_t)res_scale_dev |
+         (uintptr_t)res_shift_dev) & 15u)
+        return fail(IRN_ERR_ARG, "irn_bn_act_nhwc: tensors and constants must be 16-byte aligned");
+    const int64_t numel = n_pixels * n_channels;
+    if (numel == 0) return IRN_OK;
+    if (numel >= (1ll << 31)) return fail(IRN_ERR_ARG, "irn_bn_act_nhwc: %lld elements; at most 2^31 - 1 per call", (long long)numel);
+    const unsigned n_ch = (unsigned)n_channels, n = (unsigned)numel;
+    hipStream_t s = (hipStream_t)stream;
+    const int mode = !res_dev ? 0 : (res_scale_dev ? 2 : 1);
+#define IRN_BN_ACT_CASE(RES_MODE)                                                                                                   \
+    return relu ? launch_nhwc<RES_MODE, true>(x_dev, res_dev, scale_dev, shift_dev, res_scale_dev, res_shift_dev, n, n_ch, s)      \
+                : launch_nhwc<RES_MODE, false>(x_dev, res_dev, scale_dev, shift_dev, res_scale_dev, res_shift_dev, n, n_ch, s)
     if (mode == 0) IRN_BN_ACT_CASE(0);
     if (mode == 1) IRN_BN_ACT_CASE(1);
     IRN_BN_ACT_CASE(2);

@@ -27,10 +27,44 @@ STAGE_PLANES = (64, 128, 256, 512)
 FUSED_EPILOGUE = os.environ.get("IRN_FUSED_EPILOGUE", "1") != "0"
 
 
+# IRN_CHANNELS_LAST=1: the four stages of the trunk run on channels-last activations (MIOpen's NHWC solvers; only worth it
+# with a find database that was TUNED for those shapes: tools/miopen_warmup.py --channels-last 1).  The stem stays NCHW
+# (a 3-channel input), its pooled output is converted once; whoever consumes a stage's output in NCHW converts it back.
+CHANNELS_LAST = os.environ.get("IRN_CHANNELS_LAST", "0") == "1"
+
+
+def _dense(x):
+    """contiguous in NCHW or (4-D) in channels-last order"""
+    return x.is_contiguous() or (x.dim() == 4 and x.is_contiguous(memory_format=torch.channels_last))
+
+
 def _fused(x):
     # irn_bn_act walks the tensor in 16-byte pieces: an offset view of another tensor takes the composed ops instead
-    return (FUSED_EPILOGUE and x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and x.data_ptr() % 16 == 0
+    return (FUSED_EPILOGUE and x.is_cuda and x.dtype == torch.float32 and _dense(x) and x.data_ptr() % 16 == 0
             and not torch.is_grad_enabled())
+
+
+def to_stage_format(x):
+    """Activation entering a trunk stage: channels-last when that mode is on (inference path only)."""
+    if CHANNELS_LAST and x.is_cuda and x.dim() == 4 and not torch.is_grad_enabled():
+        return x.contiguous(memory_format=torch.channels_last)
+    return x
+
+
+def to_nchw(x):
+    """A stage's output for a consumer that wants NCHW (heads, hand-written kernels, the CAM merge)."""
+    return x if x.is_contiguous() else x.contiguous()
+
+
+def apply_memory_format(model):
+    """Convert the convolution weights of every bottleneck to channels-last once (mode on), so that MIOpen is not handed a
+    re-laid-out copy per call."""
+    if CHANNELS_LAST:
+        for m in model.modules():
+            if isinstance(m, Bottleneck):
+                for c in [m.conv1, m.conv2, m.conv3] + ([m.downsample[0]] if m.downsample is not None else []):
+                    c.weight.data = c.weight.data.contiguous(memory_format=torch.channels_last)
+    return model
 
 
 def _version(t):
@@ -66,7 +100,7 @@ class FrozenBatchNorm(nn.BatchNorm2d):
         """act(forward(x) (+ r)) with r = residual, or residual_bn.forward(residual) when a second layer is given (the
         projection shortcut's batch norm); overwrites x on the inference path (x must be a tensor nobody else reads: the
         output of the convolution in front of this layer)."""
-        if _fused(x) and (residual is None or (residual.is_contiguous() and residual.dtype == x.dtype and residual.data_ptr() % 16 == 0)):
+        if _fused(x) and (residual is None or (residual.dtype == x.dtype and residual.data_ptr() % 16 == 0 and residual.stride() == x.stride())):
             from .. import ops          # the HIP library; raises if it has not been built — there is no other GPU path
             scale, shift = self.folded()
             return ops.bn_act_(x, scale, shift, residual, relu, None if residual_bn is None else residual_bn.folded())
@@ -80,7 +114,7 @@ def stem(conv1, bn1, maxpool, x):
     """conv1 -> bn1 -> ReLU -> maxpool (net/resnet50.py:94-97); on the inference path everything behind the convolution is
     one pass (`ops.stem_pool`) when the pool is the trunk's 3x3 / stride 2 / pad 1."""
     y = conv1(x)
-    if _fused(y) and (maxpool.kernel_size, maxpool.stride, maxpool.padding, maxpool.dilation, maxpool.ceil_mode) == (3, 2, 1, 1, False):
+    if _fused(y) and y.is_contiguous() and (maxpool.kernel_size, maxpool.stride, maxpool.padding, maxpool.dilation, maxpool.ceil_mode) == (3, 2, 1, 1, False):
         from .. import ops
         return ops.stem_pool(y, *bn1.folded())
     return maxpool(bn1.apply_(y, relu=True))
@@ -93,7 +127,10 @@ class Stem(nn.Sequential):
 
     def forward(self, x):
         x = stem(self[0], self[1], self[3], x)
-        for m in list(self)[4:]:
+        rest = list(self)[4:]
+        if rest:
+            x = to_stage_format(x)
+        for m in rest:
             x = m(x)
         return x
 
@@ -148,7 +185,7 @@ class ResNet50Trunk(nn.Module):
             c_in = planes * Bottleneck.expansion
 
     def forward(self, x):
-        x = stem(self.conv1, self.bn1, self.maxpool, x)
+        x = to_stage_format(stem(self.conv1, self.bn1, self.maxpool, x))
         return self.layer4(self.layer3(self.layer2(self.layer1(x))))
 
 

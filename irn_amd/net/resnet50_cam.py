@@ -40,11 +40,11 @@ class CAM(Net):
     relu(1x1 conv with the classifier weights), original + flipped-back (net/resnet50_cam.py:55-70)."""
 
     def forward(self, x):
-        a = F.relu(F.conv2d(self.features(x), self.classifier.weight))
+        a = _r50.to_nchw(F.relu(F.conv2d(self.features(x), self.classifier.weight)))
         return a[0] + a[1].flip(-1)
 
     def forward_batch(self, x):
         """[2B,3,H,W] = B (image, h-flipped image) pairs of ONE size back to back -> [B,20,h,w]: the forward above for
         every pair in one pass of the trunk (the steps stack the images of a size group per scale)."""
-        a = F.relu(F.conv2d(self.features(x), self.classifier.weight))
+        a = _r50.to_nchw(F.relu(F.conv2d(self.features(x), self.classifier.weight)))
         return a[0::2] + a[1::2].flip(-1)

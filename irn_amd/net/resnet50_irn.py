@@ -94,10 +94,12 @@ class Net(nn.Module):
 
     def forward(self, x):
         f1 = self.stage1(x).detach()        # the trunk is frozen (net/resnet50_irn.py:111-115)
-        f2 = self.stage2(f1).detach()
+        f2 = self.stage2(_r50.to_stage_format(f1)).detach()
         f3 = self.stage3(f2).detach()
         f4 = self.stage4(f3).detach()
         f5 = self.stage5(f4).detach()
+        if _r50.CHANNELS_LAST:              # the heads (GroupNorm, the hand-written upsampling) take NCHW
+            f2, f3, f4, f5 = (_r50.to_nchw(f) for f in (f2, f3, f4, f5))
 
         e2 = self.fc_edge2(f2)
         eh, ew = e2.shape[2:]

@@ -116,9 +116,12 @@ def bn_act_(x, scale, shift, residual=None, relu=True, residual_affine=None):
     residual, or ``residual * rs[c] + rb[c]`` with ``residual_affine = (rs, rb)`` (the projection shortcut's batch norm).
     x, residual: GPU fp32 [N, C, ...] contiguous; scale, shift, rs, rb: GPU fp32 [C].  Returns x."""
     _need_cuda(x, "x")
-    if x.dtype != torch.float32 or not x.is_contiguous() or x.dim() < 2:
-        raise ValueError("bn_act_: x must be a contiguous fp32 [N, C, ...] tensor, got %s %s" % (x.dtype, tuple(x.shape)))
+    nhwc = x.dim() == 4 and not x.is_contiguous() and x.is_contiguous(memory_format=torch.channels_last)
+    if x.dtype != torch.float32 or not (x.is_contiguous() or nhwc) or x.dim() < 2:
+        raise ValueError("bn_act_: x must be a contiguous (or channels-last) fp32 [N, C, ...] tensor, got %s %s" % (x.dtype, tuple(x.shape)))
     n_ch = int(x.shape[1])
+    if nhwc and n_ch % 4:
+        raise ValueError("bn_act_: a channels-last tensor needs a multiple of 4 channels, got %d" % n_ch)
     consts = [("scale", scale), ("shift", shift)]
     if residual_affine is not None:
         if residual is None:
@@ -128,9 +131,20 @@ def bn_act_(x, scale, shift, residual=None, relu=True, residual_affine=None):
         if t.device != x.device or t.dtype != torch.float32 or not t.is_contiguous() or t.numel() != n_ch:
             raise ValueError("bn_act_: %s must be a contiguous fp32 [%d] tensor on %s" % (name, n_ch, x.device))
     if residual is not None and (residual.shape != x.shape or residual.dtype != torch.float32 or residual.device != x.device
-                                 or not residual.is_contiguous()):
-        raise ValueError("bn_act_: residual must match x (shape %s, fp32, contiguous, same device)" % (tuple(x.shape),))
+                                 or not (residual.is_contiguous(memory_format=torch.channels_last) if nhwc else residual.is_contiguous())):
+        raise ValueError("bn_act_: residual must match x (shape %s, fp32, same memory format, same device)" % (tuple(x.shape),))
     n_img = int(x.shape[0])
+    if nhwc:
+        rs, rb = (None, None) if residual_affine is None else (residual_affine[0].data_ptr(), residual_affine[1].data_ptr())
+        px = int(x.shape[2]) * int(x.shape[3])
+        per = max(1, (2 ** 31 - 1) // max(1, n_ch * px))
+        with torch.cuda.device(x.device):
+            for i in range(0, n_img, per):
+                xi = x[i:i + per]
+                ri = None if residual is None else residual[i:i + per]
+                check(lib.irn_bn_act_nhwc(xi.data_ptr(), None if ri is None else ri.data_ptr(), scale.data_ptr(), shift.data_ptr(),
+                                          rs, rb, int(xi.shape[0]) * px, n_ch, 1 if relu else 0, _stream()))
+        return x
     plane = x[0, 0].numel() if n_img else 0
     rs, rb = (None, None) if residual_affine is None else (residual_affine[0].data_ptr(), residual_affine[1].data_ptr())
     # the entry point takes at most 2^31 - 1 elements: larger batches go image group by image group

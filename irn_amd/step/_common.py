@@ -60,7 +60,8 @@ def materialise(model):
     if net is None:
         for k in [k for k in _MODELS if k[:3] == key[:3]]:      # an older version of the same checkpoint: let it go
             del _MODELS[k]
-        net = _MODELS[key] = model.build()
+        from ..net import resnet50 as _r50
+        net = _MODELS[key] = _r50.apply_memory_format(model.build())     # (a no-op unless IRN_CHANNELS_LAST=1)
     return net
 
 

@@ -363,3 +363,81 @@ def test_module_folding_equals_the_oracle_folding():
     s, b = O.fold_batch_norm(bn.weight.detach().numpy(), bn.bias.detach().numpy(), bn.running_mean.numpy(), bn.running_var.numpy(), bn.eps)
     sd, bd = bn.to(dev).folded()
     assert np.array_equal(sd.cpu().numpy(), s) and np.array_equal(bd.cpu().numpy(), b)
+
+
+@pytest.mark.parametrize("shape", [(2, 8, 16, 16), (3, 64, 7, 9), (1, 2048, 2, 3), (2, 256, 33, 47), (4, 4, 1, 5)])
+@pytest.mark.parametrize("mode", ["plain", "residual", "residual_bn"])
+@pytest.mark.parametrize("relu", [False, True])
+def test_bn_act_channels_last_equals_nchw_bitwise(shape, mode, relu):
+    """irn_bn_act_nhwc (the pass over a torch.channels_last tensor, for the trunk on MIOpen's NHWC solvers): one fmaf per
+    element with the same constants, so it must equal the NCHW pass bit for bit, residual forms included."""
+    from irn_amd import ops
+    x, res, scale, shift = _case(shape, 11, mode != "plain")
+    g = torch.Generator().manual_seed(5)
+    aff = None
+    if mode == "residual_bn":
+        aff = ((torch.rand(shape[1], generator=g) + 0.5).to(_dev()), torch.randn(shape[1], generator=g).to(_dev()))
+    scale, shift = scale.to(_dev()), shift.to(_dev())
+    a = ops.bn_act_(x.to(_dev()).clone(), scale, shift, None if res is None else res.to(_dev()), relu, aff)
+    xc = x.to(_dev()).contiguous(memory_format=torch.channels_last)
+    rc = None if res is None else res.to(_dev()).contiguous(memory_format=torch.channels_last)
+    assert not xc.is_contiguous() or 1 in shape[2:]
+    b = ops.bn_act_(xc, scale, shift, rc, relu, aff)
+    assert b.data_ptr() == xc.data_ptr() and b.stride() == xc.stride()
+    assert torch.equal(a, b.contiguous())
+
+
+def test_bn_act_channels_last_refusals():
+    from irn_amd import ops
+    x = torch.randn(2, 6, 5, 5, device=_dev()).contiguous(memory_format=torch.channels_last)     # 6 channels: not a multiple of 4
+    s = torch.ones(6, device=_dev())
+    with pytest.raises(ValueError):
+        ops.bn_act_(x, s, s)
+    x = torch.randn(2, 8, 5, 5, device=_dev()).contiguous(memory_format=torch.channels_last)
+    s = torch.ones(8, device=_dev())
+    with pytest.raises(ValueError):
+        ops.bn_act_(x, s, s, torch.randn(2, 8, 5, 5, device=_dev()))                             # residual in another memory format
+
+
+_CL_SCRIPT = """
+import os, sys
+sys.path.insert(0, %r)
+import numpy as np, torch
+from irn_amd.net import resnet50 as r50, resnet50_cam, resnet50_irn, weights
+assert r50.CHANNELS_LAST == (os.environ.get("IRN_CHANNELS_LAST") == "1")
+dev = torch.device("cuda", 0)
+g = torch.Generator().manual_seed(3)
+x = torch.randn(4, 3, 160, 208, generator=g).to(dev)
+cam = resnet50_cam.CAM(); cam.load_state_dict(weights.random_cam_state(1)); cam = r50.apply_memory_format(cam.to(dev).eval())
+irn = resnet50_irn.EdgeDisplacement(); irn.load_state_dict(weights.random_irn_state(2), strict=False)
+irn = r50.apply_memory_format(irn.to(dev).eval())
+with torch.no_grad():
+    c = cam.forward_batch(x)
+    e = irn.forward_batch([x[:2], x[2:, :, :150, :199]])
+np.savez(sys.argv[1], cam=c.cpu().numpy(), e0=e[0][0].cpu().numpy(), d0=e[0][1].cpu().numpy(), e1=e[1][0].cpu().numpy(), d1=e[1][1].cpu().numpy())
+"""
+
+
+def test_backbones_channels_last_mode_equals_nchw(tmp_path):
+    """IRN_CHANNELS_LAST=1 (the trunk's stages on channels-last activations, everything around them converted at the
+    seams) gives the CAM and IRNet outputs of the default NCHW run up to MIOpen's choice of solver."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "cl.py"
+    script.write_text(_CL_SCRIPT % root)
+    outs = {}
+    for mode in ("0", "1"):
+        env = dict(os.environ, IRN_CHANNELS_LAST=mode)
+        out = subprocess.run([sys.executable, str(script), str(tmp_path / ("m%s.npz" % mode))], env=env, capture_output=True,
+                             text=True, timeout=600)
+        assert out.returncode == 0, out.stderr[-2000:]
+        outs[mode] = np.load(tmp_path / ("m%s.npz" % mode))
+    worst = {}
+    for k in outs["0"].files:
+        a, b = outs["0"][k], outs["1"][k]
+        scale = max(float(np.abs(a).max()), 1e-6)
+        worst[k] = float(np.abs(a - b).max()) / (scale if k == "cam" else 1.0)
+    print("channels-last vs NCHW trunk: max deviation", {k: "%.2e" % v for k, v in worst.items()})
+    assert worst["cam"] <= 1e-4 and max(worst["e0"], worst["e1"]) <= 1e-4 and max(worst["d0"], worst["d1"]) <= 2e-3

@@ -28,11 +28,15 @@ def main():
     ap.add_argument("--sizes", default="512x512")
     ap.add_argument("--find-mode", default="1")
     ap.add_argument("--channels-last", type=int, default=0)
+    ap.add_argument("--single", type=int, default=1, help="also the one-pair / one-image shapes (the tail of a shard)")
+    ap.add_argument("--suffix", default="", help="appended to the output directory's key (e.g. -nhwc)")
     a = ap.parse_args()
     db = tempfile.mkdtemp(prefix="irn_miopen_warm_")
     os.environ["MIOPEN_USER_DB_PATH"] = db
     os.environ["MIOPEN_FIND_MODE"] = a.find_mode
     os.environ["IRN_MIOPEN_DB_SET"] = db                      # keep miopen_setup out of the way
+    if a.channels_last:
+        os.environ["IRN_CHANNELS_LAST"] = "1"
     import torch
     from irn_amd.net import resnet50_cam, resnet50_irn, weights
     from irn_amd.step import _common
@@ -40,29 +44,30 @@ def main():
     dev = torch.device("cuda", 0)
     cam = resnet50_cam.CAM()
     cam.load_state_dict(weights.random_cam_state(1))
-    cam = cam.to(dev).eval()
+    from irn_amd.net import resnet50 as _r50
+    cam = _r50.apply_memory_format(cam.to(dev).eval())
     irn = resnet50_irn.EdgeDisplacement()
     irn.load_state_dict(weights.random_irn_state(2), strict=False)
-    irn = irn.to(dev).eval()
+    irn = _r50.apply_memory_format(irn.to(dev).eval())
     t0 = time.time()
     with torch.no_grad():
         for size in a.sizes.split(","):
             h, w = (int(v) for v in size.split("x"))
             for s in (1.0, 0.5, 1.5, 2.0):
                 hs, ws = int(round(h * s)), int(round(w * s))
-                for b in sorted({a.batch, 1}):
+                for b in sorted({a.batch} | ({1} if a.single else set())):
                     x = torch.randn(2 * b, 3, hs, ws, device=dev)
                     t1 = time.time()
                     cam.forward_batch(x)
                     torch.cuda.synchronize()
                     print("cam   %4dx%-4d pairs %d: %.1f s" % (hs, ws, b, time.time() - t1), flush=True)
-            for b in sorted({a.batch, 1}):
+            for b in sorted({a.batch} | ({1} if a.single else set())):
                 imgs = [torch.randn(2, 3, h, w, device=dev) for _ in range(b)]
                 t1 = time.time()
                 irn.forward_batch(imgs)
                 torch.cuda.synchronize()
                 print("irnet %4dx%-4d images %d: %.1f s" % (h, w, b, time.time() - t1), flush=True)
-    key = _common.miopen_cache_key()
+    key = _common.miopen_cache_key() + a.suffix
     dst = os.path.join(a.out, key)
     os.makedirs(dst, exist_ok=True)
     n = 0
