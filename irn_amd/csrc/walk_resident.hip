@@ -54,6 +54,9 @@ typedef const double IRN_GLOBAL *gcd_t;
 typedef float IRN_GLOBAL *gf_t;
 typedef float f4a __attribute__((ext_vector_type(4)));
 
+#ifndef IRN_PROF_COMBINE
+#define IRN_PROF_COMBINE 0     // diagnostic builds only (tools/combine_profile.py): 1 / 2 move the PROF stamps into the combine phase
+#endif
 #ifndef IRN_PS_LDS_BYTES
 #define IRN_PS_LDS_BYTES (96 * 1024)       // LDS spent on the recurrence's private terms: 48 channels at radius 10, 12 at radius 5
 #endif
@@ -628,7 +631,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             }
             __syncthreads();
             if (*abort_flag) return;
-#ifndef IRN_PROF_COMBINE
+#if IRN_PROF_COMBINE == 0
             if (PROF && pslot) pslot[1] = wall_clock64();
 #endif
 
@@ -690,9 +693,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 asm volatile("" : "+v"(wl));
                 *reinterpret_cast<f4a *>(partf + (k & 1) * (kWaves * 256) + wv * 256 + wl * 4) = f4a{acc[0], acc[1], acc[2], acc[3]};
                 __syncthreads();
-#ifndef IRN_PROF_COMBINE
+#if IRN_PROF_COMBINE == 0
                 if (PROF && pslot) pslot[2] = wall_clock64();
-#else
+#elif IRN_PROF_COMBINE == 1
                 if (PROF && pslot) pslot[1] = wall_clock64();          // diagnostic build: [1] = combine entry
 #endif
                 // One pixel per combining thread, consecutive threads = consecutive pixels of a tile row (their
@@ -724,7 +727,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     for (int q = 0; q < Q; ++q) ps[q] = pr[q * 256];
                     const float centre = xsb[(py + H) * LW + px + HP];
                     const double inv = invd[i];
-#ifdef IRN_PROF_COMBINE
+#if IRN_PROF_COMBINE == 1
                     if (PROF && pslot) {
                         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                         pslot[2] = wall_clock64();
@@ -744,10 +747,15 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                         else if (inimg && !last)
                             __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2v, nv), prs, (int)o * 8, c * ch_bytes, 0);
                     }
-#ifdef IRN_PROF_COMBINE
+#if IRN_PROF_COMBINE == 1
                     if (PROF && pslot) {
                         asm volatile("" : "+v"(outv));
                         pslot[3] = wall_clock64();
+                    }
+#elif IRN_PROF_COMBINE == 2
+                    if (PROF && pslot) {                                       // mode 2: [1] = arithmetic + LDS write done
+                        asm volatile("" : "+v"(outv));
+                        pslot[1] = wall_clock64();
                     }
 #endif
                     // neighbour lane's result through a DPP quad permute (lanes 2n <-> 2n+1) instead of an LDS round trip
@@ -816,7 +824,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                             iv0[it] = invd[ii];
                             iv1[it] = invd[ii + 1];
                         }
-#ifdef IRN_PROF_COMBINE
+#if IRN_PROF_COMBINE == 1
                         if (PROF && pslot) {                                   // [2] = every LDS read of the phase has landed
                             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                             pslot[2] = wall_clock64();
@@ -838,12 +846,19 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                             s0v[it] = fmaf(ck, r0v[it], pv[it].y);
                             s1v[it] = fmaf(ck, r1v[it], pv[it].w);
                         }
-#ifdef IRN_PROF_COMBINE
+#if IRN_PROF_COMBINE == 1
                         if (PROF && pslot) {                                   // [3] = the arithmetic of both iterations is done
 #pragma unroll
                             for (int it = 0; it < NIT; ++it)
                                 asm volatile("" : "+v"(r0v[it]), "+v"(r1v[it]), "+v"(s0v[it]), "+v"(s1v[it]));
                             pslot[3] = wall_clock64();
+                        }
+#elif IRN_PROF_COMBINE == 2
+                        if (PROF && pslot) {
+#pragma unroll
+                            for (int it = 0; it < NIT; ++it)
+                                asm volatile("" : "+v"(r0v[it]), "+v"(r1v[it]), "+v"(s0v[it]), "+v"(s1v[it]));
+                            pslot[1] = wall_clock64();
                         }
 #endif
                         __builtin_amdgcn_sched_barrier(0);
@@ -886,11 +901,14 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                     }
                 }
             }
+#if IRN_PROF_COMBINE == 2
+            if (PROF && pslot) pslot[2] = wall_clock64();                      // mode 2: [2] = LDS writes and global stores issued
+#endif
             fresh = false;
             // C = 1: the next poll is timed from our own stores, so every wave has to start its delay
             // behind them (the waves that do not combine would otherwise poll ~0.2 us early)
             if (C == 1) __syncthreads();
-#ifndef IRN_PROF_COMBINE
+#if IRN_PROF_COMBINE != 1
             if (PROF && pslot) pslot[3] = wall_clock64();
 #endif
             t = tn;

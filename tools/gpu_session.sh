@@ -98,7 +98,9 @@ pmcsq)
   python tools/reduce_prof.py $OUT > $OUT/sq_summary.txt 2>&1; grep -E "resident_kernel|affinity_" $OUT/sq_summary.txt | cut -c1-40,96-200
   find $OUT -name "walk_counter_collection.csv" -delete ;;
 combineprof)
-  for cfg in "5 32 1" "5 32 2" "10 8 1" "10 8 3"; do IRN_HIP_LIB=$PWD/irn_amd/lib/libirn_hip_diag.so timeout 120 python tools/combine_profile.py $cfg 2>&1 | tail -2; done > $OUT/combine_profile.txt 2>&1; cat $OUT/combine_profile.txt ;;
+  for m in ${DIAG_MODES:-1 2}; do for cfg in "5 32 1" "5 32 2" "10 8 1" "10 8 3"; do IRN_HIP_LIB=$PWD/irn_amd/lib/libirn_hip_diag$m.so timeout 120 python tools/combine_profile.py $cfg $m 2>&1 | tail -2; done; done > $OUT/combine_profile.txt 2>&1; cat $OUT/combine_profile.txt ;;
+chlast)
+  bash tools/r4_channels_last_ab.sh $OUT ;;
 miopen)
   bash tools/r4_miopen_ab.sh $OUT ${MIOPEN_ARGS:-} ;;
 stepprof)
