@@ -385,8 +385,7 @@ def run_backbone(a, workload, rank, world, device, dist, parallel, steps, warmup
     scales = (1.0, 0.5, 1.5, 2.0)
     cam_net = resnet50_cam.CAM()
     cam_net.load_state_dict(weights.random_cam_state(1))
-    from irn_amd.net import resnet50 as _r50
-    cam_net = _r50.apply_memory_format(cam_net.to(device).eval())
+    cam_net = cam_net.to(device).eval()
     # decoded uint8 images resident in HBM; the per-scale normalised (image, flip) pairs are built inside the timed
     # step by irn_msf_pack (Pillow-exact bicubic), like make_cam._work does for every loader item
     u8 = [torch.from_numpy(synth.photo(H, W, seed=1234 + rank * batch + i)).to(device) for i in range(batch)]
@@ -399,7 +398,7 @@ def run_backbone(a, workload, rank, world, device, dist, parallel, steps, warmup
     if workload == "e2e":
         irn = resnet50_irn.EdgeDisplacement()
         irn.load_state_dict(weights.random_irn_state(2), strict=False)
-        irn = _r50.apply_memory_format(irn.to(device).eval())
+        irn = irn.to(device).eval()
         walker = indexing.RandomWalk(10, device)
 
     def step():

@@ -27,10 +27,52 @@ STAGE_PLANES = (64, 128, 256, 512)
 FUSED_EPILOGUE = os.environ.get("IRN_FUSED_EPILOGUE", "1") != "0"
 
 
-# IRN_CHANNELS_LAST=1: the four stages of the trunk run on channels-last activations (MIOpen's NHWC solvers; only worth it
-# with a find database that was TUNED for those shapes: tools/miopen_warmup.py --channels-last 1).  The stem stays NCHW
-# (a 3-channel input), its pooled output is converted once; whoever consumes a stage's output in NCHW converts it back.
-CHANNELS_LAST = os.environ.get("IRN_CHANNELS_LAST", "0") == "1"
+# Layout of the trunk's four stages.  MIOpen's NHWC solvers beat its NCHW ones on this network — `cam` 97.4 -> 104.6,
+# `e2e` 81.1 -> 86.6 images/s (profiles/r04_s3_channels_last_ab.txt) — but ONLY for problems its find database was TUNED
+# for: an untuned NHWC problem falls to an immediate-mode pick that is 2.2x SLOWER than NCHW's (43.6 images/s).  So the
+# layout is chosen per input shape:
+#   IRN_CHANNELS_LAST = "auto" (default)  channels-last for the network-input shapes [n, H, W] listed in the find database
+#                                         shipped for this device (irn_amd/data/miopen/<key>/nhwc_shapes.json, written by
+#                                         tools/miopen_warmup.py --channels-last 1; step/_common.miopen_setup merges that
+#                                         database into the process's user database), NCHW for every other shape;
+#                       "1" / "0"          always / never.
+# The stem stays NCHW (a 3-channel input); its pooled output is converted once, and whoever consumes a stage's output in
+# NCHW (the IRNet heads, the CAM merge) converts it back.  Convolution weights stay as they are: PyTorch hands MIOpen a
+# re-laid-out copy per call (94 MB per forward, < 1 % of it).
+CHANNELS_LAST_MODE = os.environ.get("IRN_CHANNELS_LAST", "auto")
+_TUNED_SHAPES = None
+
+
+def tuned_nhwc_shapes():
+    """Network-input shapes (n, H, W) the shipped find database holds tuned NHWC solvers for (empty without a GPU or a
+    database for this device / HIP version)."""
+    global _TUNED_SHAPES
+    if _TUNED_SHAPES is None:
+        shapes = set()
+        try:
+            import json
+            from ..step import _common
+            path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "data", "miopen",
+                                _common.miopen_cache_key(), "nhwc_shapes.json")
+            if os.path.exists(path) and os.environ.get("IRN_MIOPEN_SEED", "1") != "0":
+                shapes = {tuple(int(v) for v in s) for s in json.load(open(path))}
+        except Exception:
+            shapes = set()
+        _TUNED_SHAPES = shapes
+    return _TUNED_SHAPES
+
+
+def channels_last_for(x):
+    """Does the trunk run channels-last for the network input `x` [n, 3, H, W]?  (inference path only)"""
+    if CHANNELS_LAST_MODE == "0" or not x.is_cuda or x.dim() != 4 or torch.is_grad_enabled():
+        return False
+    if CHANNELS_LAST_MODE == "1":
+        return True
+    # auto: only in a process whose MIOpen user database has been completed from the shipped one (step/_common.miopen_setup:
+    # the steps' workers, the in-process step path, bench.py) — anywhere else the NHWC problems would be untuned
+    if not os.environ.get("IRN_MIOPEN_DB_SET"):
+        return False
+    return (int(x.shape[0]), int(x.shape[2]), int(x.shape[3])) in tuned_nhwc_shapes()
 
 
 def _dense(x):
@@ -44,27 +86,14 @@ def _fused(x):
             and not torch.is_grad_enabled())
 
 
-def to_stage_format(x):
-    """Activation entering a trunk stage: channels-last when that mode is on (inference path only)."""
-    if CHANNELS_LAST and x.is_cuda and x.dim() == 4 and not torch.is_grad_enabled():
-        return x.contiguous(memory_format=torch.channels_last)
-    return x
+def to_stage_format(x, channels_last):
+    """Activation entering a trunk stage."""
+    return x.contiguous(memory_format=torch.channels_last) if channels_last else x
 
 
 def to_nchw(x):
     """A stage's output for a consumer that wants NCHW (heads, hand-written kernels, the CAM merge)."""
     return x if x.is_contiguous() else x.contiguous()
-
-
-def apply_memory_format(model):
-    """Convert the convolution weights of every bottleneck to channels-last once (mode on), so that MIOpen is not handed a
-    re-laid-out copy per call."""
-    if CHANNELS_LAST:
-        for m in model.modules():
-            if isinstance(m, Bottleneck):
-                for c in [m.conv1, m.conv2, m.conv3] + ([m.downsample[0]] if m.downsample is not None else []):
-                    c.weight.data = c.weight.data.contiguous(memory_format=torch.channels_last)
-    return model
 
 
 def _version(t):
@@ -126,10 +155,11 @@ class Stem(nn.Sequential):
     and the pool taken in one pass."""
 
     def forward(self, x):
+        cl = channels_last_for(x)
         x = stem(self[0], self[1], self[3], x)
         rest = list(self)[4:]
         if rest:
-            x = to_stage_format(x)
+            x = to_stage_format(x, cl)
         for m in rest:
             x = m(x)
         return x
@@ -185,7 +215,7 @@ class ResNet50Trunk(nn.Module):
             c_in = planes * Bottleneck.expansion
 
     def forward(self, x):
-        x = to_stage_format(stem(self.conv1, self.bn1, self.maxpool, x))
+        x = to_stage_format(stem(self.conv1, self.bn1, self.maxpool, x), channels_last_for(x))
         return self.layer4(self.layer3(self.layer2(self.layer1(x))))
 
 

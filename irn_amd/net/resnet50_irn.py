@@ -93,12 +93,13 @@ class Net(nn.Module):
                                         self.fc_dp5, self.fc_dp6, self.fc_dp7])
 
     def forward(self, x):
+        cl = _r50.channels_last_for(x)      # the trunk's stages on MIOpen's NHWC solvers where they are tuned (resnet50.py)
         f1 = self.stage1(x).detach()        # the trunk is frozen (net/resnet50_irn.py:111-115)
-        f2 = self.stage2(_r50.to_stage_format(f1)).detach()
+        f2 = self.stage2(_r50.to_stage_format(f1, cl)).detach()
         f3 = self.stage3(f2).detach()
         f4 = self.stage4(f3).detach()
         f5 = self.stage5(f4).detach()
-        if _r50.CHANNELS_LAST:              # the heads (GroupNorm, the hand-written upsampling) take NCHW
+        if cl:                              # the heads (GroupNorm, the hand-written upsampling) take NCHW
             f2, f3, f4, f5 = (_r50.to_nchw(f) for f in (f2, f3, f4, f5))
 
         e2 = self.fc_edge2(f2)

@@ -60,8 +60,7 @@ def materialise(model):
     if net is None:
         for k in [k for k in _MODELS if k[:3] == key[:3]]:      # an older version of the same checkpoint: let it go
             del _MODELS[k]
-        from ..net import resnet50 as _r50
-        net = _MODELS[key] = _r50.apply_memory_format(model.build())     # (a no-op unless IRN_CHANNELS_LAST=1)
+        net = _MODELS[key] = model.build()
     return net
 
 
@@ -110,6 +109,30 @@ def miopen_cache_key():
     return "%s-hip%s" % (name, (torch.version.hip or "none").replace("/", "_"))
 
 
+def merge_miopen_db(src_dir, dst_dir):
+    """Add to the MIOpen user database in `dst_dir` every entry of the one in `src_dir` that it does not have yet (the
+    find database `*.ufdb.txt` and the tuning database `*.udb.txt` are text files of `problem=solvers` lines; entries
+    already present — what this machine measured itself — win).  -> number of entries added.  The channels-last mode of
+    the trunk relies on this: an existing user database without the shipped NHWC entries would leave those problems
+    untuned, which is 2x slower than not using the layout at all."""
+    added = 0
+    for f in sorted(os.listdir(src_dir)):
+        if not (f.endswith(".ufdb.txt") or f.endswith(".udb.txt")):
+            continue
+        have = set()
+        dst = os.path.join(dst_dir, f)
+        if os.path.exists(dst):
+            with open(dst) as fh:
+                have = {line.split("=", 1)[0] for line in fh if "=" in line}
+        with open(os.path.join(src_dir, f)) as fh:
+            new = [line if line.endswith("\n") else line + "\n" for line in fh if "=" in line and line.split("=", 1)[0] not in have]
+        if new:
+            with open(dst, "a") as fh:
+                fh.writelines(new)
+            added += len(new)
+    return added
+
+
 _MIOPEN_LOCKS = []           # lock files held for the life of the process
 
 
@@ -121,8 +144,10 @@ def miopen_setup(device_ordinal):
       * stable across runs — `$IRN_MIOPEN_CACHE` or `~/.cache/irn_amd/miopen`, / (device name, HIP version) / dev<ordinal>
         — so that what one run's workers found the next run's workers reuse (each worker process used to start with
         a cold database named after its rank);
-      * seeded, when empty, from the database shipped with the package for this (device, HIP) pair
-        (`irn_amd/data/miopen/<key>/`, written on a GPU box by `tools/miopen_warmup.py`);
+      * completed from the database shipped with the package for this (device, HIP) pair (`irn_amd/data/miopen/<key>/`,
+        written on a GPU box by `tools/miopen_warmup.py`): every shipped entry the user database lacks is added
+        (`merge_miopen_db`), what this machine measured itself is kept — the trunk's channels-last layout, chosen per
+        input shape (net/resnet50.py), depends on the shipped NHWC entries being there;
       * never shared by two live processes: the directory is claimed with an advisory lock, and a process that finds
         it taken (a second job on the same host and GPU) works on a private copy `dev<ordinal>-pid<pid>` instead
         (eight workers appending to one database collided in round 2).
@@ -142,11 +167,6 @@ def miopen_setup(device_ordinal):
     key = miopen_cache_key()
     stable = os.path.join(base, key, "dev%d" % int(device_ordinal))
     os.makedirs(stable, exist_ok=True)
-    seed = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "data", "miopen", key)
-    if os.environ.get("IRN_MIOPEN_SEED", "1") != "0" and os.path.isdir(seed) and not any(f.endswith(".txt") or f.endswith(".db") for f in os.listdir(stable)):
-        for f in os.listdir(seed):
-            if os.path.isfile(os.path.join(seed, f)):
-                shutil.copy2(os.path.join(seed, f), os.path.join(stable, f))
     use = stable
     try:
         fh = open(os.path.join(stable, ".lock"), "w")
@@ -159,6 +179,9 @@ def miopen_setup(device_ordinal):
             if f != ".lock" and os.path.isfile(os.path.join(stable, f)):
                 shutil.copy2(os.path.join(stable, f), os.path.join(use, f))
         atexit.register(shutil.rmtree, use, True)
+    seed = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "data", "miopen", key)
+    if os.environ.get("IRN_MIOPEN_SEED", "1") != "0" and os.path.isdir(seed):
+        merge_miopen_db(seed, use)         # (after the claim: nobody else appends to `use` now)
     os.environ["MIOPEN_USER_DB_PATH"] = use
     os.environ["IRN_MIOPEN_DB_SET"] = use
     return use

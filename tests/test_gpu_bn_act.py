@@ -404,13 +404,13 @@ import os, sys
 sys.path.insert(0, %r)
 import numpy as np, torch
 from irn_amd.net import resnet50 as r50, resnet50_cam, resnet50_irn, weights
-assert r50.CHANNELS_LAST == (os.environ.get("IRN_CHANNELS_LAST") == "1")
+assert r50.CHANNELS_LAST_MODE == os.environ.get("IRN_CHANNELS_LAST")
 dev = torch.device("cuda", 0)
 g = torch.Generator().manual_seed(3)
 x = torch.randn(4, 3, 160, 208, generator=g).to(dev)
-cam = resnet50_cam.CAM(); cam.load_state_dict(weights.random_cam_state(1)); cam = r50.apply_memory_format(cam.to(dev).eval())
+cam = resnet50_cam.CAM(); cam.load_state_dict(weights.random_cam_state(1)); cam = cam.to(dev).eval()
 irn = resnet50_irn.EdgeDisplacement(); irn.load_state_dict(weights.random_irn_state(2), strict=False)
-irn = r50.apply_memory_format(irn.to(dev).eval())
+irn = irn.to(dev).eval()
 with torch.no_grad():
     c = cam.forward_batch(x)
     e = irn.forward_batch([x[:2], x[2:, :, :150, :199]])

@@ -58,7 +58,16 @@ def _rel(a, ref):
     return float(np.abs(a - ref).max() / max(1.0, np.abs(ref).max()))
 
 
-def test_cam_forward_on_device_vs_reference(golden):
+@pytest.fixture(params=["nchw", "channels_last"])
+def trunk_layout(request, monkeypatch):
+    """The backbones against the reference in BOTH layouts of the trunk: NCHW, and the four stages on channels-last
+    activations (MIOpen's NHWC solvers; net/resnet50.py picks it per input shape in production, forced here)."""
+    from irn_amd.net import resnet50 as r50
+    monkeypatch.setattr(r50, "CHANNELS_LAST_MODE", "1" if request.param == "channels_last" else "0")
+    return request.param
+
+
+def test_cam_forward_on_device_vs_reference(golden, trunk_layout):
     """a2: activation maps relative to their own scale (random weights give maps in the thousands), and — what the
     north star's 1e-4 is quoted on — the max-normalised CAM the step stores (step/make_cam.py:47-48)."""
     from irn_amd import synth
@@ -81,7 +90,7 @@ def test_cam_forward_on_device_vs_reference(golden):
             assert np.abs(norm(y) - norm(ref)).max() <= TOL_REF, tuple(x.shape)
 
 
-def test_cam_forward_batched_equals_reference(golden):
+def test_cam_forward_batched_equals_reference(golden, trunk_layout):
     """The steps stack several images per scale ([image, flip, image, flip, ...]); every pair of the batch must still
     be the reference's single-pair forward."""
     from irn_amd import synth
@@ -108,7 +117,7 @@ def test_cam_forward_batched_equals_reference(golden):
         assert _rel(y[1], gs[key + "_out"]) <= TOL_REF and np.abs(norm(y[1]) - norm(gs[key + "_out"])).max() <= TOL_REF, key
 
 
-def test_edge_displacement_on_device_vs_reference(golden):
+def test_edge_displacement_on_device_vs_reference(golden, trunk_layout):
     """a4: edge in (0,1) at 1e-4 absolute; displacement relative to its scale."""
     from irn_amd import synth
     g = golden("nets")
@@ -126,7 +135,7 @@ def test_edge_displacement_on_device_vs_reference(golden):
             assert _rel(dp, dp_ref) <= TOL_REF, (tuple(x.shape), _rel(dp, dp_ref))
 
 
-def test_edge_displacement_batched_ragged_equals_reference(golden):
+def test_edge_displacement_batched_ragged_equals_reference(golden, trunk_layout):
     """The label steps pad ragged images to the 512^2 crop and run ONE forward for the batch."""
     from irn_amd import synth
     g5 = golden("nets512")

@@ -483,3 +483,48 @@ def test_miopen_setup_is_stable_seeded_and_exclusive(tmp_path, monkeypatch):
     monkeypatch.delenv("IRN_MIOPEN_DB_SET")
     monkeypatch.setenv("MIOPEN_FIND_MODE", "1")
     assert _common.miopen_setup(3).endswith(os.path.join(key, "dev3")) and os.environ["MIOPEN_FIND_MODE"] == "1"
+
+
+def test_merge_miopen_db_adds_missing_entries_only(tmp_path):
+    """The shipped find database completes a user database: entries the user database lacks are appended, entries it has
+    (what this machine measured) are kept, other files are left alone."""
+    from irn_amd.step import _common
+    src, dst = tmp_path / "src", tmp_path / "dst"
+    src.mkdir()
+    dst.mkdir()
+    (src / "gfx.ufdb.txt").write_text("a-NCHW=solverA:1\nb-NHWC-NHWC-NHWC=solverB:2\n")
+    (src / "gfx.udb.txt").write_text("p=1,2,3")
+    (src / "nhwc_shapes.json").write_text("[[16, 512, 512]]")
+    (dst / "gfx.ufdb.txt").write_text("a-NCHW=mine:0.5\n")
+    assert _common.merge_miopen_db(str(src), str(dst)) == 2
+    assert (dst / "gfx.ufdb.txt").read_text() == "a-NCHW=mine:0.5\nb-NHWC-NHWC-NHWC=solverB:2\n"
+    assert (dst / "gfx.udb.txt").read_text() == "p=1,2,3\n" and not (dst / "nhwc_shapes.json").exists()
+    assert _common.merge_miopen_db(str(src), str(dst)) == 0
+
+
+def test_trunk_layout_is_chosen_per_input_shape(monkeypatch):
+    """auto: channels-last only for the network-input shapes the shipped find database was tuned for; 1 / 0 force it."""
+    from irn_amd.net import resnet50 as r50
+
+    class _T:                    # a tensor stand-in: only the attributes channels_last_for reads
+        def __init__(self, shape, cuda=True):
+            self.shape, self.is_cuda = shape, cuda
+
+        def dim(self):
+            return len(self.shape)
+
+    monkeypatch.setattr(r50, "_TUNED_SHAPES", {(16, 512, 512)})
+    with torch.no_grad():
+        monkeypatch.setattr(r50, "CHANNELS_LAST_MODE", "auto")
+        monkeypatch.delenv("IRN_MIOPEN_DB_SET", raising=False)
+        assert not r50.channels_last_for(_T((16, 3, 512, 512)))       # no miopen_setup in this process: the NHWC entries may be missing
+        monkeypatch.setenv("IRN_MIOPEN_DB_SET", "/somewhere")
+        assert r50.channels_last_for(_T((16, 3, 512, 512))) and not r50.channels_last_for(_T((16, 3, 375, 500)))
+        assert not r50.channels_last_for(_T((2, 3, 512, 512))) and not r50.channels_last_for(_T((16, 3, 512, 512), cuda=False))
+        monkeypatch.setattr(r50, "CHANNELS_LAST_MODE", "1")
+        assert r50.channels_last_for(_T((2, 3, 375, 500)))
+        monkeypatch.setattr(r50, "CHANNELS_LAST_MODE", "0")
+        assert not r50.channels_last_for(_T((16, 3, 512, 512)))
+    monkeypatch.setattr(r50, "CHANNELS_LAST_MODE", "1")
+    with torch.enable_grad():
+        assert not r50.channels_last_for(_T((16, 3, 512, 512)))       # the training seam keeps the composed NCHW path

@@ -99,6 +99,10 @@ pmcsq)
   find $OUT -name "walk_counter_collection.csv" -delete ;;
 combineprof)
   for m in ${DIAG_MODES:-1 2}; do for cfg in "5 32 1" "5 32 2" "10 8 1" "10 8 3"; do IRN_HIP_LIB=$PWD/irn_amd/lib/libirn_hip_diag$m.so timeout 120 python tools/combine_profile.py $cfg $m 2>&1 | tail -2; done; done > $OUT/combine_profile.txt 2>&1; cat $OUT/combine_profile.txt ;;
+warmvoc)
+  # tuned NHWC entries for the two image sizes that dominate VOC12 (500x375, 375x500), 8 images per trunk pass
+  T0=$(date +%s)
+  timeout 1200 python tools/miopen_warmup.py --channels-last 1 --single 0 --sizes ${VOC_SIZES:-375x500,500x375} --out $OUT/miopen_db_voc > $OUT/miopen_warmup_voc.log 2>&1; echo "VOC-size NHWC warm-up rc=$? wall $(( $(date +%s) - T0 )) s"; grep -E "^cam|^irnet|nhwc_shapes|find database" $OUT/miopen_warmup_voc.log ;;
 chlast)
   bash tools/r4_channels_last_ab.sh $OUT ;;
 miopen)

@@ -35,8 +35,7 @@ def main():
     os.environ["MIOPEN_USER_DB_PATH"] = db
     os.environ["MIOPEN_FIND_MODE"] = a.find_mode
     os.environ["IRN_MIOPEN_DB_SET"] = db                      # keep miopen_setup out of the way
-    if a.channels_last:
-        os.environ["IRN_CHANNELS_LAST"] = "1"
+    os.environ["IRN_CHANNELS_LAST"] = "1" if a.channels_last else "0"
     import torch
     from irn_amd.net import resnet50_cam, resnet50_irn, weights
     from irn_amd.step import _common
@@ -44,12 +43,12 @@ def main():
     dev = torch.device("cuda", 0)
     cam = resnet50_cam.CAM()
     cam.load_state_dict(weights.random_cam_state(1))
-    from irn_amd.net import resnet50 as _r50
-    cam = _r50.apply_memory_format(cam.to(dev).eval())
+    cam = cam.to(dev).eval()
     irn = resnet50_irn.EdgeDisplacement()
     irn.load_state_dict(weights.random_irn_state(2), strict=False)
-    irn = _r50.apply_memory_format(irn.to(dev).eval())
+    irn = irn.to(dev).eval()
     t0 = time.time()
+    shapes = set()
     with torch.no_grad():
         for size in a.sizes.split(","):
             h, w = (int(v) for v in size.split("x"))
@@ -57,12 +56,14 @@ def main():
                 hs, ws = int(round(h * s)), int(round(w * s))
                 for b in sorted({a.batch} | ({1} if a.single else set())):
                     x = torch.randn(2 * b, 3, hs, ws, device=dev)
+                    shapes.add((2 * b, hs, ws))
                     t1 = time.time()
                     cam.forward_batch(x)
                     torch.cuda.synchronize()
                     print("cam   %4dx%-4d pairs %d: %.1f s" % (hs, ws, b, time.time() - t1), flush=True)
             for b in sorted({a.batch} | ({1} if a.single else set())):
                 imgs = [torch.randn(2, 3, h, w, device=dev) for _ in range(b)]
+                shapes.add((2 * b, irn.crop_size, irn.crop_size))
                 t1 = time.time()
                 irn.forward_batch(imgs)
                 torch.cuda.synchronize()
@@ -70,12 +71,15 @@ def main():
     key = _common.miopen_cache_key() + a.suffix
     dst = os.path.join(a.out, key)
     os.makedirs(dst, exist_ok=True)
-    n = 0
-    for f in os.listdir(db):
-        if os.path.isfile(os.path.join(db, f)) and not f.startswith("."):
-            shutil.copy2(os.path.join(db, f), os.path.join(dst, f))
-            n += 1
-            print("  %s  %d bytes" % (f, os.path.getsize(os.path.join(dst, f))))
+    n = _common.merge_miopen_db(db, dst)                      # adds to what an earlier warm-up (the other layout) left there
+    for f in sorted(os.listdir(dst)):
+        print("  %s  %d bytes" % (f, os.path.getsize(os.path.join(dst, f))))
+    if a.channels_last:
+        import json
+        path = os.path.join(dst, "nhwc_shapes.json")
+        old = {tuple(v) for v in json.load(open(path))} if os.path.exists(path) else set()
+        json.dump(sorted(old | shapes), open(path, "w"))
+        print("  nhwc_shapes.json: %s" % sorted(old | shapes))
     print("find database of %s: %d file(s) -> %s (%.0f s)" % (key, n, dst, time.time() - t0))
     shutil.rmtree(db, ignore_errors=True)
 
