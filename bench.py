@@ -494,6 +494,7 @@ def run_steps(a, rank, world, device, dist, parallel, steps, warmup, batch=0):
 
         t_setup = time.perf_counter() - t_setup
         hits0, misses0 = _common.CAM_STORE.hits, _common.CAM_STORE.misses
+        e_hits0 = _common.EDGE_STORE.hits
         elapsed, _ = timed_loop(step, steps, warmup, dist, parallel, device)
         n_png = len([f for f in os.listdir(args.sem_seg_out_dir) if f.endswith(".png")])
         n_ins = len([f for f in os.listdir(args.ins_seg_out_dir) if f.endswith(".npy")])
@@ -501,7 +502,7 @@ def run_steps(a, rank, world, device, dist, parallel, steps, warmup, batch=0):
             raise RuntimeError("steps leg: %d label maps written for %d images" % (n_png, batch))
         return {"value": steps * batch * world / elapsed, "ms_per_step": 1e3 * elapsed / steps, "batch": batch,
                 "cam_store_hits": _common.CAM_STORE.hits - hits0, "cam_store_misses": _common.CAM_STORE.misses - misses0,
-                "loader_workers": args.num_workers, "instance_files": n_ins,
+                "edge_store_hits": _common.EDGE_STORE.hits - e_hits0, "loader_workers": args.num_workers, "instance_files": n_ins,
                 "through": "make_cam.run(args) + make_ins_seg_labels.run(args) + make_sem_seg_labels.run(args)",
                 "pass_seconds": [{k: round(v, 3) for k, v in p.items()} for p in passes[warmup:]], "setup_seconds": t_setup}
     finally:
@@ -680,7 +681,7 @@ def main(argv=None):
             res["config"].update({"variant": a.variant, "mean_channels": float(np.mean([s[2] for s in r["shapes"]])),
                                   "walk_self_checks": r.get("tuning")})
             res["label_checksum"] = r["label_checksum"]
-        for k in ("detections_per_image", "fallback_runs", "cam_store_hits", "cam_store_misses", "loader_workers", "pass_seconds", "instance_files", "through"):
+        for k in ("detections_per_image", "fallback_runs", "cam_store_hits", "cam_store_misses", "edge_store_hits", "loader_workers", "pass_seconds", "instance_files", "through"):
             if k in r:
                 res["config"][k] = r[k]
         res["cpu_baseline"] = None
@@ -704,7 +705,7 @@ def main(argv=None):
                     if "shapes" in lr:
                         ro = roofline_object(a, name, lr)
                         legs[name]["fp32_vector_frac"] = ro["frac"] if ro.get("bound") == "fp32_vector" else ro["fp32_vector"]["frac"]
-                    for k in ("detections_per_image", "cam_store_hits", "cam_store_misses", "loader_workers", "pass_seconds", "instance_files", "setup_seconds", "through", "n_applied"):
+                    for k in ("detections_per_image", "cam_store_hits", "cam_store_misses", "edge_store_hits", "loader_workers", "pass_seconds", "instance_files", "setup_seconds", "through", "n_applied"):
                         if k in lr:
                             legs[name][k] = lr[k]
                 except Exception as e:                      # a leg must never cost the headline line

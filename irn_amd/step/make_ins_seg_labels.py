@@ -71,7 +71,8 @@ def _flush(model, walker, pend, args, writer, in_flight):
     """Enqueue the batch in `pend`, then collect and write the batch before it (`in_flight`, a one-element list): its
     detections crossed PCIe while this batch's kernels were being enqueued and run."""
     if pend:
-        make_sem_seg_labels.edges_for(model, pend, int(getattr(args, "irn_batch", 0) or 8))
+        make_sem_seg_labels.edges_for(model, pend, int(getattr(args, "irn_batch", 0) or 8),
+                                      **make_sem_seg_labels._edge_store_kw(model, args))
         cur = ([it["name"] for it in pend],
                instance_labels_batch(walker, pend, float(args.beta), int(args.exp_times), float(args.ins_seg_bg_thres),
                                      deferred=True))
@@ -84,7 +85,10 @@ def _flush(model, walker, pend, args, writer, in_flight):
 
 
 def _work(process_id, model, dataset, args):
+    spec_key = model.key() if isinstance(model, _common.ModelSpec) else None
     model = _common.materialise(model)      # a network, or the (class, checkpoint) a worker builds it from
+    if spec_key is not None:
+        make_sem_seg_labels._MODEL_KEYS[id(model)] = spec_key
     databin = dataset[process_id]
     n_gpus = len(dataset)
     loader = _common.make_loader(databin, int(args.num_workers) // n_gpus)
@@ -105,7 +109,7 @@ def _work(process_id, model, dataset, args):
                 size = (int(pack["size"][0]), int(pack["size"][1]))
                 keys, _keys_dev, cam = _common.CAM_STORE.get(name, args.cam_out_dir, dev, cam_run, use_store)
                 pend.append({"name": name, "size": size, "img": _common.device_images(pack, (1.0,))[0],
-                             "cam": cam, "keys": keys})
+                             "cam": cam, "keys": keys, "stamp": _common.image_stamp(args.voc12_root, name)})
                 if len(pend) == batch:
                     _flush(model, walker, pend, args, writer, in_flight)
                 _common.progress(process_id, n_gpus, it, len(databin))

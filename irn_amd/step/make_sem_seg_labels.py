@@ -27,13 +27,40 @@ def _save_png(path, label):
     Image.fromarray(label).save(path)
 
 
-def edges_for(model, pend, irn_batch):
+def edges_for(model, pend, irn_batch, store=None, model_key=None):
     """EdgeDisplacement forward for the pending images, `irn_batch` at a time: ragged images are padded to the
-    512^2 crop like the reference pads each one (net/resnet50_irn.py:225), so a chunk is ONE trunk pass."""
-    for i in range(0, len(pend), irn_batch):
-        chunk = pend[i:i + irn_batch]
+    512^2 crop like the reference pads each one (net/resnet50_irn.py:225), so a chunk is ONE trunk pass.  With a `store`
+    (`_common.EDGE_STORE`) the maps the other label step already computed for an image (same network, same file) are taken
+    from device memory instead, and what is computed here is left there for it."""
+    todo = pend
+    if store is not None:
+        todo = []
+        for p in pend:
+            key = (model_key, getattr(model, "crop_size", None), getattr(model, "stride", None), p.get("stamp"))
+            hit = store.get(key, p["img"].device) if p.get("stamp") is not None else None
+            if hit is not None:
+                p["edge"], p["dp"] = hit
+                p.pop("img")
+            else:
+                p["_edge_key"] = key if p.get("stamp") is not None else None
+                todo.append(p)
+    for i in range(0, len(todo), irn_batch):
+        chunk = todo[i:i + irn_batch]
         for p, (edge, dp) in zip(chunk, model.forward_batch([p.pop("img") for p in chunk])):
             p["edge"], p["dp"] = edge, dp
+            key = p.pop("_edge_key", None)
+            if store is not None and key is not None:
+                store.put(key, edge, dp.clone())         # dp is a view into the batch's output: keep 1 image, not 8
+
+
+_MODEL_KEYS = {}          # id(network) -> key of the ModelSpec it was built from (set in _work)
+
+
+def _edge_store_kw(model, args):
+    """Keyword arguments of `edges_for` that switch the device hand-off of the edge maps on (see _common.EdgeStore)."""
+    if not _common.keep_edges(args):
+        return {}
+    return {"store": _common.EDGE_STORE, "model_key": _MODEL_KEYS.get(id(model), ("module", id(model)))}
 
 
 def _start_copy(batch):
@@ -55,7 +82,7 @@ def _start_copy(batch):
 def _enqueue(model, walker, pend, args):
     """IRNet forward, walk, label epilogue and the transfer of the label maps of the images in `pend`, enqueued only;
     returns what `_collect` needs."""
-    edges_for(model, pend, int(getattr(args, "irn_batch", 0) or 8))
+    edges_for(model, pend, int(getattr(args, "irn_batch", 0) or 8), **_edge_store_kw(model, args))
     rws = walker([p["edge"] for p in pend], [p["cam"] for p in pend],
                  beta=float(args.beta), exp_times=int(args.exp_times))
     sizes, keys = [p["size"] for p in pend], [p["keys_dev"] for p in pend]
@@ -92,7 +119,10 @@ def _flush(model, walker, pend, args, writer):
 
 
 def _work(process_id, model, dataset, args):
+    spec_key = model.key() if isinstance(model, _common.ModelSpec) else None
     model = _common.materialise(model)      # a network, or the (class, checkpoint) a worker builds it from
+    if spec_key is not None:
+        _MODEL_KEYS[id(model)] = spec_key
     databin = dataset[process_id]
     n_gpus = len(dataset)
     loader = _common.make_loader(databin, int(args.num_workers) // n_gpus)
@@ -116,7 +146,7 @@ def _work(process_id, model, dataset, args):
                 # CAM of this image: still on the device when make_cam ran in this process, else from its file
                 _keys, keys_dev, cam = _common.CAM_STORE.get(name, args.cam_out_dir, dev, cam_run, use_store)
                 pend.append({"name": name, "size": size, "img": _common.device_images(pack, (1.0,))[0],
-                             "cam": cam, "keys_dev": keys_dev})
+                             "cam": cam, "keys_dev": keys_dev, "stamp": _common.image_stamp(args.voc12_root, name)})
                 if len(pend) == batch:
                     _collect(walker, running, args, writer)
                     running = _enqueue(model, walker, pend, args)

@@ -57,6 +57,9 @@ def build_parser():
     p.add_argument("--keep_cams_on_device", default=True, type=_flag,
                    help="hand the CAMs of make_cam to the label steps in device memory when they run in the same process "
                         "(the .npy files are written all the same)")
+    p.add_argument("--keep_edges_on_device", default=True, type=_flag,
+                   help="the label step that runs first leaves every image's boundary / displacement maps on the device and the "
+                        "other one skips its IRNet forward (the reference runs EdgeDisplacement in both steps)")
     p.add_argument("--walk_batch", default=0, type=int,
                    help="images per random-walk launch (not in the reference); 0 = the step's default (64 sem-seg, 32 ins-seg)")
     p.add_argument("--walk_accel", default=None, type=int, choices=(0, 1),

@@ -46,8 +46,8 @@ class _CaptureEdges:
         self.module, self.orig, self.edges, self.dps = module, module.edges_for, {}, {}
 
     def __enter__(self):
-        def wrapped(model, pend, irn_batch):
-            self.orig(model, pend, irn_batch)
+        def wrapped(model, pend, irn_batch, **kw):
+            self.orig(model, pend, irn_batch, **kw)
             for p in pend:
                 self.edges[p["name"]] = p["edge"][0].cpu().numpy()
                 self.dps[p["name"]] = p["dp"].cpu().numpy()
@@ -102,10 +102,14 @@ def test_steps_end_to_end(tmp_path):
 
     from irn_amd.step import _common
     hits0, misses0 = _common.CAM_STORE.hits, _common.CAM_STORE.misses
+    _common.EDGE_STORE.clear()
+    e_hits0, e_misses0 = _common.EDGE_STORE.hits, _common.EDGE_STORE.misses
     with _CaptureEdges(make_sem_seg_labels) as cap:
         make_sem_seg_labels.run(args)
     edges = cap.edges
     assert _common.CAM_STORE.hits - hits0 == len(names) and _common.CAM_STORE.misses == misses0   # CAMs came from device memory
+    # first label step of the run: every edge map computed and left on the device for the other label step
+    assert _common.EDGE_STORE.misses - e_misses0 == len(names) and _common.EDGE_STORE.hits == e_hits0 and len(_common.EDGE_STORE) == len(names)
     from oracle import build_oracle, irn_oracle as O
     olib = build_oracle.load()
     for n in names:
@@ -127,6 +131,17 @@ def test_steps_end_to_end(tmp_path):
     _common.CAM_STORE.clear()
     make_sem_seg_labels.run(file_args)
     assert _common.CAM_STORE.misses - misses0 == len(names)
+    assert _common.EDGE_STORE.hits - e_hits0 == len(names)             # ... and this run took its edge maps from the store: no IRNet forward
+    # the hand-off off: the maps are recomputed and equal the stored ones up to MIOpen's run-to-run solver choice
+    off_args = argparse.Namespace(**{**vars(args), "sem_seg_out_dir": str(tmp_path / "sem_nostore"), "keep_edges_on_device": False})
+    os.makedirs(off_args.sem_seg_out_dir)
+    e_total = _common.EDGE_STORE.hits + _common.EDGE_STORE.misses
+    with _CaptureEdges(make_sem_seg_labels) as cap_off:
+        make_sem_seg_labels.run(off_args)
+    assert _common.EDGE_STORE.hits + _common.EDGE_STORE.misses == e_total
+    worst = max(float(np.abs(cap_off.edges[n] - edges[n]).max()) for n in names)
+    print("edge maps recomputed vs handed over in device memory: max deviation %.2e" % worst)
+    assert worst <= 1e-4
     for n in names:
         a = np.asarray(Image.open(os.path.join(args.sem_seg_out_dir, n + ".png")))
         b = np.asarray(Image.open(os.path.join(file_args.sem_seg_out_dir, n + ".png")))
@@ -144,8 +159,10 @@ def test_steps_end_to_end(tmp_path):
     n_diff, gap = label_mismatches(png, want, up, 0.25, lut=np.concatenate([[0], d["keys"].numpy() + 1]), what=n + " radius 10")
     print("%s radius 10: %d of %d label pixels differ from the oracle (largest top-2 gap %.2e)" % (n, n_diff, png.size, gap))
 
+    e_hits1 = _common.EDGE_STORE.hits
     with _CaptureEdges(make_sem_seg_labels) as capi:
         make_ins_seg_labels.run(args)
+    assert _common.EDGE_STORE.hits - e_hits1 == len(names)             # boundary AND displacement maps of the semantic step reused
     written = [n for n in names if os.path.exists(os.path.join(args.ins_seg_out_dir, n + ".npy"))]
     assert written, "no instance file written"
     for n in written:

@@ -528,3 +528,50 @@ def test_trunk_layout_is_chosen_per_input_shape(monkeypatch):
     monkeypatch.setattr(r50, "CHANNELS_LAST_MODE", "1")
     with torch.enable_grad():
         assert not r50.channels_last_for(_T((16, 3, 512, 512)))       # the training seam keeps the composed NCHW path
+
+
+def test_edge_store_keys_and_cap(tmp_path):
+    """step/_common.EdgeStore: the boundary / displacement maps one label step leaves for the other are keyed by network,
+    forward geometry and image FILE; another checkpoint, another image under the same name (new mtime / size) or another
+    device is a miss; the oldest entries leave when the cap is reached; edges_for fills and uses it."""
+    from irn_amd.step import _common, make_sem_seg_labels
+    root = tmp_path / "voc"
+    (root / "JPEGImages").mkdir(parents=True)
+    (root / "JPEGImages" / "2008_000001.jpg").write_bytes(b"a" * 100)
+    stamp = _common.image_stamp(str(root), "2008_000001")
+    assert stamp[0].endswith("2008_000001.jpg") and stamp[2] == 100
+    (root / "JPEGImages" / "2008_000001.jpg").write_bytes(b"b" * 101)
+    assert _common.image_stamp(str(root), "2008_000001") != stamp and _common.image_stamp(str(root), "missing")[1:] == (-1, -1)
+
+    class _Net:                      # stands in for EdgeDisplacement: counts its forwards
+        crop_size, stride, calls = 512, 4, 0
+
+        def forward_batch(self, items):
+            _Net.calls += 1
+            return [(it[:1, 0, ::4, ::4] + 1.0, it[:, 0, ::4, ::4] * 2.0) for it in items]
+
+    store = _common.EdgeStore(max_bytes=1 << 20)
+    net = _Net()
+    mk = lambda names: [{"name": n, "img": torch.full((2, 3, 16, 20), float(i)), "stamp": ("/p/" + n, 1, 2)} for i, n in enumerate(names)]
+    a = mk(["x", "y", "z"])
+    make_sem_seg_labels.edges_for(net, a, 2, store=store, model_key=("ckpt", 1))
+    assert _Net.calls == 2 and store.misses == 3 and store.hits == 0 and len(store) == 3 and "img" not in a[0]
+    b = mk(["x", "y", "z", "w"])
+    make_sem_seg_labels.edges_for(net, b, 2, store=store, model_key=("ckpt", 1))
+    assert _Net.calls == 3 and store.hits == 3                                    # only "w" went through the network
+    for p, q in zip(a, b):
+        assert torch.equal(p["edge"], q["edge"]) and torch.equal(p["dp"], q["dp"])
+    c = mk(["x"])
+    make_sem_seg_labels.edges_for(net, c, 2, store=store, model_key=("ckpt", 2))   # another checkpoint: computed again
+    assert _Net.calls == 4
+    d = mk(["x"])
+    d[0]["stamp"] = ("/p/x", 9, 2)                                                # the file changed
+    make_sem_seg_labels.edges_for(net, d, 2, store=store, model_key=("ckpt", 1))
+    assert _Net.calls == 5
+    e = mk(["x"])
+    make_sem_seg_labels.edges_for(net, e, 2)                                       # no store: always computed, nothing stored
+    assert _Net.calls == 6 and "stamp" in e[0]
+    small = _common.EdgeStore(max_bytes=3 * 4 * 60)
+    for i in range(5):
+        small.put(("k", i), torch.zeros(1, 4, 5), torch.zeros(2, 4, 5))
+    assert len(small) == 3 and small.get(("k", 0), torch.device("cpu")) is None and small.get(("k", 4), torch.device("cpu")) is not None
