@@ -156,11 +156,11 @@ int irn_walk_fallback_runs(irn_walk_ctx *ctx);
  *   placement   0 not checked yet, 1 "block b of a launch runs on XCD b % 8" holds on this device (the tiles of an image are
  *               then packed onto one XCD), 2 it does not (tiles keep launch order; one line on stderr says so);
  *   poll_delay  the delay (units of 64 clocks) between a single-channel tile's stores and its first poll in use now;
- *   probe_ms3   launch times in ms the start-up probe measured for delays 8, 10, 12 on this context's first representative
+ *   probe_ms4   launch times in ms the start-up probe measured for delays 6, 8, 10, 12 on this context's first representative
  *               batch (zeros: this context did not probe — too small a batch, another context of the process probed
  *               before, or option "poll_delay" pinned the value; "poll_delay_auto" = 0 switches the probe off).
  * Any pointer may be null. */
-int irn_walk_tuning(irn_walk_ctx *ctx, int *poll_delay, int *placement, float *probe_ms3);
+int irn_walk_tuning(irn_walk_ctx *ctx, int *poll_delay, int *placement, float *probe_ms4);
 
 /* Diagnostic (option "profile" = 1, resident walk only): per-sweep time stamps of two workgroups of
  * the first round — host_out is int64 [2][256][4] = {sweep start, state staged, first partial sums

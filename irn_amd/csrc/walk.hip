@@ -1134,12 +1134,12 @@ extern "C" int irn_walk_sync(irn_walk_ctx *ctx, int *fell_back) {
 
 extern "C" int irn_walk_fallback_runs(irn_walk_ctx *ctx) { return ctx ? ctx->fallback_runs : 0; }
 
-extern "C" int irn_walk_tuning(irn_walk_ctx *ctx, int *poll_delay, int *placement, float *probe_ms3) {
+extern "C" int irn_walk_tuning(irn_walk_ctx *ctx, int *poll_delay, int *placement, float *probe_ms4) {
     if (!ctx) return fail(IRN_ERR_ARG, "irn_walk_tuning: null ctx");
     if (poll_delay) *poll_delay = ctx->res_poll_delay;
     if (placement) *placement = ctx->res_placement;
-    if (probe_ms3)
-        for (int k = 0; k < 3; ++k) probe_ms3[k] = ctx->res_poll_probe_ms[k];
+    if (probe_ms4)
+        for (int k = 0; k < 4; ++k) probe_ms4[k] = ctx->res_poll_probe_ms[k];
     return IRN_OK;
 }
 
