@@ -478,7 +478,11 @@ def run_steps(a, rank, world, device, dist, parallel, steps, warmup, batch=0):
             real = sys.stdout
             sys.stdout = _Quiet()                      # progress ticks of the steps would break the one-JSON-line contract
             try:
-                # the step API itself, as run_sample.py calls it (checkpoints loaded, shards made, workers run, files written)
+                # the step API itself, as run_sample.py calls it (checkpoints loaded, shards made, workers run, files written).
+                # Every pass starts like a fresh run_sample.py invocation as far as results of earlier passes go: the edge /
+                # displacement maps an earlier pass left on the device are dropped, so that only the hand-off INSIDE a pass
+                # (make_ins_seg_labels -> make_sem_seg_labels) is measured, never one across passes
+                _common.EDGE_STORE.clear()
                 t0 = time.perf_counter()
                 make_cam.run(args)
                 t1 = time.perf_counter()
