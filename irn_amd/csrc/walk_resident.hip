@@ -569,6 +569,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         int t = t_first, c = 0;
         bool fresh = true;             // first step of the job: its input has been there since before the launch
         bool polled = false;           // the poll of the current step is already in flight
+        constexpr bool ROT = IRN_ROTATED_STAGE != 0 && R == 10;      // (radius 5: the rotated loop spills 5 registers)
         // consume the poll slot into an LDS state buffer: examine what came back, re-poll what is not there yet (bounded)
         auto consume = [&](float *xdst, __amdgpu_buffer_rsrc_t rs, int soff, unsigned want_tag, int t_err) __attribute__((always_inline)) {
             unsigned pend = vmask;
@@ -601,7 +602,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 }
             }
         };
-#if IRN_ROTATED_STAGE
+        if constexpr (ROT) {
         // Rotated step loop: the input of step k + 1 is staged at the END of step k — by the polling waves, while waves 0-3
         // run the combine of step k (for >= 2 channels that poll was prefetched, and the polling waves would idle there).
         // The staging of a job's first step therefore sits here, in front of the loop.  ONE consumption site inside the
@@ -613,7 +614,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         }
         __syncthreads();
         if (*abort_flag) return;
-#endif
+        }
 #pragma unroll 1
         for (int k = 0; k < n_steps; ++k) {
             const __amdgpu_buffer_rsrc_t src = state_rsrc(t), dst = state_rsrc(t + 1);
@@ -633,8 +634,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             // just after the neighbours' stores have landed.  Polling early is worse than useless
             // (delay 0: 4.3 us per sweep, delay 20: 2.6 — early loads pull stale lines that the
             // stores must then displace, and a miss costs a whole ~0.85 us round trip).
-#if !IRN_ROTATED_STAGE
+            if constexpr (!ROT) {
             if (poller) {
+                unsigned pend = vmask;
                 if (!polled) {
                     if (!fresh) nap(job_delay);
                     issue(src, c * ch_bytes);
@@ -646,13 +648,40 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                         err[3] = blockIdx.x;
                     }
                     *abort_flag = 1;
-                } else {
-                    consume(xsb, src, c * ch_bytes, want, t);
+                    pend = 0;
+                }
+                long long t_start = 0;
+                for (;;) {
+#pragma unroll
+                    for (int kk = 0; kk < NK; ++kk) {
+                        if (((pend >> (2 * kk)) & 1u) && va[kk].y == want) {
+                            xsb[btab[kk] & 0xfff] = __uint_as_float(va[kk].x);
+                            pend &= ~(1u << (2 * kk));
+                        }
+                        if (((pend >> (2 * kk)) & 2u) && va[kk].w == want) {
+                            xsb[(btab[kk] & 0xfff) + 1] = __uint_as_float(va[kk].z);
+                            pend &= ~(2u << (2 * kk));
+                        }
+                    }
+                    if (!__builtin_amdgcn_ballot_w64(pend != 0)) break;
+                    issue(src, c * ch_bytes);
+                    const long long now = wall_clock64();
+                    if (t_start == 0) t_start = now;
+                    else if (now - t_start > timeout_ticks ||
+                             __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+                        if (lane == 0 && atomicCAS(err, 0u, 1u) == 0u) {
+                            err[1] = (unsigned)je.x;
+                            err[2] = (unsigned)t;
+                            err[3] = blockIdx.x;
+                        }
+                        *abort_flag = 1;
+                        break;
+                    }
                 }
             }
             __syncthreads();
             if (*abort_flag) return;
-#endif
+            }
 #if IRN_PROF_COMBINE == 0
             if (PROF && pslot) pslot[1] = wall_clock64();
 #endif
@@ -927,7 +956,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             if (PROF && pslot) pslot[2] = wall_clock64();                      // mode 2: [2] = LDS writes and global stores issued
 #endif
             fresh = false;
-#if IRN_ROTATED_STAGE
+            if constexpr (ROT) {
             if (k + 1 < n_steps) {
                 if (!polled) {
                     // C = 1: the next poll is timed from our own stores, so every wave starts its delay behind them
@@ -952,11 +981,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
                 __syncthreads();
                 if (*abort_flag) return;
             }
-#else
+            } else {
             // C = 1: the next poll is timed from our own stores, so every wave has to start its delay
             // behind them (the waves that do not combine would otherwise poll ~0.2 us early)
             if (C == 1) __syncthreads();
-#endif
+            }
 #if IRN_PROF_COMBINE != 1
             if (PROF && pslot) pslot[3] = wall_clock64();
 #endif

@@ -107,6 +107,11 @@ chlast)
   bash tools/r4_channels_last_ab.sh $OUT ;;
 miopen)
   bash tools/r4_miopen_ab.sh $OUT ${MIOPEN_ARGS:-} ;;
+libtests)
+  # the walk's GPU tests against another build of the library (IRN_HIP_LIB)
+  for lib in ${AB_LIBS:-libirn_hip.so}; do
+    IRN_HIP_LIB=$PWD/irn_amd/lib/$lib timeout 900 python -m pytest tests/test_gpu_resident.py tests/test_gpu_schedule.py tests/test_gpu_walk.py tests/test_gpu_parity_r2.py -m gpu -q -x -k "not forward and not edge_displacement" > $OUT/pytest_${lib%.so}.log 2>&1; echo "$lib tests rc=$?"; tail -2 $OUT/pytest_${lib%.so}.log
+  done ;;
 stepprof)
   for lib in ${AB_LIBS:-libirn_hip.so}; do echo "== $lib"; bash tools/r4_profile.sh $OUT $lib; done > $OUT/step_profile.txt 2>&1; cat $OUT/step_profile.txt ;;
 ranks)
