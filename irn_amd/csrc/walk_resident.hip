@@ -54,9 +54,6 @@ typedef const double IRN_GLOBAL *gcd_t;
 typedef float IRN_GLOBAL *gf_t;
 typedef float f4a __attribute__((ext_vector_type(4)));
 
-#ifndef IRN_ROTATED_STAGE
-#define IRN_ROTATED_STAGE 0    // 1: the next step's input is staged at the end of a step, under the combine (see the step loop)
-#endif
 #ifndef IRN_PROF_COMBINE
 #define IRN_PROF_COMBINE 0     // diagnostic builds only (tools/combine_profile.py): 1 / 2 move the PROF stamps into the combine phase
 #endif
@@ -569,52 +566,6 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         int t = t_first, c = 0;
         bool fresh = true;             // first step of the job: its input has been there since before the launch
         bool polled = false;           // the poll of the current step is already in flight
-        constexpr bool ROT = IRN_ROTATED_STAGE != 0 && R == 10;      // (radius 5: the rotated loop spills 5 registers)
-        // consume the poll slot into an LDS state buffer: examine what came back, re-poll what is not there yet (bounded)
-        auto consume = [&](float *xdst, __amdgpu_buffer_rsrc_t rs, int soff, unsigned want_tag, int t_err) __attribute__((always_inline)) {
-            unsigned pend = vmask;
-            long long t_start = 0;
-            for (;;) {
-#pragma unroll
-                for (int kk = 0; kk < NK; ++kk) {
-                    if (((pend >> (2 * kk)) & 1u) && va[kk].y == want_tag) {
-                        xdst[btab[kk] & 0xfff] = __uint_as_float(va[kk].x);
-                        pend &= ~(1u << (2 * kk));
-                    }
-                    if (((pend >> (2 * kk)) & 2u) && va[kk].w == want_tag) {
-                        xdst[(btab[kk] & 0xfff) + 1] = __uint_as_float(va[kk].z);
-                        pend &= ~(2u << (2 * kk));
-                    }
-                }
-                if (!__builtin_amdgcn_ballot_w64(pend != 0)) break;
-                issue(rs, soff);
-                const long long now = wall_clock64();
-                if (t_start == 0) t_start = now;
-                else if (now - t_start > timeout_ticks ||
-                         __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
-                    if (lane == 0 && atomicCAS(err, 0u, 1u) == 0u) {
-                        err[1] = (unsigned)je.x;
-                        err[2] = (unsigned)t_err;
-                        err[3] = blockIdx.x;
-                    }
-                    *abort_flag = 1;
-                    break;
-                }
-            }
-        };
-        if constexpr (ROT) {
-        // Rotated step loop: the input of step k + 1 is staged at the END of step k — by the polling waves, while waves 0-3
-        // run the combine of step k (for >= 2 channels that poll was prefetched, and the polling waves would idle there).
-        // The staging of a job's first step therefore sits here, in front of the loop.  ONE consumption site inside the
-        // loop: round 3's "early_stage" switch added a second one and the compiler then waited for the poll loads in the
-        // middle of the arithmetic (LESSONS.md 26).
-        if (poller && n_steps > 0) {
-            issue(state_rsrc(t), 0);
-            consume(xs, state_rsrc(t), 0, (unsigned)(t + 1), t);
-        }
-        __syncthreads();
-        if (*abort_flag) return;
-        }
 #pragma unroll 1
         for (int k = 0; k < n_steps; ++k) {
             const __amdgpu_buffer_rsrc_t src = state_rsrc(t), dst = state_rsrc(t + 1);
@@ -634,7 +585,6 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             // just after the neighbours' stores have landed.  Polling early is worse than useless
             // (delay 0: 4.3 us per sweep, delay 20: 2.6 — early loads pull stale lines that the
             // stores must then displace, and a miss costs a whole ~0.85 us round trip).
-            if constexpr (!ROT) {
             if (poller) {
                 unsigned pend = vmask;
                 if (!polled) {
@@ -681,7 +631,6 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             }
             __syncthreads();
             if (*abort_flag) return;
-            }
 #if IRN_PROF_COMBINE == 0
             if (PROF && pslot) pslot[1] = wall_clock64();
 #endif
@@ -956,36 +905,9 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
             if (PROF && pslot) pslot[2] = wall_clock64();                      // mode 2: [2] = LDS writes and global stores issued
 #endif
             fresh = false;
-            if constexpr (ROT) {
-            if (k + 1 < n_steps) {
-                if (!polled) {
-                    // C = 1: the next poll is timed from our own stores, so every wave starts its delay behind them
-                    __syncthreads();
-                    if (poller) {
-                        nap(job_delay);
-                        issue(state_rsrc(tn), cn * ch_bytes);
-                    }
-                }
-                if (poller) {
-                    if (timeout_ticks < 0) {            // test hook (option inject_timeout): give up at the first hand-off
-                        if (lane == 0 && atomicCAS(err, 0u, 1u) == 0u) {
-                            err[1] = (unsigned)je.x;
-                            err[2] = (unsigned)tn;
-                            err[3] = blockIdx.x;
-                        }
-                        *abort_flag = 1;
-                    } else {
-                        consume(xs + ((k + 1) & 1) * (LH * LW), state_rsrc(tn), cn * ch_bytes, (unsigned)(tn + 1), tn);
-                    }
-                }
-                __syncthreads();
-                if (*abort_flag) return;
-            }
-            } else {
             // C = 1: the next poll is timed from our own stores, so every wave has to start its delay
             // behind them (the waves that do not combine would otherwise poll ~0.2 us early)
             if (C == 1) __syncthreads();
-            }
 #if IRN_PROF_COMBINE != 1
             if (PROF && pslot) pslot[3] = wall_clock64();
 #endif
