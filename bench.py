@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """bench.py — throughput of the IRN pseudo-label hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W            (N > 1: launched by torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W            (N > 1: under torch.distributed.run, or it starts its own N ranks;
+                                                              --rank-devices 0,0 = two ranks on one GPU)
 
 Workload (default `walk`, BASELINE.json configs[2], the case the north-star target is quoted on):
 semantic pseudo-label generation for a batch of synthetic VOC12-shaped images — 512x512 images,
@@ -29,10 +30,11 @@ One JSON line on rank 0:
                    below 1e-4); `reference_algorithm`: the reference's own dense algorithm (oracle/dense_ref.py =
                    misc/indexing.py:91-165 op for op on torch CPU) timed IN FULL at the workload's 128x128 grid (and at
                    64x64 as the scaling check), per-phase seconds, same thread count as the port.
-  legs             short runs of the other configurations at N = 1: cam (configs[1]), e2e (cam + IRNet + walk +
-                   labels), steps (the run_sample.py step API through `run(args)` on a synthetic VOC directory), walk_r5,
-                   walk_plain (the default workload with the plain 2^exp_times iteration, option accel = 0), ins
-                   (configs[3]), coco (configs[4]) — images/s each.
+  legs             runs of the other configurations at N = 1 (>= 10 steps or >= 96 images each): cam (configs[1]), e2e (cam +
+                   IRNet + walk + labels), steps (the run_sample.py step API through `run(args)` on a synthetic VOC directory:
+                   make_cam -> make_ins_seg_labels -> make_sem_seg_labels, 256 images, per-pass seconds), walk_r5, walk_plain (the
+                   default workload with the plain 2^exp_times iteration, option accel = 0), ins / ins_r10 (configs[3]), coco
+                   (configs[4]) — images/s each.
 Other main workloads: --workload walk_r5 | ins | coco | cam | e2e | steps.
 """
 import argparse
