@@ -203,7 +203,9 @@ def test_walk_voc_grids_vs_reference_golden(golden, variant):
         n_diff, gap = label_mismatches(lab, want, up, 0.25, lut=np.concatenate([[0], keys + 1]), what=n)
         print("%s variant %d: max |gpu - reference| %.2e, %d of %d label pixels differ (largest top-2 gap %.2e)" %
               (n, variant, np.abs(rw - ref).max(), n_diff, lab.size, gap))
-        assert n_diff <= 16
+        # measured: 0 (radius 5) and 1 (radius 10: a tie with a top-2 gap of 7.5e-7).  No head-room beyond that kind of pixel:
+        # at most two, and only ties an order of magnitude below the 1e-4 bar (label_mismatches has checked each one is a tie)
+        assert n_diff <= 2 and (n_diff == 0 or gap < 1e-5), (n, variant, n_diff, gap)
         walker.close()
 
 
@@ -225,7 +227,7 @@ def test_walk_128_labels_vs_reference_epilogue(golden):
     from _parity import label_mismatches
     n_diff, gap = label_mismatches(lab, want, up, 0.25, lut=np.concatenate([[0], keys + 1]), what="walk128 r10 labels")
     print("labels vs the reference's walk + epilogue at 512x512: %d of %d pixels differ (largest top-2 gap %.2e)" % (n_diff, lab.size, gap))
-    assert n_diff <= 16
+    assert n_diff == 0           # measured since round 2: not one of 262 144 pixels
     walker.close()
 
 

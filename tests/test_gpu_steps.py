@@ -366,7 +366,7 @@ def test_bench_contract_one_json_line():
     pe = rf["power_equivalent"]
     assert abs(pe["achieved"] / rf["achieved"] - 256.0 / 84.0) < 1e-6 and abs(pe["flops"] / rf["flops_per_launch"] - 256.0 / 84.0) < 1e-6
     lp = r["label_parity"]
-    assert lp["images"] == 2 and lp["not_a_tie"] == 0 and lp["pixels_differing"] <= 16 * lp["images"] and lp["max_top2_gap"] < 1e-4
+    assert lp["images"] == 2 and lp["not_a_tie"] == 0 and lp["pixels_differing"] == 0 and lp["max_top2_gap"] < 1e-4
     assert abs(r["value"] - 2 * 8 / (r["ms_per_step"] * 2e-3)) / r["value"] < 1e-6
     cb = r["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and cb["unit"] == "images/s" and cb["sample"]
