@@ -288,7 +288,10 @@ def test_run_sample_cli_end_to_end(tmp_path):
                          "--ins_seg_out_dir", str(tmp_path / "ins"), "--ir_label_out_dir", str(tmp_path / "ir"),
                          "--log_name", str(tmp_path / "log"), "--cam_scales", "1.0", "0.5",
                          "--cam_learning_rate", "0.05", "--irn_batch_size", "16", "--conf_fg_thres", "0.3", "--beta", "10",
-                         "--exp_times", "8", "--train_cam_pass", "False", "--eval_cam_pass", "False"])
+                         "--exp_times", "8", "--train_cam_pass", "False", "--eval_cam_pass", "False",
+                         # this build's own flags: the schedule switch, the step deadline, the device hand-offs
+                         "--walk_accel", "1", "--walk_accel_tol_exp", "7", "--step_timeout", "900",
+                         "--keep_cams_on_device", "1", "--keep_edges_on_device", "1"])
     finally:
         if isinstance(sys.stdout, pyutils.Logger):
             sys.stdout.close()
@@ -298,6 +301,27 @@ def test_run_sample_cli_end_to_end(tmp_path):
         W, H = Image.open(root / "JPEGImages" / (n + ".jpg")).size
         assert np.asarray(Image.open(tmp_path / "sem" / (n + ".png"))).shape == (H, W)
     assert any(os.path.exists(tmp_path / "ins" / (n + ".npy")) for n in names)
+    # the reference's own schedule (2^exp_times applications) through the same command line: labels equal except at ties
+    stdout = sys.stdout
+    try:
+        run_sample.main(["--voc12_root", str(root), "--train_list", lst, "--infer_list", lst, "--num_workers", "2",
+                         "--cam_weights_name", str(tmp_path / "res50_cam"), "--irn_weights_name", str(tmp_path / "res50_irn.pth"),
+                         "--cam_out_dir", str(tmp_path / "cam"), "--sem_seg_out_dir", str(tmp_path / "sem_plain"),
+                         "--ins_seg_out_dir", str(tmp_path / "ins_plain"), "--log_name", str(tmp_path / "log_plain"),
+                         "--cam_scales", "1.0", "0.5", "--make_cam_pass", "False", "--make_ins_seg_pass", "False",
+                         "--walk_accel", "0"])
+    finally:
+        if isinstance(sys.stdout, pyutils.Logger):
+            sys.stdout.close()
+        sys.stdout = stdout
+    n_px = n_diff = 0
+    for n in names:
+        a = np.asarray(Image.open(tmp_path / "sem" / (n + ".png")))
+        b = np.asarray(Image.open(tmp_path / "sem_plain" / (n + ".png")))
+        n_px += a.size
+        n_diff += int((a != b).sum())
+    print("run_sample.py --walk_accel 1 vs 0: %d of %d semantic label pixels differ" % (n_diff, n_px))
+    assert n_diff <= 2                                    # two schedules of the same operator: exact ties only (measured: 0)
     with pytest.raises(SystemExit):                      # a pass this build does not implement refuses loudly
         run_sample.main(["--voc12_root", str(root), "--train_irn_pass", "True", "--log_name", str(tmp_path / "log2")])
 
