@@ -69,11 +69,16 @@ template <>
 struct RCfg<10> {
     static constexpr int Q = 8, SL_Y = 1, SL_X = 1;
     static constexpr bool PREFETCH_ROWS = true;     // read the next neighbour row's window ahead of this row's FMAs
+#ifndef IRN_R10_ROLE_SPLIT
+#define IRN_R10_ROLE_SPLIT 1
+#endif
+    static constexpr bool ROLE_SPLIT = IRN_R10_ROLE_SPLIT != 0;     // one copy of the step loop per wave role (see the step loop)
 };
 template <>
 struct RCfg<5> {
     static constexpr int Q = 2, SL_Y = 2, SL_X = 2;
     static constexpr bool PREFETCH_ROWS = true;     // fits since the fp32 chains freed the fp64 accumulators (250 VGPRs)
+    static constexpr bool ROLE_SPLIT = false;       // split, the radius-5 instantiation spills six registers
 };
 
 // The neighbour disc (dy,dx) != (0,0), dx^2 + dy^2 < R^2, in raster order: the union of the
@@ -566,353 +571,31 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         int t = t_first, c = 0;
         bool fresh = true;             // first step of the job: its input has been there since before the launch
         bool polled = false;           // the poll of the current step is already in flight
-#pragma unroll 1
-        for (int k = 0; k < n_steps; ++k) {
-            const __amdgpu_buffer_rsrc_t src = state_rsrc(t), dst = state_rsrc(t + 1);
-            const bool last = (t + 1 == t_total);
-            const unsigned want = (unsigned)(t + 1);
-            const float ck = cheb ? coef[t + 1] : 0.f;       // coefficient of y_{t+1} in the series (scalar load)
-            const bool rec2 = cheb && t > 0;                 // y_{t+1} = 2 T y_t - y_{t-1}; the first step is y_1 = T y_0
-            float *xsb = xs + (k & 1) * (LH * LW);
-            long long *pslot = nullptr;   // diagnostic time stamps of round 0 for two workgroups
-            if (PROF && prof && round == 0 && tid == 0 && (blockIdx.x == 0 || blockIdx.x == gridDim.x / 2) && k < 248)
-                pslot = prof + ((blockIdx.x == 0 ? 0 : 256) + k) * 4;
-            if (PROF && pslot) pslot[0] = wall_clock64();
-
-            // ---- [A] poll + stage x_t[c] of the tile and its halo (polling waves) ----
-            // All tiles of an image run in lock step, so nothing is ready right after our own stores:
-            // an unprefetched poll (C = 1) goes out `poll_delay` behind them so that it samples memory
-            // just after the neighbours' stores have landed.  Polling early is worse than useless
-            // (delay 0: 4.3 us per sweep, delay 20: 2.6 — early loads pull stale lines that the
-            // stores must then displace, and a miss costs a whole ~0.85 us round trip).
+        // One copy of the step loop per wave ROLE at radius 10 (round 4): the polling waves' copy has no stores and the
+        // combining waves' copy no poll registers, so no wait — and no register-allocation accident — of one role can land on
+        // the other; each copy's arithmetic switch holds only its own four parts, so the code does not grow.  Measured
+        // (profiles/r04_s10_role_split_ab.txt): default workload +4.2 %, COCO shape +6.1 %; steps 2.12 / 1.49 / 1.38 ->
+        // 1.94 / 1.40 / 1.29 us at 1 / 2 / 3 channels.  Radius 5 keeps the shared copy: split, it spills six registers.
+        if constexpr (RCfg<R>::ROLE_SPLIT) {
+            auto step_loop = [&](auto role_tag) __attribute__((always_inline)) -> bool {
+                constexpr int ROLE = decltype(role_tag)::value;
+                const bool poller_ = ROLE == 1;
+#define IRN_STEP_ABORT return true
+#include "walk_resident_steps.inc"
+#undef IRN_STEP_ABORT
+                return false;
+            };
             if (poller) {
-                unsigned pend = vmask;
-                if (!polled) {
-                    if (!fresh) nap(job_delay);
-                    issue(src, c * ch_bytes);
-                }
-                if (timeout_ticks < 0 && k > 0) {       // test hook (option inject_timeout): give up at the first hand-off
-                    if (lane == 0 && atomicCAS(err, 0u, 1u) == 0u) {
-                        err[1] = (unsigned)je.x;
-                        err[2] = (unsigned)t;
-                        err[3] = blockIdx.x;
-                    }
-                    *abort_flag = 1;
-                    pend = 0;
-                }
-                long long t_start = 0;
-                for (;;) {
-#pragma unroll
-                    for (int kk = 0; kk < NK; ++kk) {
-                        if (((pend >> (2 * kk)) & 1u) && va[kk].y == want) {
-                            xsb[btab[kk] & 0xfff] = __uint_as_float(va[kk].x);
-                            pend &= ~(1u << (2 * kk));
-                        }
-                        if (((pend >> (2 * kk)) & 2u) && va[kk].w == want) {
-                            xsb[(btab[kk] & 0xfff) + 1] = __uint_as_float(va[kk].z);
-                            pend &= ~(2u << (2 * kk));
-                        }
-                    }
-                    if (!__builtin_amdgcn_ballot_w64(pend != 0)) break;
-                    issue(src, c * ch_bytes);
-                    const long long now = wall_clock64();
-                    if (t_start == 0) t_start = now;
-                    else if (now - t_start > timeout_ticks ||
-                             __hip_atomic_load(err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
-                        if (lane == 0 && atomicCAS(err, 0u, 1u) == 0u) {
-                            err[1] = (unsigned)je.x;
-                            err[2] = (unsigned)t;
-                            err[3] = blockIdx.x;
-                        }
-                        *abort_flag = 1;
-                        break;
-                    }
-                }
+                if (step_loop(std::integral_constant<int, 1>{})) return;
+            } else {
+                if (step_loop(std::integral_constant<int, 2>{})) return;
             }
-            __syncthreads();
-            if (*abort_flag) return;
-#if IRN_PROF_COMBINE == 0
-            if (PROF && pslot) pslot[1] = wall_clock64();
-#endif
-
-            // ---- [B] prefetch: the next step's poll is issued as soon as its input can be there ----
-            // chain cn was stored C-1 steps ago: long ago for C >= 3 (issue before the arithmetic), at the
-            // end of the previous step for C = 2 (issue behind the arithmetic, ~1 us after the stores)
-            int tn = t, cn = c + 1;
-            if (cn == C) {
-                cn = 0;
-                ++tn;
-            }
-            polled = C >= 2 && k + 1 < n_steps;
-            if (polled && poller && C >= 3) issue(state_rsrc(tn), cn * ch_bytes);
-
-            // ---- [C] partial sums -> LDS -> fp64 combine -> store ----
-            {
-                const float *xrow = xsb + (ly + H) * LW + lx + HP;
-                float acc[4];
-                if (R == 10 && C == 2) {
-                    switch (qi) {
-                        case 0: partial_sums<R, 0, 0>(wr, xrow, acc); break;
-                        case 1: partial_sums<R, 1 % Q, 0>(wr, xrow, acc); break;
-                        case 2: partial_sums<R, 2 % Q, 0>(wr, xrow, acc); break;
-                        case 3: partial_sums<R, 3 % Q, 0>(wr, xrow, acc); break;
-                        case 4: partial_sums<R, 4 % Q, 0>(wr, xrow, acc); break;
-                        case 5: partial_sums<R, 5 % Q, 0>(wr, xrow, acc); break;
-                        case 6: partial_sums<R, 6 % Q, 0>(wr, xrow, acc); break;
-                        default: partial_sums<R, 7 % Q, 0>(wr, xrow, acc); break;
-                    }
-                    // C = 2: the next step's chain was stored at the end of the previous step; half-way through
-                    // the arithmetic (~0.7 us behind those stores) its poll goes out and flies under the rest
-                    if (polled && poller) issue(state_rsrc(tn), cn * ch_bytes);
-                    switch (qi) {
-                        case 0: partial_sums<R, 0, 1>(wr, xrow, acc); break;
-                        case 1: partial_sums<R, 1 % Q, 1>(wr, xrow, acc); break;
-                        case 2: partial_sums<R, 2 % Q, 1>(wr, xrow, acc); break;
-                        case 3: partial_sums<R, 3 % Q, 1>(wr, xrow, acc); break;
-                        case 4: partial_sums<R, 4 % Q, 1>(wr, xrow, acc); break;
-                        case 5: partial_sums<R, 5 % Q, 1>(wr, xrow, acc); break;
-                        case 6: partial_sums<R, 6 % Q, 1>(wr, xrow, acc); break;
-                        default: partial_sums<R, 7 % Q, 1>(wr, xrow, acc); break;
-                    }
-                } else {
-                    switch (qi) {
-                        case 0: partial_sums<R, 0, 2>(wr, xrow, acc); break;
-                        case 1: partial_sums<R, 1 % Q, 2>(wr, xrow, acc); break;
-                        case 2: partial_sums<R, 2 % Q, 2>(wr, xrow, acc); break;
-                        case 3: partial_sums<R, 3 % Q, 2>(wr, xrow, acc); break;
-                        case 4: partial_sums<R, 4 % Q, 2>(wr, xrow, acc); break;
-                        case 5: partial_sums<R, 5 % Q, 2>(wr, xrow, acc); break;
-                        case 6: partial_sums<R, 6 % Q, 2>(wr, xrow, acc); break;
-                        default: partial_sums<R, 7 % Q, 2>(wr, xrow, acc); break;
-                    }
-                    if (polled && poller && C == 2) issue(state_rsrc(tn), cn * ch_bytes);   // radius 5
-                }
-                // the wave's four chains leave as ONE 16-byte LDS write; [buffer][wave][lane][j] fp32
-                float *partf = reinterpret_cast<float *>(part);
-                int wl = lane;                         // opaque: the LDS address is rebuilt per step instead of living in a register
-                asm volatile("" : "+v"(wl));
-                *reinterpret_cast<f4a *>(partf + (k & 1) * (kWaves * 256) + wv * 256 + wl * 4) = f4a{acc[0], acc[1], acc[2], acc[3]};
-                __syncthreads();
-#if IRN_PROF_COMBINE == 0
-                if (PROF && pslot) pslot[2] = wall_clock64();
-#elif IRN_PROF_COMBINE == 1
-                if (PROF && pslot) pslot[1] = wall_clock64();          // diagnostic build: [1] = combine entry
-#endif
-                // One pixel per combining thread, consecutive threads = consecutive pixels of a tile row (their
-                // partial sums are contiguous in LDS).  Neighbouring lanes then swap results and the even lane
-                // stores BOTH granules with one 16-byte store (8-byte sc1 stores are the expensive form, lesson 10;
-                // folding two pixels per thread instead doubled the combine's latency chain: 0.21 -> 0.40 us).
-                if constexpr (R == 10) {
-                auto combine10 = [&](auto lds_tag) __attribute__((always_inline)) {
-                    constexpr bool PS_LDS = decltype(lds_tag)::value;
-                    const int i = tid;                    // G::SLABS * 256 == 256: one pixel per combining thread
-                    const int s2 = i >> 8, prow = (i >> 5) & 7, x = i & 31;
-                    const int py = (s2 / G::C::SL_X) * kSlabH + prow;
-                    const int px = (s2 % G::C::SL_X) * kSlabW + x;
-                    const float *pr = partf + (k & 1) * (kWaves * 256) + (s2 * Q) * 256 + (prow * 8 + (x >> 2)) * 4 + (x & 3);
-                    const int yy = ty0 + py, xx = tx0 + px;
-                    const bool inimg = yy < h && xx < w;
-                    const unsigned o = (unsigned)(yy * w + xx);
-                    // {y_{t-1}, s_t} of this pixel: LDS for the first CAPC channels (read together with the partial sums),
-                    // else the workspace (asked for first: an L2 round trip that the LDS reads below cover)
-                    f2a pv{0.f, 0.f};
-                    if constexpr (PS_LDS) pv = psl[c * G::TPX + i];
-                    else if (inimg) pv = __builtin_bit_cast(f2a, __builtin_amdgcn_raw_buffer_load_b64(prs, (int)o * 8, c * ch_bytes, 0));
-                    // the Q fp32 chains of the pixel: pairwise in fp32 (as close to the exact operator as adding them in
-                    // fp64: the model of tests/test_precision_model.py gives the same 1.5e-6 after 256 sweeps), then centre
-                    // term and normalisation in fp64.  A chain of Q dependent fp64 conversions + additions was most of the
-                    // combine's latency.
-                    float ps[Q];
-#pragma unroll
-                    for (int q = 0; q < Q; ++q) ps[q] = pr[q * 256];
-                    const float centre = xsb[(py + H) * LW + px + HP];
-                    const double inv = invd[i];
-#if IRN_PROF_COMBINE == 1
-                    if (PROF && pslot) {
-                        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                        pslot[2] = wall_clock64();
-                    }
-#endif
-#pragma unroll
-                    for (int span = 1; span < Q; span *= 2)
-#pragma unroll
-                        for (int q = 0; q + span < Q; q += 2 * span) ps[q] = ps[q] + ps[q + span];
-                    const double m = ((double)centre + (double)ps[0]) * inv;
-                    const float res = rec2 ? (float)(2.0 * m - (double)pv.x) : (float)m;
-                    float outv = res;
-                    if (cheb) {
-                        outv = fmaf(ck, res, pv.y);
-                        const f2a nv{centre, outv};
-                        if constexpr (PS_LDS) psl[c * G::TPX + i] = nv;
-                        else if (inimg && !last)
-                            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2v, nv), prs, (int)o * 8, c * ch_bytes, 0);
-                    }
-#if IRN_PROF_COMBINE == 1
-                    if (PROF && pslot) {
-                        asm volatile("" : "+v"(outv));
-                        pslot[3] = wall_clock64();
-                    }
-#elif IRN_PROF_COMBINE == 2
-                    if (PROF && pslot) {                                       // mode 2: [1] = arithmetic + LDS write done
-                        asm volatile("" : "+v"(outv));
-                        pslot[1] = wall_clock64();
-                    }
-#endif
-                    // neighbour lane's result through a DPP quad permute (lanes 2n <-> 2n+1) instead of an LDS round trip
-                    const float other = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(res), 0xB1, 0xF, 0xF, true));
-                    if (inimg) {
-                        if (last) ((gf_t)I.out)[(unsigned)c * n + o] = outv;
-                        else if ((x & 1) == 0 && xx + 1 < w) {
-                            if (plain_st) st_granule2<0>(dst, (int)o * 8, c * ch_bytes, want + 1, res, other);
-                            else st_granule2(dst, (int)o * 8, c * ch_bytes, want + 1, res, other);
-                        } else if ((x & 1) == 0) {
-                            if (plain_st) st_granule<0>(dst, (int)o * 8, c * ch_bytes, want + 1, res);
-                            else st_granule(dst, (int)o * 8, c * ch_bytes, want + 1, res);
-                        }
-                    }
-                };
-                static_assert(R != 10 || G::SLABS * 256 == 256, "one pixel per combining thread at radius 10");
-                if (!poller) {
-                    if (!cheb || c < G::CAPC) combine10(std::true_type{});
-                    else combine10(std::false_type{});
-                }
-                } else {
-                    // radius 5 (1024 pixels per tile, 4 per combining thread): a pixel PAIR per thread and iteration
-                    // (0.41 vs 0.75 us for four single pixels); the sums of all iterations are formed before the
-                    // first store so that their LDS reads overlap
-                    constexpr int NIT = G::SLABS * 128 / 256;
-                    // Three phases, each over all iterations: every read is issued before the first dependent operation,
-                    // every write comes last (written iteration by iteration, the LDS write of one iteration's recurrence
-                    // terms kept the next iteration's reads behind it — one array to the compiler — and the phase took
-                    // 0.8 us instead of 0.46).  Two copies of the body, chosen per step: recurrence terms in LDS (the
-                    // common case, no branches inside) or in the workspace (channels beyond CAPC).
-                    auto combine5 = [&](auto lds_tag) __attribute__((always_inline)) {
-                        constexpr bool PS_LDS = decltype(lds_tag)::value;
-                        float pa[NIT][Q], pb[NIT][Q], ce0[NIT], ce1[NIT];
-                        double iv0[NIT], iv1[NIT];
-                        f4a pv[NIT];
-#pragma unroll
-                        for (int it = 0; it < NIT; ++it) {
-                            const int i = tid + it * 256;
-                            const int s2 = i >> 7, prow = (i >> 4) & 7, x = (i & 15) * 2;
-                            const int py = (s2 / G::C::SL_X) * kSlabH + prow;
-                            const int px = (s2 % G::C::SL_X) * kSlabW + x;
-                            const int ii = s2 * 256 + prow * 32 + x;
-                            if constexpr (PS_LDS) {
-                                pv[it] = *reinterpret_cast<const f4a *>(psl + c * G::TPX + ii);
-                            } else {
-                                const int yy = ty0 + py, xx = tx0 + px;
-                                const bool in0 = yy < h && xx < w, in1 = in0 && xx + 1 < w;
-                                const unsigned o = (unsigned)(yy * w + xx);
-                                pv[it] = f4a{0.f, 0.f, 0.f, 0.f};
-                                if (in1) pv[it] = __builtin_bit_cast(f4a, __builtin_amdgcn_raw_buffer_load_b128(prs, (int)o * 8, c * ch_bytes, 0));
-                                else if (in0) {
-                                    const f2a p2 = __builtin_bit_cast(f2a, __builtin_amdgcn_raw_buffer_load_b64(prs, (int)o * 8, c * ch_bytes, 0));
-                                    pv[it].x = p2.x;
-                                    pv[it].y = p2.y;
-                                }
-                            }
-                            const float *pr = partf + (k & 1) * (kWaves * 256) + (s2 * Q) * 256 + (prow * 8 + (x >> 2)) * 4 + (x & 3);
-                            const float *xc = xsb + (py + H) * LW + px + HP;
-#pragma unroll
-                            for (int q = 0; q < Q; ++q) {
-                                pa[it][q] = pr[q * 256];
-                                pb[it][q] = pr[q * 256 + 1];
-                            }
-                            ce0[it] = xc[0];
-                            ce1[it] = xc[1];
-                            iv0[it] = invd[ii];
-                            iv1[it] = invd[ii + 1];
-                        }
-#if IRN_PROF_COMBINE == 1
-                        if (PROF && pslot) {                                   // [2] = every LDS read of the phase has landed
-                            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                            pslot[2] = wall_clock64();
-                        }
-#endif
-                        __builtin_amdgcn_sched_barrier(0);
-                        float r0v[NIT], r1v[NIT], s0v[NIT], s1v[NIT];
-#pragma unroll
-                        for (int it = 0; it < NIT; ++it) {
-                            float ps0 = pa[it][0], ps1 = pb[it][0];
-#pragma unroll
-                            for (int q = 1; q < Q; ++q) {
-                                ps0 += pa[it][q];
-                                ps1 += pb[it][q];
-                            }
-                            const double m0 = ((double)ce0[it] + (double)ps0) * iv0[it], m1 = ((double)ce1[it] + (double)ps1) * iv1[it];
-                            r0v[it] = rec2 ? (float)(2.0 * m0 - (double)pv[it].x) : (float)m0;
-                            r1v[it] = rec2 ? (float)(2.0 * m1 - (double)pv[it].z) : (float)m1;
-                            s0v[it] = fmaf(ck, r0v[it], pv[it].y);
-                            s1v[it] = fmaf(ck, r1v[it], pv[it].w);
-                        }
-#if IRN_PROF_COMBINE == 1
-                        if (PROF && pslot) {                                   // [3] = the arithmetic of both iterations is done
-#pragma unroll
-                            for (int it = 0; it < NIT; ++it)
-                                asm volatile("" : "+v"(r0v[it]), "+v"(r1v[it]), "+v"(s0v[it]), "+v"(s1v[it]));
-                            pslot[3] = wall_clock64();
-                        }
-#elif IRN_PROF_COMBINE == 2
-                        if (PROF && pslot) {
-#pragma unroll
-                            for (int it = 0; it < NIT; ++it)
-                                asm volatile("" : "+v"(r0v[it]), "+v"(r1v[it]), "+v"(s0v[it]), "+v"(s1v[it]));
-                            pslot[1] = wall_clock64();
-                        }
-#endif
-                        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                        for (int it = 0; it < NIT; ++it) {
-                            const int i = tid + it * 256;
-                            const int s2 = i >> 7, prow = (i >> 4) & 7, x = (i & 15) * 2;
-                            const int ii = s2 * 256 + prow * 32 + x;
-                            const int yy = ty0 + (s2 / G::C::SL_X) * kSlabH + prow;
-                            const int xx = tx0 + (s2 % G::C::SL_X) * kSlabW + x;
-                            const bool in0 = yy < h && xx < w, in1 = in0 && xx + 1 < w;
-                            const unsigned o = (unsigned)(yy * w + xx);
-                            if (cheb) {
-                                const f4a nv{ce0[it], s0v[it], ce1[it], s1v[it]};
-                                if constexpr (PS_LDS) {
-                                    *reinterpret_cast<f4a *>(psl + c * G::TPX + ii) = nv;
-                                } else if (!last) {
-                                    if (in1) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u4v, nv), prs, (int)o * 8, c * ch_bytes, 0);
-                                    else if (in0) __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u2v, f2a{ce0[it], s0v[it]}), prs, (int)o * 8, c * ch_bytes, 0);
-                                }
-                            }
-                            const float r0 = r0v[it], r1 = r1v[it];
-                            if (in0) {
-                                if (last) {         // the series sum is the result (plain powers: the state itself)
-                                    ((gf_t)I.out)[(unsigned)c * n + o] = cheb ? s0v[it] : r0;
-                                    if (in1) ((gf_t)I.out)[(unsigned)c * n + o + 1] = cheb ? s1v[it] : r1;
-                                } else if (in1) {
-                                    if (plain_st) st_granule2<0>(dst, (int)o * 8, c * ch_bytes, want + 1, r0, r1);
-                                    else st_granule2(dst, (int)o * 8, c * ch_bytes, want + 1, r0, r1);
-                                } else {
-                                    if (plain_st) st_granule<0>(dst, (int)o * 8, c * ch_bytes, want + 1, r0);
-                                    else st_granule(dst, (int)o * 8, c * ch_bytes, want + 1, r0);
-                                }
-                            }
-                        }
-                    };
-                    if (!poller) {
-                        if (!cheb || c < G::CAPC) combine5(std::true_type{});
-                        else combine5(std::false_type{});
-                    }
-                }
-            }
-#if IRN_PROF_COMBINE == 2
-            if (PROF && pslot) pslot[2] = wall_clock64();                      // mode 2: [2] = LDS writes and global stores issued
-#endif
-            fresh = false;
-            // C = 1: the next poll is timed from our own stores, so every wave has to start its delay
-            // behind them (the waves that do not combine would otherwise poll ~0.2 us early)
-            if (C == 1) __syncthreads();
-#if IRN_PROF_COMBINE != 1
-            if (PROF && pslot) pslot[3] = wall_clock64();
-#endif
-            t = tn;
-            c = cn;
+        } else {
+            constexpr int ROLE = 0;
+            const bool poller_ = poller;
+#define IRN_STEP_ABORT return
+#include "walk_resident_steps.inc"
+#undef IRN_STEP_ABORT
         }
         // a walk cut into several launches (test hook): the LDS-held terms go back to the workspace for the next one
         if (c_lds > 0 && t_first + t_count < t_total) {
