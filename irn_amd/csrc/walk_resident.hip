@@ -78,7 +78,12 @@ template <>
 struct RCfg<5> {
     static constexpr int Q = 2, SL_Y = 2, SL_X = 2;
     static constexpr bool PREFETCH_ROWS = true;     // fits since the fp32 chains freed the fp64 accumulators (250 VGPRs)
-    static constexpr bool ROLE_SPLIT = false;       // split, the radius-5 instantiation spills six registers
+#ifndef IRN_R5_ROLE_SPLIT
+#define IRN_R5_ROLE_SPLIT 1
+#endif
+    // split, this instantiation spills six loop-invariant registers that the polling waves reload once per step (their
+    // staging addresses) — and is still 3.6 % faster (profiles/r04_s11_role_split_radius5_ab.txt)
+    static constexpr bool ROLE_SPLIT = IRN_R5_ROLE_SPLIT != 0;
 };
 
 // The neighbour disc (dy,dx) != (0,0), dx^2 + dy^2 < R^2, in raster order: the union of the
@@ -571,11 +576,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         int t = t_first, c = 0;
         bool fresh = true;             // first step of the job: its input has been there since before the launch
         bool polled = false;           // the poll of the current step is already in flight
-        // One copy of the step loop per wave ROLE at radius 10 (round 4): the polling waves' copy has no stores and the
+        // One copy of the step loop per wave ROLE (round 4): the polling waves' copy has no stores and the
         // combining waves' copy no poll registers, so no wait — and no register-allocation accident — of one role can land on
-        // the other; each copy's arithmetic switch holds only its own four parts, so the code does not grow.  Measured
+        // the other; at radius 10 each copy's arithmetic switch holds only its own four parts, so the code does not grow.  Measured
         // (profiles/r04_s10_role_split_ab.txt): default workload +4.2 %, COCO shape +6.1 %; steps 2.12 / 1.49 / 1.38 ->
-        // 1.94 / 1.40 / 1.29 us at 1 / 2 / 3 channels.  Radius 5 keeps the shared copy: split, it spills six registers.
+        // 1.94 / 1.40 / 1.29 us at 1 / 2 / 3 channels; radius 5 (r04_s11): 66 398 -> 68 815 images/s, steps 1.88 / 1.54 -> 1.79 / 1.41 us.
         if constexpr (RCfg<R>::ROLE_SPLIT) {
             auto step_loop = [&](auto role_tag) __attribute__((always_inline)) -> bool {
                 constexpr int ROLE = decltype(role_tag)::value;
