@@ -54,6 +54,9 @@ typedef const double IRN_GLOBAL *gcd_t;
 typedef float IRN_GLOBAL *gf_t;
 typedef float f4a __attribute__((ext_vector_type(4)));
 
+#ifndef IRN_R5_SHARED_COMBINE
+#define IRN_R5_SHARED_COMBINE 1    // radius 5, single-channel jobs: the polling waves take half of the combine (walk_resident_steps.inc)
+#endif
 #ifndef IRN_PROF_COMBINE
 #define IRN_PROF_COMBINE 0     // diagnostic builds only (tools/combine_profile.py): 1 / 2 move the PROF stamps into the combine phase
 #endif
