@@ -21,6 +21,10 @@
 //     0-3 add them pairwise in fp32, add the centre term and multiply by 1/deg in fp64, apply the recurrence of the
 //     schedule (below) and store y_{t+1}[c] (numerics: tests/test_precision_model.py).  Channels are
 //     independent chains: with C >= 2 the poll of the next step flies during the arithmetic of this one.
+//   * the step loop (walk_resident_steps.inc) exists once per wave ROLE since round 4: the polling waves' copy never
+//     stores, the combining waves' copy holds no poll registers; a wave branches into its copy once per job and the
+//     barriers of the two copies match one for one (LESSONS.md 31).  Radius 5, single-channel jobs: the polling waves
+//     take half of the combine.
 //
 // Exchange between workgroups (tiles of one image; no kernel boundary between sweeps)
 //   state buffers hold one 8-byte granule {tag = sweep + 1, fp32 value} per pixel and channel, written
