@@ -156,7 +156,7 @@ int irn_walk_fallback_runs(irn_walk_ctx *ctx);
  *   placement   0 not checked yet, 1 "block b of a launch runs on XCD b % 8" holds on this device (the tiles of an image are
  *               then packed onto one XCD), 2 it does not (tiles keep launch order; one line on stderr says so);
  *   poll_delay  the delay (units of 64 clocks) between a single-channel tile's stores and its first poll in use now;
- *   probe_ms4   launch times in ms the start-up probe measured for delays 6, 8, 10, 12 on this context's first representative
+ *   probe_ms4   launch times in ms the start-up probe measured for delays 8, 10, 12, 14 on this context's first representative
  *               batch (zeros: this context did not probe — too small a batch, another context of the process probed
  *               before, or option "poll_delay" pinned the value; "poll_delay_auto" = 0 switches the probe off).
  * Any pointer may be null. */

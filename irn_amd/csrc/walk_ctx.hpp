@@ -109,7 +109,7 @@ struct irn_walk_ctx {
     long long *res_prof_dev = nullptr;     // [2][256][4] time stamps (option "profile")
     int res_poll_delay = 10;   // s_sleep(1) units (64 clocks): first poll this long after our own stores
     int res_poll_auto = 1;     // 1: the first representative batch of the process probes 8 / 10 / 12 (walk_resident.hip); 0: pinned
-    float res_poll_probe_ms[4] = {0.f, 0.f, 0.f, 0.f};   // launch times the probe measured for delays 6, 8, 10, 12 (0 = not probed by this context)
+    float res_poll_probe_ms[4] = {0.f, 0.f, 0.f, 0.f};   // launch times the probe measured for delays 8, 10, 12, 14 (0 = not probed by this context)
     int res_placement = 0;     // block -> XCD round robin: 0 not checked, 1 holds, 2 does not (resident_check_placement)
     bool res_plain_store = false;          // radius 5: plain state stores for images whose tiles share an XCD (voted in-kernel)
     int res_poll_delay_plain = 2;          // poll delay of such jobs

@@ -875,9 +875,9 @@ static int resident_enqueue(irn_walk_ctx *ctx, hipStream_t stream) {
 // neighbours') was tuned by hand on one box: 8 / 10 / 12 within 2 % of each other there, 20 before the stores were
 // widened.  It is a property of the fabric's store -> load latency at this clock, so instead of trusting the constant the
 // first representative batch of a process (radius 10, >= 4 rounds, at least a third of its images single-channel) is
-// run with 6, 8, 10 and 12 — twice each, the walk writes the same bits whatever the delay — and the fastest wins if it
-// beats the default (10) by more than 0.7 % (round 4's three sessions: 8 was 0.6-1.5 % ahead of 10 every time, 12 behind); cached
-// per device.  Option "poll_delay" (or IRN_POLL_DELAY) pins the value and
+// run with 8, 10, 12 and 14 — twice each, the walk writes the same bits whatever the delay — and the fastest wins if it
+// beats the default (10) by more than 0.7 %; cached per device.  (Round 4: with the shared step loop 8 was 0.6-1.5 % ahead of 10 on
+// three boxes; with one loop per wave role 10 and 12 are level and 8 is 3.5 % behind — the optimum moves with the code.)  Option "poll_delay" (or IRN_POLL_DELAY) pins the value and
 // switches the probe off.  g_poll_delay[dev]: 0 = not probed yet.
 static int g_poll_delay[64] = {};
 
@@ -899,7 +899,7 @@ static int resident_probe_poll_delay(irn_walk_ctx *ctx, hipStream_t stream) {
     IRN_HIP_TRY(hipEventCreate(&e0));
     IRN_HIP_TRY(hipEventCreate(&e1));
     constexpr int NC = 4;
-    const int cand[NC] = {10, 8, 6, 12};            // the hand-tuned default first
+    const int cand[NC] = {10, 8, 12, 14};           // the hand-tuned default first
     float best_ms[NC] = {1e30f, 1e30f, 1e30f, 1e30f};
     int rc = IRN_OK;
     for (int rep = 0; rep < 2 && !rc; ++rep)
@@ -921,9 +921,9 @@ static int resident_probe_poll_delay(irn_walk_ctx *ctx, hipStream_t stream) {
     for (int k = 1; k < NC; ++k)
         if (best_ms[k] < 0.993f * best_ms[0] && best_ms[k] < best_ms[pick]) pick = k;      // 0.7 %: twice the run-to-run spread of the minimum of two
     ctx->res_poll_delay = cand[pick];
-    ctx->res_poll_probe_ms[0] = best_ms[2];      // 6, 8, 10, 12 in that order
-    ctx->res_poll_probe_ms[1] = best_ms[1];
-    ctx->res_poll_probe_ms[2] = best_ms[0];
+    ctx->res_poll_probe_ms[0] = best_ms[1];      // 8, 10, 12, 14 in that order
+    ctx->res_poll_probe_ms[1] = best_ms[0];
+    ctx->res_poll_probe_ms[2] = best_ms[2];
     ctx->res_poll_probe_ms[3] = best_ms[3];
     if (!rc && best_ms[0] < 1e29f) g_poll_delay[dev] = cand[pick];
     return rc;

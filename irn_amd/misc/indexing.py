@@ -297,7 +297,7 @@ class RandomWalk:
 
     def tuning(self):
         """{'poll_delay', 'placement' (0 unchecked / 1 block -> XCD round robin holds / 2 it does not), 'probe_ms' (launch
-        times the start-up probe measured for poll delays 6, 8, 10, 12, or None)} — irn_walk_tuning."""
+        times the start-up probe measured for poll delays 8, 10, 12, 14, or None)} — irn_walk_tuning."""
         d, pl = C.c_int(), C.c_int()
         ms = (C.c_float * 4)()
         check(lib.irn_walk_tuning(self._ctx, C.byref(d), C.byref(pl), ms))
