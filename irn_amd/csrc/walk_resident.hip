@@ -58,6 +58,9 @@ typedef const double IRN_GLOBAL *gcd_t;
 typedef float IRN_GLOBAL *gf_t;
 typedef float f4a __attribute__((ext_vector_type(4)));
 
+#ifndef IRN_R10_COMBINER_UNSPLIT
+#define IRN_R10_COMBINER_UNSPLIT 1 // radius 10, two channels: the combining waves (no poll to issue) run the arithmetic as ONE pipeline
+#endif
 #ifndef IRN_R5_SHARED_COMBINE
 #define IRN_R5_SHARED_COMBINE 1    // radius 5, single-channel jobs: the polling waves take half of the combine (walk_resident_steps.inc)
 #endif
