@@ -730,26 +730,64 @@ int resident_configure(irn_walk_ctx *ctx) {
         if (ctx->c[a] != ctx->c[b]) return ctx->c[a] > ctx->c[b];
         return tiles[a] > tiles[b];
     });
-    std::vector<std::vector<int4>> rounds;
+    std::vector<std::vector<int>> round_imgs;
     std::vector<int> used;
     for (int oi = 0; oi < n; ++oi) {
         const int i = order[oi];
         size_t r = 0;
-        for (; r < rounds.size(); ++r)
+        for (; r < round_imgs.size(); ++r)
             if (used[r] + tiles[i] <= n_wg) break;
-        if (r == rounds.size()) {
-            rounds.emplace_back(n_wg, make_int4(-1, 0, 0, 0));
+        if (r == round_imgs.size()) {
+            round_imgs.emplace_back();
             used.push_back(0);
         }
-        for (int ty = 0; ty < ctx->h[i]; ty += th)
-            for (int tx = 0; tx < ctx->w[i]; tx += tw) {
-                const int slot = used[r]++;
-                // consecutive slots share an XCD: block b is dispatched to XCD b % 8 (checked: resident_check_placement)
-                const int per = (n_wg + 7) / 8;
-                int b = (slot % per) * 8 + slot / per;
-                if (n_wg % 8 != 0 || b >= n_wg || ctx->res_placement == 2) b = slot;
-                rounds[r][b] = make_int4(i, ty, tx, tiles[i]);
-            }
+        round_imgs[r].push_back(i);
+        used[r] += tiles[i];
+    }
+    // Placement inside a round.  The tile groups of the same slot range run their rounds back to back, so a range that
+    // was handed the heavier image of every mixed round (descending order: always the first one) finishes last — by up
+    // to the cost difference between the heaviest and the lightest image of the batch.  Where the images of a round
+    // have equal tile counts (the slot ranges are interchangeable) the heaviest image goes to the range that is free
+    // first.  Cost model: steps x channels x the measured step period of that channel count (relative weights only).
+    auto cost_of = [&](int i) {
+        const int c = ctx->c[i];
+        return 7.0 + c * (c == 1 ? 1.5 : c == 2 ? 1.07 : 1.0) * 84.0;
+    };
+    std::vector<double> busy(n_wg, 0.0);                   // modelled finishing time of each slot so far
+    std::vector<std::vector<int4>> rounds;
+    for (auto &imgs : round_imgs) {
+        rounds.emplace_back(n_wg, make_int4(-1, 0, 0, 0));
+        const int m = (int)imgs.size();
+        bool uniform = true;
+        for (int j = 1; j < m; ++j) uniform = uniform && tiles[imgs[j]] == tiles[imgs[0]];
+        std::vector<int> first(m);                         // first slot of range j
+        for (int j = 0, sl = 0; j < m; ++j) {
+            first[j] = sl;
+            sl += tiles[imgs[j]];
+        }
+        std::vector<int> range_of(m);                      // image j of the round (descending cost) -> range
+        for (int j = 0; j < m; ++j) range_of[j] = j;
+        if (uniform && m > 1) {
+            std::vector<double> ready(m, 0.0);
+            for (int j = 0; j < m; ++j)
+                for (int q = 0; q < tiles[imgs[0]]; ++q) ready[j] = std::max(ready[j], busy[first[j] + q]);
+            std::stable_sort(range_of.begin(), range_of.end(), [&](int a, int b) { return ready[a] < ready[b]; });
+        }
+        for (int j = 0; j < m; ++j) {
+            const int i = imgs[j], rg = range_of[j];
+            double start = 0.0;
+            for (int q = 0; q < tiles[i]; ++q) start = std::max(start, busy[first[rg] + q]);
+            for (int q = 0; q < tiles[i]; ++q) busy[first[rg] + q] = start + cost_of(i);
+            int slot = first[rg];
+            for (int ty = 0; ty < ctx->h[i]; ty += th)
+                for (int tx = 0; tx < ctx->w[i]; tx += tw, ++slot) {
+                    // consecutive slots share an XCD: block b is dispatched to XCD b % 8 (checked: resident_check_placement)
+                    const int per = (n_wg + 7) / 8;
+                    int b = (slot % per) * 8 + slot / per;
+                    if (n_wg % 8 != 0 || b >= n_wg || ctx->res_placement == 2) b = slot;
+                    rounds[rounds.size() - 1][b] = make_int4(i, ty, tx, tiles[i]);
+                }
+        }
     }
     const int total = (int)rounds.size() * n_wg;
     if (total > ctx->res_cap_jobs) {
