@@ -162,6 +162,17 @@ int irn_walk_fallback_runs(irn_walk_ctx *ctx);
  * Any pointer may be null. */
 int irn_walk_tuning(irn_walk_ctx *ctx, int *poll_delay, int *placement, float *probe_ms4);
 
+/* How the weights-stationary walk packs a batch onto the device — host arithmetic only, no device and no context needed
+ * (the CPU tests check it; the reference has no counterpart: it walks one image at a time, step/make_sem_seg_labels.py:41).
+ * Images i = 0..n_images-1 of h[i] x w[i] grid pixels and channels[i] walk channels are cut into tiles (one workgroup each)
+ * and packed into rounds of at most n_workgroups tiles; the workgroups run their rounds back to back, so inside a round the
+ * heaviest image goes to the slot range that is free first.  placement as irn_walk_tuning reports it (1: consecutive slots
+ * share an XCD, 2: launch order).  jobs_out: int32 [cap_rounds][n_workgroups][4] = {image or -1, tile y0, tile x0, tiles of
+ * the image}; *n_rounds = rounds needed, 0 when the batch does not fit the persistent launch (an image with more tiles than
+ * workgroups, or narrower than the radius: such batches run on the streaming sweeps).  cap_rounds = 0 only asks for *n_rounds. */
+int irn_walk_plan_rounds(int radius, int n_images, const int32_t *h, const int32_t *w, const int32_t *channels,
+                         int n_workgroups, int placement, int32_t *jobs_out, int cap_rounds, int *n_rounds);
+
 /* Diagnostic (option "profile" = 1, resident walk only): per-sweep time stamps of two workgroups of
  * the first round — host_out is int64 [2][256][4] = {sweep start, state staged, first partial sums
  * in LDS, sweep stored} in ticks of the 100 MHz wall clock.  Synchronises the device. */

@@ -46,6 +46,7 @@ _SIGS = {
     "irn_walk_check": (i32, [vp]),
     "irn_walk_fallback_runs": (i32, [vp]),
     "irn_walk_tuning": (i32, [vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(f32)]),
+    "irn_walk_plan_rounds": (i32, [i32, i32, pi32, pi32, pi32, i32, i32, pi32, i32, C.POINTER(i32)]),
     "irn_walk_read_profile": (i32, [vp, vp]),
     "irn_walk_enable_timing": (i32, [vp, i32]),
     "irn_walk_last_sweep_ms": (i32, [vp, C.POINTER(f32), C.POINTER(i32)]),

@@ -1143,6 +1143,23 @@ extern "C" int irn_walk_tuning(irn_walk_ctx *ctx, int *poll_delay, int *placemen
     return IRN_OK;
 }
 
+extern "C" int irn_walk_plan_rounds(int radius, int n_images, const int32_t *h, const int32_t *w, const int32_t *channels,
+                                    int n_workgroups, int placement, int32_t *jobs_out, int cap_rounds, int *n_rounds) {
+    if (!h || !w || !channels || !n_rounds || n_images < 1 || n_workgroups < 1 || cap_rounds < 0 || (cap_rounds > 0 && !jobs_out))
+        return fail(IRN_ERR_ARG, "irn_walk_plan_rounds: bad argument");
+    if (radius != 5 && radius != 10) return fail(IRN_ERR_ARG, "irn_walk_plan_rounds: the persistent walk exists for radius 5 and 10");
+    std::vector<int> jobs;
+    int nr = 0;
+    if (!irn::resident_plan_rounds(radius, n_images, h, w, channels, n_workgroups, placement, jobs, &nr)) {
+        *n_rounds = 0;                       // not an error: such a batch runs on the streaming sweeps
+        return IRN_OK;
+    }
+    *n_rounds = nr;
+    if (nr > cap_rounds) return cap_rounds == 0 ? IRN_OK : fail(IRN_ERR_ARG, "irn_walk_plan_rounds: jobs_out too small");
+    std::copy(jobs.begin(), jobs.end(), jobs_out);
+    return IRN_OK;
+}
+
 extern "C" int irn_walk_read_profile(irn_walk_ctx *ctx, long long *host_out) {
     if (!ctx || !host_out) return fail(IRN_ERR_ARG, "null argument");
     if (!ctx->res_prof_dev) return fail(IRN_ERR_STATE, "option 'profile' is off");

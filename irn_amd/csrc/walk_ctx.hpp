@@ -146,6 +146,9 @@ namespace irn {
 // walk_resident.hip: weights-stationary persistent walk (variant 2)
 bool resident_supported(const irn_walk_ctx *ctx);
 int resident_configure(irn_walk_ctx *ctx);
+// the packing of a batch into rounds of the persistent launch, as plain host arithmetic (irn_walk_plan_rounds)
+bool resident_plan_rounds(int radius, int n, const int *h, const int *w, const int *c, int n_wg, int placement,
+                          std::vector<int> &jobs, int *n_rounds);
 int resident_run(irn_walk_ctx *ctx, int n_sweeps, hipStream_t stream);
 // walk.hip: the schedule that evaluates x . T^n_sweeps for this context's options (uploads the coefficient table on
 // first use; stream-ordered) — ctx->sched_steps operator applications

@@ -693,32 +693,18 @@ int resident_check_placement(irn_walk_ctx *ctx) {
     return IRN_OK;
 }
 
-// Pack the batch into rounds of at most n_wg tiles.  Sets ctx->res_ok = false (not an error) when an
-// image does not fit one round or is narrower than the radius (then irn_walk_run falls back to the
-// streaming sweeps).
-int resident_configure(irn_walk_ctx *ctx) {
-    ctx->res_ok = false;
-    if (!resident_supported(ctx)) return IRN_OK;
-    if (ctx->res_nwg == 0) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        IRN_HIP_TRY(hipGetDevice(&dev));
-        IRN_HIP_TRY(hipGetDeviceProperties(&prop, dev));
-        ctx->res_nwg = prop.multiProcessorCount;
-    }
-    const int n_wg = ctx->res_nwg;
-    if (ctx->res_placement == 0) {
-        const int rc_p = resident_check_placement(ctx);
-        if (rc_p) return rc_p;
-    }
+// Pack a batch into rounds of at most n_wg tiles (pure host arithmetic: no device, no context — also exported for the CPU
+// tests as irn_walk_plan_rounds).  False when an image does not fit one round or is narrower than the radius.
+static bool pack_rounds(int radius, const std::vector<int> &h, const std::vector<int> &w, const std::vector<int> &c, int n_wg,
+                        int placement, std::vector<std::vector<int4>> &rounds) {
     int th, tw;
-    tile_shape(ctx->radius, &th, &tw);
-    const int n = (int)ctx->h.size();
+    tile_shape(radius, &th, &tw);
+    const int n = (int)h.size();
     std::vector<int> tiles(n);
     for (int i = 0; i < n; ++i) {
-        if (ctx->w[i] < ctx->radius) return IRN_OK;
-        tiles[i] = cdiv(ctx->h[i], th) * cdiv(ctx->w[i], tw);
-        if (tiles[i] > n_wg) return IRN_OK;
+        if (w[i] < radius) return false;
+        tiles[i] = cdiv(h[i], th) * cdiv(w[i], tw);
+        if (tiles[i] > n_wg) return false;
     }
     // First-fit over the images in descending cost order (channels = steps per sweep, then tiles);
     // slots of an image are consecutive.  Workgroups run their rounds back to back without a grid
@@ -727,7 +713,7 @@ int resident_configure(irn_walk_ctx *ctx) {
     std::vector<int> order(n);
     for (int i = 0; i < n; ++i) order[i] = i;
     std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
-        if (ctx->c[a] != ctx->c[b]) return ctx->c[a] > ctx->c[b];
+        if (c[a] != c[b]) return c[a] > c[b];
         return tiles[a] > tiles[b];
     });
     std::vector<std::vector<int>> round_imgs;
@@ -748,13 +734,15 @@ int resident_configure(irn_walk_ctx *ctx) {
     // was handed the heavier image of every mixed round (descending order: always the first one) finishes last — by up
     // to the cost difference between the heaviest and the lightest image of the batch.  Where the images of a round
     // have equal tile counts (the slot ranges are interchangeable) the heaviest image goes to the range that is free
-    // first.  Cost model: steps x channels x the measured step period of that channel count (relative weights only).
+    // first.  Cost model: steps x channels x the measured step period of that channel count (relative weights only;
+    // profiles/r04_s15_resident_step_profile.txt: 1.94 / 1.37 / 1.26 us at radius 10, 1.68 / 1.46 / 1.47 at radius 5).
     auto cost_of = [&](int i) {
-        const int c = ctx->c[i];
-        return 7.0 + c * (c == 1 ? 1.5 : c == 2 ? 1.07 : 1.0) * 84.0;
+        const int ch = c[i];
+        const double per = radius == 10 ? (ch == 1 ? 1.5 : ch == 2 ? 1.07 : 1.0) : (ch == 1 ? 1.15 : 1.0);
+        return 7.0 + ch * per * 84.0;
     };
     std::vector<double> busy(n_wg, 0.0);                   // modelled finishing time of each slot so far
-    std::vector<std::vector<int4>> rounds;
+    rounds.clear();
     for (auto &imgs : round_imgs) {
         rounds.emplace_back(n_wg, make_int4(-1, 0, 0, 0));
         const int m = (int)imgs.size();
@@ -779,16 +767,58 @@ int resident_configure(irn_walk_ctx *ctx) {
             for (int q = 0; q < tiles[i]; ++q) start = std::max(start, busy[first[rg] + q]);
             for (int q = 0; q < tiles[i]; ++q) busy[first[rg] + q] = start + cost_of(i);
             int slot = first[rg];
-            for (int ty = 0; ty < ctx->h[i]; ty += th)
-                for (int tx = 0; tx < ctx->w[i]; tx += tw, ++slot) {
+            for (int ty = 0; ty < h[i]; ty += th)
+                for (int tx = 0; tx < w[i]; tx += tw, ++slot) {
                     // consecutive slots share an XCD: block b is dispatched to XCD b % 8 (checked: resident_check_placement)
                     const int per = (n_wg + 7) / 8;
                     int b = (slot % per) * 8 + slot / per;
-                    if (n_wg % 8 != 0 || b >= n_wg || ctx->res_placement == 2) b = slot;
+                    if (n_wg % 8 != 0 || b >= n_wg || placement == 2) b = slot;
                     rounds[rounds.size() - 1][b] = make_int4(i, ty, tx, tiles[i]);
                 }
         }
     }
+    return true;
+}
+
+bool resident_plan_rounds(int radius, int n, const int *h, const int *w, const int *c, int n_wg, int placement,
+                          std::vector<int> &jobs, int *n_rounds) {
+    std::vector<std::vector<int4>> rounds;
+    if (!pack_rounds(radius, std::vector<int>(h, h + n), std::vector<int>(w, w + n), std::vector<int>(c, c + n), n_wg, placement,
+                     rounds))
+        return false;
+    jobs.clear();
+    for (auto &r : rounds)
+        for (const int4 &j : r) {
+            jobs.push_back(j.x);
+            jobs.push_back(j.y);
+            jobs.push_back(j.z);
+            jobs.push_back(j.w);
+        }
+    *n_rounds = (int)rounds.size();
+    return true;
+}
+
+// Pack the batch into rounds of at most n_wg tiles.  Sets ctx->res_ok = false (not an error) when an
+// image does not fit one round or is narrower than the radius (then irn_walk_run falls back to the
+// streaming sweeps).
+int resident_configure(irn_walk_ctx *ctx) {
+    ctx->res_ok = false;
+    if (!resident_supported(ctx)) return IRN_OK;
+    if (ctx->res_nwg == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        IRN_HIP_TRY(hipGetDevice(&dev));
+        IRN_HIP_TRY(hipGetDeviceProperties(&prop, dev));
+        ctx->res_nwg = prop.multiProcessorCount;
+    }
+    const int n_wg = ctx->res_nwg;
+    if (ctx->res_placement == 0) {
+        const int rc_p = resident_check_placement(ctx);
+        if (rc_p) return rc_p;
+    }
+    std::vector<std::vector<int4>> rounds;
+    if (!pack_rounds(ctx->radius, ctx->h, ctx->w, ctx->c, n_wg, ctx->res_placement, rounds)) return IRN_OK;
+    const int n = (int)ctx->h.size();
     const int total = (int)rounds.size() * n_wg;
     if (total > ctx->res_cap_jobs) {
         if (ctx->res_jobs_dev) (void)hipFree(ctx->res_jobs_dev);
