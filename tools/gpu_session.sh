@@ -1,5 +1,5 @@
 #!/bin/bash
-# One gpurun call of round 4 (results land in gpurun_out/r3_sN/; copy what should be judged into profiles/).
+# One gpurun call of round 4 (results land in gpurun_out/r4_sN/; copy what should be judged into profiles/).
 # usage: tools/gpu_session.sh <N> [what...]
 #   what: tests tests_all testsel smoke bench default ab abopt prof pmc pmcsq <script under tools/>
 #   env:  TESTSEL="-k expr or paths" (testsel), AB_LIBS="libirn_hip.so other.so", AB_WL="walk coco walk_r5",
