@@ -269,6 +269,24 @@ int irn_bn_act(float *x_dev, const float *res_dev, const float *scale_dev, const
 int irn_bn_act_nhwc(float *x_dev, const float *res_dev, const float *scale_dev, const float *shift_dev, const float *res_scale_dev,
                     const float *res_shift_dev, int64_t n_pixels, int n_channels, int relu, void *stream);
 
+/* 1x1 convolution of a channels-last activation with its whole elementwise tail in the GEMM's epilogue (hipBLASLt, fp32
+ * compute): conv1 -> bn1 -> ReLU and conv3 -> bn3 -> (+ residual) -> ReLU of Bottleneck.forward, reference
+ * net/resnet50.py:34-54 (FixedBatchNorm :11-14 is a constant affine map: its scale is folded into `w` by the caller in
+ * double precision, its shift is `bias`), and the projection shortcut :48-49.
+ *   x dev fp32 [m, cin] (= [N, cin, H, W] in torch.channels_last, m = N*H*W), w dev fp32 [cout, cin] (the convolution's
+ *   weight, scale folded in), bias dev fp32 [cout] or NULL, residual dev fp32 [m, cout] or NULL (may be `out`),
+ *   out dev fp32 [m, cout]:      out = act(x . w^T + bias (+ residual)),   act = ReLU if relu else identity.
+ *   algo_rank: 0 = hipBLASLt's first heuristic choice for the problem, k = its k-th (irn_conv1x1_algo_count gives how many
+ *   there are): a function of the problem only, never of a timing made in this process, so that every process computes
+ *   the same bits.  workspace: caller device memory of irn_conv1x1_workspace_bytes() (may be 0 / NULL: fewer kernels
+ *   qualify).  Enqueued on `stream`; nothing synchronises. */
+size_t irn_conv1x1_workspace_bytes(void);
+int irn_conv1x1_algo_count(int64_t m, int cin, int cout, int has_bias, int has_residual, int relu, size_t workspace_bytes,
+                           int *count_out);
+int irn_conv1x1_nhwc(const float *x_dev, const float *w_dev, const float *bias_dev, const float *residual_dev, float *out_dev,
+                     int64_t m, int cin, int cout, int relu, int algo_rank, void *workspace_dev, size_t workspace_bytes,
+                     void *stream);
+
 /* Stem: batch norm + ReLU + max pool 3x3 / stride 2 / pad 1 in one pass (reference net/resnet50.py:94-97; the nets'
  * stage1, net/resnet50_cam.py:14, net/resnet50_irn.py:15).
  *   x dev fp32 [n_images, n_channels, h, w] (conv1's output) -> out dev fp32 [n_images, n_channels, (h-1)/2+1, (w-1)/2+1]

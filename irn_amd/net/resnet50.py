@@ -86,6 +86,17 @@ def _fused(x):
             and not torch.is_grad_enabled())
 
 
+# IRN_FUSED_GEMM=0 keeps the trunk's 1x1 convolutions on MIOpen with a separate `bn_act_` pass behind each (A/B runs)
+FUSED_GEMM = os.environ.get("IRN_FUSED_GEMM", "1") != "0"
+
+
+def _gemm_path(x):
+    """A bottleneck's 1x1 convolutions run as hipBLASLt GEMMs with a fused epilogue when its input is a channels-last
+    activation on the inference path (the layout in which the activation IS the GEMM's operand)."""
+    return (FUSED_GEMM and FUSED_EPILOGUE and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and not torch.is_grad_enabled()
+            and not x.is_contiguous() and x.is_contiguous(memory_format=torch.channels_last) and x.data_ptr() % 16 == 0)
+
+
 def to_stage_format(x, channels_last):
     """Activation entering a trunk stage."""
     return x.contiguous(memory_format=torch.channels_last) if channels_last else x
@@ -183,13 +194,58 @@ class Bottleneck(nn.Module):
             self.downsample = nn.Sequential(nn.Conv2d(c_in, c_out, 1, stride=stride, bias=False),
                                             FrozenBatchNorm(c_out))
 
+    _gemm = None
+
+    def gemm_params(self):
+        """The unit's 1x1 convolutions as GEMM operands: weights [cout, cin] with their batch norm's scale folded in
+        (double precision, rounded once), the shifts as biases; for a projection unit the shortcut's shift rides in
+        conv3's bias (the shortcut GEMM has none).  Cached until a parameter or statistic is written or moved."""
+        convs = [self.conv1, self.conv3] + ([] if self.downsample is None else [self.downsample[0]])
+        bns = [self.bn1, self.bn3] + ([] if self.downsample is None else [self.downsample[1]])
+        src = [c.weight for c in convs] + [t for b in bns for t in (b.weight, b.bias, b.running_mean, b.running_var)]
+        key = tuple((t.data_ptr(), _version(t)) for t in src)
+        if self._gemm is None or self._gemm[0] != key:
+            with torch.no_grad():
+                folded = []
+                for c, b in zip(convs, bns):
+                    scale = b.weight.detach().double() / torch.sqrt(b.running_var.detach().double() + b.eps)
+                    shift = b.bias.detach().double() - b.running_mean.detach().double() * scale
+                    folded.append(((c.weight.detach().double() * scale.view(-1, 1, 1, 1)).float().contiguous(), shift))
+                p = {"w1": folded[0][0].flatten(1), "b1": folded[0][1].float().contiguous(), "w3": folded[1][0].flatten(1)}
+                if self.downsample is None:
+                    p["b3"] = folded[1][1].float().contiguous()
+                else:
+                    p["wd"] = folded[2][0]                                   # [cout, cin, 1, 1]: also MIOpen's operand when strided
+                    p["b3"] = (folded[1][1] + folded[2][1]).float().contiguous()
+            self._gemm = (key, p)
+        return self._gemm[1]
+
     def forward(self, x):
+        if _gemm_path(x):
+            return self._forward_gemm(x)
         y = self.bn1.apply_(self.conv1(x), relu=True)
         y = self.bn2.apply_(self.conv2(y), relu=True)
         if self.downsample is None:
             return self.bn3.apply_(self.conv3(y), residual=x, relu=True)
         # the shortcut's batch norm rides in the same pass: its output never exists as a tensor
         return self.bn3.apply_(self.conv3(y), residual=self.downsample[0](x), relu=True, residual_bn=self.downsample[1])
+
+    def _forward_gemm(self, x):
+        """Channels-last inference path: conv1 and conv3 are GEMMs over the [pixels, channels] matrix the activation
+        already is, with batch norm, residual and ReLU in their epilogue (`ops.conv1x1_nhwc`) — no elementwise pass is
+        left around them; the 3x3 convolution stays on MIOpen with its one in-place `bn_act_` pass."""
+        from .. import ops
+        p = self.gemm_params()
+        y = ops.conv1x1_nhwc(x, p["w1"], p["b1"], relu=True)
+        y = self.bn2.apply_(self.conv2(y), relu=True).contiguous(memory_format=torch.channels_last)
+        if self.downsample is None:
+            return ops.conv1x1_nhwc(y, p["w3"], p["b3"], residual=x, relu=True)
+        ds = self.downsample[0]
+        if tuple(ds.stride) == (1, 1):
+            sc = ops.conv1x1_nhwc(x, p["wd"].flatten(1))
+        else:                   # a strided shortcut is not a matrix view of x: MIOpen, with the folded weight
+            sc = F.conv2d(x, p["wd"], None, ds.stride).contiguous(memory_format=torch.channels_last)
+        return ops.conv1x1_nhwc(y, p["w3"], p["b3"], residual=sc, relu=True, out=sc)
 
 
 def _stage(c_in, planes, n_blocks, stride, dilation):

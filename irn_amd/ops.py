@@ -158,6 +158,76 @@ def bn_act_(x, scale, shift, residual=None, relu=True, residual_affine=None):
     return x
 
 
+_GEMM_WS = {}          # device index -> workspace tensor of the fused 1x1 convolutions (one per device, stream-ordered use)
+_GEMM_RANKS = None     # (m, cin, cout, bias, residual, relu) -> rank in hipBLASLt's heuristic list, measured once per device
+
+
+def gemm_ranks():
+    """The shipped table `irn_amd/data/gemm/<device>-hip<version>.json` (written by tools/conv1x1_tune.py on a GPU box):
+    for the problems listed, which entry of hipBLASLt's heuristic list was fastest.  Problems not listed use entry 0.  The
+    table is data, not a timing: every process picks the same kernel for the same problem."""
+    global _GEMM_RANKS
+    if _GEMM_RANKS is None:
+        ranks = {}
+        try:
+            import json
+            import os
+            from .step import _common
+            path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data", "gemm", _common.miopen_cache_key() + ".json")
+            if os.path.exists(path) and os.environ.get("IRN_GEMM_TABLE", "1") != "0":
+                ranks = {tuple(int(v) for v in k.split(",")): int(r) for k, r in json.load(open(path))["ranks"].items()}
+        except Exception:
+            ranks = {}
+        _GEMM_RANKS = ranks
+    return _GEMM_RANKS
+
+
+def conv1x1_nhwc(x, weight, bias=None, residual=None, relu=False, out=None, algo_rank=None):
+    """1x1 convolution (stride 1) of a channels-last activation with bias, residual add and ReLU in the GEMM's epilogue
+    (irn_conv1x1_nhwc; reference net/resnet50.py:34-54 with FixedBatchNorm folded into `weight` / `bias`).
+    x: GPU fp32 [N, cin, H, W] in torch.channels_last; weight: GPU fp32 [cout, cin] (or [cout, cin, 1, 1]) contiguous;
+    bias: GPU fp32 [cout] or None; residual: like the result, or None; out: a channels-last [N, cout, H, W] tensor to write
+    (may be `residual`), else a fresh one.  -> act(conv(x, weight) + bias (+ residual))."""
+    _need_cuda(x, "x")
+    if x.dtype != torch.float32 or x.dim() != 4 or not x.is_contiguous(memory_format=torch.channels_last):
+        raise ValueError("conv1x1_nhwc: x must be a channels-last fp32 [N, C, H, W] tensor, got %s %s %s" % (x.dtype, tuple(x.shape), x.stride()))
+    n, cin, h, w_ = (int(v) for v in x.shape)
+    cout = int(weight.shape[0])
+    if weight.dtype != torch.float32 or weight.device != x.device or not weight.is_contiguous() or weight.numel() != cout * cin:
+        raise ValueError("conv1x1_nhwc: weight must be a contiguous fp32 [%d-out, %d] tensor on %s" % (cout, cin, x.device))
+    if bias is not None and (bias.dtype != torch.float32 or bias.device != x.device or not bias.is_contiguous() or bias.numel() != cout):
+        raise ValueError("conv1x1_nhwc: bias must be a contiguous fp32 [%d] tensor on %s" % (cout, x.device))
+    shape = (n, cout, h, w_)
+    for name, t in (("residual", residual), ("out", out)):
+        if t is not None and (tuple(t.shape) != shape or t.dtype != torch.float32 or t.device != x.device
+                              or not t.is_contiguous(memory_format=torch.channels_last)):
+            raise ValueError("conv1x1_nhwc: %s must be a channels-last fp32 %s tensor on %s" % (name, shape, x.device))
+    if out is None:
+        out = torch.empty(shape, dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
+    m = n * h * w_
+    if m == 0:
+        return out
+    dev = x.device.index if x.device.index is not None else torch.cuda.current_device()
+    ws = _GEMM_WS.get(dev)
+    if ws is None:
+        ws = _GEMM_WS[dev] = torch.empty(int(lib.irn_conv1x1_workspace_bytes()), dtype=torch.uint8, device=x.device)
+    if algo_rank is None:
+        algo_rank = gemm_ranks().get((m, cin, cout, int(bias is not None), int(residual is not None), int(bool(relu))), 0)
+    with torch.cuda.device(x.device):
+        check(lib.irn_conv1x1_nhwc(x.data_ptr(), weight.data_ptr(), None if bias is None else bias.data_ptr(),
+                                   None if residual is None else residual.data_ptr(), out.data_ptr(), m, cin, cout,
+                                   1 if relu else 0, int(algo_rank), ws.data_ptr(), ws.numel(), _stream()))
+    return out
+
+
+def conv1x1_algo_count(m, cin, cout, bias, residual, relu):
+    """How many kernels hipBLASLt's heuristic offers for the problem (tools/conv1x1_tune.py times each of them once)."""
+    n = C.c_int(0)
+    check(lib.irn_conv1x1_algo_count(int(m), int(cin), int(cout), int(bool(bias)), int(bool(residual)), int(bool(relu)),
+                                     int(lib.irn_conv1x1_workspace_bytes()), C.byref(n)))
+    return n.value
+
+
 def _need_f32_contig(t, what, min_dim):
     _need_cuda(t, what)
     if t.dtype != torch.float32 or not t.is_contiguous() or t.dim() < min_dim:

@@ -1,5 +1,5 @@
 #!/bin/bash
-# One gpurun call of round 4 (results land in gpurun_out/r4_sN/; copy what should be judged into profiles/).
+# One gpurun call (round ${ROUND:-5}) (results land in gpurun_out/r4_sN/; copy what should be judged into profiles/).
 # usage: tools/gpu_session.sh <N> [what...]
 #   what: tests tests_all testsel smoke bench default ab abopt prof pmc pmcsq <script under tools/>
 #   env:  TESTSEL="-k expr or paths" (testsel), AB_LIBS="libirn_hip.so other.so", AB_WL="walk coco walk_r5",
@@ -7,7 +7,7 @@
 set -u
 S=${1:-1}; shift || true
 WHAT=${*:-tests bench prof}
-OUT=gpurun_out/r4_s$S
+OUT=gpurun_out/r${ROUND:-5}_s$S
 mkdir -p $OUT
 export TMPDIR=/tmp MIOPEN_FIND_MODE=${MIOPEN_FIND_MODE:-2}
 report() {   # report <json> <label>
