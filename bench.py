@@ -60,9 +60,9 @@ def parse(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="walk", choices=["walk", "walk_r5", "walk_plain", "ins", "ins_r10", "coco", "cam", "e2e", "steps"])
+    ap.add_argument("--workload", default="walk", choices=["walk", "walk_r5", "walk_plain", "walk_voc", "walk_voc_r5", "ins", "ins_r10", "coco", "cam", "e2e", "steps", "steps_voc"])
     ap.add_argument("--batch", type=int, default=0, help="images per GPU per step (0 = workload default)")
-    ap.add_argument("--unique", type=int, default=96, help="distinct synthetic images per GPU")
+    ap.add_argument("--unique", type=int, default=0, help="distinct synthetic images per GPU (0 = the batch: no image twice in a step)")
     ap.add_argument("--variant", type=int, default=2, help="0 generic sweep, 1 blocked streaming sweep, 2 weights-stationary persistent walk")
     ap.add_argument("--xcd-map", type=int, default=1)
     ap.add_argument("--tile", type=int, default=8, help="sweep tile shape id (irn_walk_set_option 'tile')")
@@ -86,7 +86,7 @@ def parse(argv=None):
                     help="self-launched N > 1 runs: kill the launcher's process group after this many seconds (0 = no limit)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-legs", action="store_true", help="skip the short secondary runs (cam, e2e, steps, walk_r5, ins, coco)")
-    ap.add_argument("--legs", default="walk_r5,walk_plain,ins,ins_r10,coco,cam,e2e,steps")
+    ap.add_argument("--legs", default="walk_voc,walk_voc_r5,walk_r5,walk_plain,ins,ins_r10,coco,cam,e2e,steps,steps_voc")
     ap.add_argument("--legs-budget-s", type=float, default=240.0,
                     help="stop starting new legs once the legs have used this much wall time (the rest are recorded as skipped)")
     ap.add_argument("--loader-workers", type=int, default=4, help="DataLoader workers of the `steps` workload")
@@ -105,15 +105,30 @@ WORKLOADS = {
     "ins":     (128, 128, 5, 10.0, 8, (512, 512), 64),      # configs[3]: instance labels, radius 5 = the reference's call site (step/make_ins_seg_labels.py:135)
     "ins_r10": (128, 128, 10, 10.0, 8, (512, 512), 64),     # the same at SURVEY.md 8(d)'s row 4 radius
     "coco":    (256, 256, 10, 10.0, 8, (1024, 1024), 2),    # configs[4]: 80 classes, 1024^2
+    # SURVEY.md 8(d) "ragged variant" of configs[2]: image sizes drawn from the VOC12 size histogram (synth.VOC_SIZES:
+    # 500x375, 375x500, 500x333, ...), i.e. 94x125, 125x94, 84x125, ... grids; h, w here are only the nominal grid
+    "walk_voc":    (128, 128, 10, 10.0, 8, None, 192),
+    "walk_voc_r5": (128, 128, 5, 10.0, 8, None, 256),
 }
+WALK_WORKLOADS = ("walk", "walk_r5", "walk_plain", "coco", "walk_voc", "walk_voc_r5")
+
+
+def image_geometry(workload, seed):
+    """(grid h, grid w, (H, W)) of synthetic image `seed` of a workload."""
+    from irn_amd import synth
+    h, w, _, _, _, out_hw, _ = WORKLOADS[workload]
+    if out_hw is None:
+        out_hw = synth.voc_image_size(seed)
+        h, w = synth.grid_of(out_hw)
+    return h, w, out_hw
 
 
 def make_inputs(workload, n_unique, seed0, device):
     from irn_amd import synth
-    h, w, radius, beta, exp_times, out_hw, _ = WORKLOADS[workload]
     edges, cams, keys, dps = [], [], [], []
     for i in range(n_unique):
         seed = seed0 + i
+        h, w, _ = image_geometry(workload, seed)
         k = 80 if workload == "coco" else synth.voc_num_classes(seed)
         edges.append(torch.from_numpy(synth.edge_field(h, w, seed)).to(device))
         cams.append(torch.from_numpy(synth.cam_blobs(k, h, w, seed)).to(device))
@@ -150,6 +165,19 @@ def _label_ties(got, want, up, bg, lut):
     return n, float(gap.max()), int((gap >= 1e-4).sum())
 
 
+def host_cpu_model():
+    """The host CPU's model string (the "x CPU" ratio moves by +-40 % from one GPU box to the next; this says which box)."""
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.lower().startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    import platform
+    return platform.processor() or "unknown"
+
+
 def cpu_baseline(a, workload, n_images, seed0, gpu_labels=None):
     from irn_amd import synth
     from oracle import build_oracle, irn_oracle
@@ -167,7 +195,7 @@ def cpu_baseline(a, workload, n_images, seed0, gpu_labels=None):
     t0 = time.perf_counter()
     rws = build_oracle.walk_batch(lib, cams, edges, radius, beta, 2 ** exp_times)
     dt = time.perf_counter() - t0
-    res = {"value": n_images / dt, "unit": "images/s", "cores": threads, "kind": "port",
+    res = {"value": n_images / dt, "unit": "images/s", "cores": threads, "cpu_model": host_cpu_model(), "kind": "port",
            "sample": "%d images of the same workload (walk only: oracle/walk_oracle.c irn_oracle_walk_batch, fp64 stencil port of "
                      "misc/indexing.py:141-165, one image per OpenMP thread, rows vectorised; %.1f s)" % (n_images, dt)}
     res["which_is_which"] = {
@@ -271,12 +299,12 @@ def run_walk(a, workload, rank, world, device, dist, parallel, steps, warmup, ba
     from irn_amd.misc import indexing
     h, w, radius, beta, exp_times, out_hw, default_batch = WORKLOADS[workload]
     batch = batch or default_batch
-    n_unique = min(a.unique, batch)
+    n_unique = min(a.unique or batch, batch)
     edges_u, cams_u, keys_u, _ = make_inputs(workload, n_unique, 1000 * (rank + 1), device)
     idx = [i % n_unique for i in range(batch)]
     edges, cams, keys = [edges_u[i] for i in idx], [cams_u[i] for i in idx], [keys_u[i] for i in idx]
-    shapes = [(h, w, cams[i].shape[0]) for i in range(batch)]
-    sizes = [out_hw] * batch
+    shapes = [(int(cams[i].shape[1]), int(cams[i].shape[2]), int(cams[i].shape[0])) for i in range(batch)]
+    sizes = [image_geometry(workload, 1000 * (rank + 1) + i)[2] for i in idx]
 
     walker = indexing.RandomWalk(radius, device)
     walker.set_option("variant", a.variant)
@@ -292,7 +320,7 @@ def run_walk(a, workload, rank, world, device, dist, parallel, steps, warmup, ba
         name, value = kv.split("=")
         walker.set_option(name, int(value))
     walker.enable_timing(True)
-    outs = [torch.empty((s[2], 1, h, w), device=device) for s in shapes]
+    outs = [torch.empty((s[2], 1, s[0], s[1]), device=device) for s in shapes]
 
     def step():
         rws = walker(edges, cams, beta=beta, exp_times=exp_times, outs=outs)
@@ -307,8 +335,19 @@ def run_walk(a, workload, rank, world, device, dist, parallel, steps, warmup, ba
     n_applied = walker.steps(n_sweeps)                     # operator applications the schedule spends on T^n_sweeps
     head = [(labels[i].cpu().numpy(), keys[i].cpu().numpy()) for i in range(min(8, n_unique))]   # for cpu_baseline.label_parity
     tuning = walker.tuning()
+    fallback_runs = walker.fallback_runs
     walker.close()
     n_dirs = N_DIRS[radius]
+    rounds = None
+    if a.variant == 2:                                   # how the persistent launch packed the batch (host arithmetic)
+        import ctypes
+        from irn_amd import _lib
+        nr = ctypes.c_int(0)
+        arr = lambda v: _lib.i32_array([int(x) for x in v])
+        n_wg = torch.cuda.get_device_properties(device).multi_processor_count
+        if _lib.lib.irn_walk_plan_rounds(radius, batch, arr(s[0] for s in shapes), arr(s[1] for s in shapes), arr(s[2] for s in shapes),
+                                         n_wg, tuning["placement"] or 1, None, 0, ctypes.byref(nr)) == 0:
+            rounds = int(nr.value)
     avg_sweep_ms = sweep_ms / max(sweep_launches, 1)
     # one "launch" of the dominant kernel: the streaming variants launch once per operator application; the
     # weights-stationary walk is ONE launch for the whole walk of the batch
@@ -321,7 +360,8 @@ def run_walk(a, workload, rank, world, device, dist, parallel, steps, warmup, ba
             "avg_launch_ms": avg_launch_ms, "sweeps_per_launch": sweeps_per_launch, "n_applied": n_applied, "n_sweeps": n_sweeps,
             "launches_timed": sweep_launches // max(sweeps_per_launch, 1), "flops_per_launch": flops_per_launch,
             "bytes_per_launch": bytes_per_launch, "sweep_share_of_step": sweep_ms / (1e3 * elapsed),
-            "label_checksum": checksum, "head_labels": head, "tuning": tuning}
+            "label_checksum": checksum, "head_labels": head, "tuning": tuning, "fallback_runs": fallback_runs, "rounds": rounds,
+            "grid_pixels": int(sum(s[0] * s[1] for s in shapes)), "sizes": sizes}
 
 
 def run_ins(a, workload, rank, world, device, dist, parallel, steps, warmup, batch=0):
@@ -333,7 +373,7 @@ def run_ins(a, workload, rank, world, device, dist, parallel, steps, warmup, bat
     from irn_amd.step import make_ins_seg_labels as mis
     h, w, radius, beta, exp_times, out_hw, default_batch = WORKLOADS[workload]
     batch = batch or default_batch
-    n_unique = min(a.unique, batch)
+    n_unique = min(a.unique or batch, batch)
     edges_u, cams_u, keys_u, dps_u = make_inputs(workload, n_unique, 1000 * (rank + 1), device)
     items = [{"edge": edges_u[i % n_unique][None], "dp": dps_u[i % n_unique], "cam": cams_u[i % n_unique],
               "keys": keys_u[i % n_unique].cpu(), "size": out_hw} for i in range(batch)]
@@ -415,13 +455,17 @@ def run_backbone(a, workload, rank, world, device, dist, parallel, steps, warmup
             return ops.label_epilogue(rws, [(H, W)] * batch, 0.25, keys=[c[0] for c in cams])["labels"]
 
     elapsed, _ = timed_loop(step, steps, warmup, dist, parallel, device)
+    out = {"value": steps * batch * world / elapsed, "ms_per_step": 1e3 * elapsed / steps, "batch": batch, "scales": scales}
     if walker is not None:
-        walker.check()
+        walker.check()                  # raises when a persistent launch gave up (nothing here calls sync(), so nothing re-ran)
+        out["walk_fallback_runs"] = walker.fallback_runs
         walker.close()
-    return {"value": steps * batch * world / elapsed, "ms_per_step": 1e3 * elapsed / steps, "batch": batch, "scales": scales}
+        if out["walk_fallback_runs"]:
+            raise RuntimeError("e2e leg: %d walk batch(es) fell back to the streaming sweeps" % out["walk_fallback_runs"])
+    return out
 
 
-def run_steps(a, rank, world, device, dist, parallel, steps, warmup, batch=0):
+def run_steps(a, rank, world, device, dist, parallel, steps, warmup, batch=0, voc_sizes=False):
     """The drop-in step API itself, in run_sample.py's order (reference run_sample.py:91-131): make_cam.run(args) ->
     make_ins_seg_labels.run(args) -> make_sem_seg_labels.run(args) on a synthetic VOC-shaped directory of 512x512 JPEGs
     with random-init checkpoints: DataLoader + JPEG decode, multi-scale CAM, CAM hand-off, IRNet, walk, detections, PNG /
@@ -443,7 +487,8 @@ def run_steps(a, rank, world, device, dist, parallel, steps, warmup, batch=0):
         names, labels = [], {}
         for i in range(batch):
             name = "2009_%06d" % (rank * batch + i + 1)
-            Image.fromarray(synth.photo(512, 512, seed=7000 + rank * batch + i)).save(
+            ih, iw = synth.voc_image_size(7000 + rank * batch + i) if voc_sizes else (512, 512)
+            Image.fromarray(synth.photo(ih, iw, seed=7000 + rank * batch + i)).save(
                 os.path.join(root, "JPEGImages", name + ".jpg"), quality=92)
             lab = np.zeros(20, np.float32)
             lab[synth.voc_keys(synth.voc_num_classes(i + 11), i + 11)] = 1
@@ -501,7 +546,16 @@ def run_steps(a, rank, world, device, dist, parallel, steps, warmup, batch=0):
         t_setup = time.perf_counter() - t_setup
         hits0, misses0 = _common.CAM_STORE.hits, _common.CAM_STORE.misses
         e_hits0 = _common.EDGE_STORE.hits
-        elapsed, _ = timed_loop(step, steps, warmup, dist, parallel, device)
+        for _ in range(warmup):                      # (here, not in timed_loop: the counters below must cover the timed passes only)
+            step()
+        fb0 = _common.WALK_STATS["fallback_runs"]
+        cam0 = dict(_common.CAM_STATS)
+        elapsed, _ = timed_loop(step, steps, 0, dist, parallel, device)
+        fallback_runs = _common.WALK_STATS["fallback_runs"] - fb0
+        if fallback_runs:
+            # a persistent walk that lost its bounded wait is re-run on the streaming sweeps (11x slower): correct files, but
+            # not a measurement of the default path
+            raise RuntimeError("steps leg: %d walk batch(es) fell back to the streaming sweeps inside the timed passes" % fallback_runs)
         n_png = len([f for f in os.listdir(args.sem_seg_out_dir) if f.endswith(".png")])
         n_ins = len([f for f in os.listdir(args.ins_seg_out_dir) if f.endswith(".npy")])
         if n_png != batch:
@@ -509,6 +563,8 @@ def run_steps(a, rank, world, device, dist, parallel, steps, warmup, batch=0):
         return {"value": steps * batch * world / elapsed, "ms_per_step": 1e3 * elapsed / steps, "batch": batch,
                 "cam_store_hits": _common.CAM_STORE.hits - hits0, "cam_store_misses": _common.CAM_STORE.misses - misses0,
                 "edge_store_hits": _common.EDGE_STORE.hits - e_hits0, "loader_workers": args.num_workers, "instance_files": n_ins,
+                "walk_fallback_runs": fallback_runs, "voc_sizes": bool(voc_sizes),
+                "cam_trunk_passes": {k: _common.CAM_STATS[k] - cam0[k] for k in cam0},
                 "through": "make_cam.run(args) + make_ins_seg_labels.run(args) + make_sem_seg_labels.run(args)",
                 "pass_seconds": [{k: round(v, 3) for k, v in p.items()} for p in passes[warmup:]], "setup_seconds": t_setup}
     finally:
@@ -518,16 +574,27 @@ def run_steps(a, rank, world, device, dist, parallel, steps, warmup, batch=0):
 # ------------------------------------------------------------------------------------------------
 
 def describe(workload, r):
-    if workload in ("walk", "walk_r5", "walk_plain", "coco"):
+    if workload in WALK_WORKLOADS and r.get("out_hw"):
         return ("%s: VOC12-shaped %dx%d images (%dx%d stride-4 grids), affinity random walk radius=%d beta=%g 2^%d sweeps "
                 "+ x4 upsample/argmax label epilogue; K~VOC label histogram%s; inputs resident in HBM" %
                 (workload, r["out_hw"][0], r["out_hw"][1], r["h"], r["w"], r["radius"], r["beta"], r["exp_times"],
                  " (80 classes)" if workload == "coco" else ""))
+    if workload in ("walk_voc", "walk_voc_r5"):
+        import collections
+        top = collections.Counter((s[0], s[1]) for s in r["shapes"]).most_common(4)
+        return ("%s: ragged variant of configs[2] (SURVEY.md 8d): image sizes drawn from the VOC12 size histogram (synth.VOC_SIZES), "
+                "grids %s ..., affinity random walk radius=%d beta=%g 2^%d sweeps + x4 upsample/argmax label epilogue cropped to each "
+                "image; K~VOC label histogram; inputs resident in HBM" %
+                (workload, ", ".join("%dx%d (%d)" % (g[0], g[1], n) for g, n in top), r["radius"], r["beta"], r["exp_times"]))
     if workload in ("ins", "ins_r10"):
         return ("ins: VOC12-shaped %dx%d images (%dx%d grids), instance labels: displacement-field centroids + clustering + "
                 "per-instance random walk radius=%d beta=%g 2^%d + epilogue + connected-component detections copied to the "
                 "host; edge / displacement / CAM tensors resident in HBM" %
                 (r["out_hw"][0], r["out_hw"][1], r["h"], r["w"], r["radius"], r["beta"], r["exp_times"]))
+    if workload == "steps_voc":
+        return ("steps_voc: run_sample.py step API (make_cam -> make_ins_seg_labels at radius 5 -> make_sem_seg_labels at radius 10) "
+                "on a synthetic VOC directory of JPEGs whose sizes follow the VOC12 size histogram (synth.VOC_SIZES: 500x375, 375x500, "
+                "500x333, ...), random-init checkpoints, files written")
     if workload == "steps":
         return ("steps: run_sample.py step API (make_cam -> make_ins_seg_labels at radius 5 -> make_sem_seg_labels at radius 10) "
                 "on a synthetic VOC directory of 512x512 JPEGs, random-init checkpoints, files written")
@@ -537,23 +604,24 @@ def describe(workload, r):
 
 
 def run_workload(a, workload, rank, world, device, dist, parallel, steps, warmup, batch=0):
-    if workload in ("walk", "walk_r5", "walk_plain", "coco"):
+    if workload in WALK_WORKLOADS:
         return run_walk(a, workload, rank, world, device, dist, parallel, steps, warmup, batch)
     if workload in ("ins", "ins_r10"):
         return run_ins(a, workload, rank, world, device, dist, parallel, steps, warmup, batch)
-    if workload == "steps":
-        return run_steps(a, rank, world, device, dist, parallel, steps, warmup, batch)
+    if workload in ("steps", "steps_voc"):
+        return run_steps(a, rank, world, device, dist, parallel, steps, warmup, batch, voc_sizes=(workload == "steps_voc"))
     return run_backbone(a, workload, rank, world, device, dist, parallel, steps, warmup, batch)
 
 
 LEG_RUNS = {   # short runs for the `legs` object of the default line: (steps, warmup, batch)
     "cam": (12, 1, 8), "e2e": (12, 1, 8), "steps": (2, 1, 256), "walk_r5": (10, 2, 256), "walk_plain": (4, 1, 192),
     "ins": (10, 2, 64), "ins_r10": (8, 2, 64), "coco": (10, 2, 2),
+    "walk_voc": (10, 2, 192), "walk_voc_r5": (10, 2, 256), "steps_voc": (1, 1, 256),
 }
 
 
 def roofline_object(a, workload, r):
-    if workload not in ("walk", "walk_r5", "walk_plain", "coco"):
+    if workload not in WALK_WORKLOADS:
         return None
     sec = r["avg_launch_ms"] * 1e-3
     tflops = r["flops_per_launch"] / sec / 1e12
@@ -597,7 +665,7 @@ def roofline_object(a, workload, r):
         top = dict(hbm)
         top["bound"] = "hbm"
         top["fp32_vector"] = fma
-    top.update({"traffic": traffic, "traffic_source": traffic_src, "kernel": kernel, "avg_launch_ms": r["avg_launch_ms"],
+    top.update({"traffic": traffic, "traffic_source": None if traffic is None else "static", "traffic_detail": traffic_src, "kernel": kernel, "avg_launch_ms": r["avg_launch_ms"],
                 "sweeps_per_launch": r["sweeps_per_launch"], "launches_timed": r["launches_timed"],
                 "sweep_share_of_step": r["sweep_share_of_step"],
                 "schedule": {"n_sweeps": r["n_sweeps"], "operator_applications": r["n_applied"],
@@ -669,6 +737,9 @@ def main(argv=None):
                  "coco": "random-walk label generation stage, COCO shape", "ins": "instance label generation stage",
                  "ins_r10": "instance label generation stage, radius 10",
                  "cam": "multi-scale CAM inference stage", "e2e": "CAM + IRNet + walk + labels, end to end",
+                 "walk_voc": "random-walk label generation stage, VOC12 image-size histogram (ragged grids)",
+                 "walk_voc_r5": "random-walk label generation stage, VOC12 image-size histogram, radius 5",
+                 "steps_voc": "run_sample.py step API on JPEGs with the VOC12 image-size histogram",
                  "steps": "run_sample.py step API, make_cam + make_ins_seg_labels + make_sem_seg_labels"}[a.workload]
         res = {
             "metric": "%s (%s)" % (METRIC, stage),
@@ -687,11 +758,11 @@ def main(argv=None):
             res["config"].update({"variant": a.variant, "mean_channels": float(np.mean([s[2] for s in r["shapes"]])),
                                   "walk_self_checks": r.get("tuning")})
             res["label_checksum"] = r["label_checksum"]
-        for k in ("detections_per_image", "fallback_runs", "cam_store_hits", "cam_store_misses", "edge_store_hits", "loader_workers", "pass_seconds", "instance_files", "through"):
+        for k in ("detections_per_image", "fallback_runs", "rounds", "walk_fallback_runs", "cam_trunk_passes", "cam_store_hits", "cam_store_misses", "edge_store_hits", "loader_workers", "pass_seconds", "instance_files", "through"):
             if k in r:
                 res["config"][k] = r[k]
         res["cpu_baseline"] = None
-        if world == 1 and not a.no_cpu_baseline and a.workload in ("walk", "walk_r5", "walk_plain", "coco"):
+        if world == 1 and not a.no_cpu_baseline and a.workload in ("walk", "walk_r5", "walk_plain", "coco"):      # (square-grid workloads)
             res["cpu_baseline"] = cpu_baseline(a, a.workload, a.cpu_images, 1000, gpu_labels=r.get("head_labels"))
             if "label_parity" in res["cpu_baseline"]:
                 res["label_parity"] = res["cpu_baseline"]["label_parity"]
@@ -711,7 +782,7 @@ def main(argv=None):
                     if "shapes" in lr:
                         ro = roofline_object(a, name, lr)
                         legs[name]["fp32_vector_frac"] = ro["frac"] if ro.get("bound") == "fp32_vector" else ro["fp32_vector"]["frac"]
-                    for k in ("detections_per_image", "cam_store_hits", "cam_store_misses", "edge_store_hits", "loader_workers", "pass_seconds", "instance_files", "setup_seconds", "through", "n_applied"):
+                    for k in ("detections_per_image", "fallback_runs", "rounds", "grid_pixels", "walk_fallback_runs", "cam_trunk_passes", "cam_store_hits", "cam_store_misses", "edge_store_hits", "loader_workers", "pass_seconds", "instance_files", "setup_seconds", "through", "n_applied"):
                         if k in lr:
                             legs[name][k] = lr[k]
                 except Exception as e:                      # a leg must never cost the headline line

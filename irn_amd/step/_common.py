@@ -377,6 +377,9 @@ def split_by_owner(dataset, n_splits, names, owners, slack=0.25):
     return [Subset(dataset, np.asarray(sorted(s), dtype=np.int64)) for s in shards]
 
 
+# make_cam's trunk passes of this process, by layout (net/resnet50.channels_last_for: channels-last only for input shapes the
+# shipped find database is tuned for), and its size-group flushes (full groups of `cam_batch` images vs partial ones)
+CAM_STATS = {"channels_last": 0, "nchw": 0, "full_group_flushes": 0, "partial_group_flushes": 0}
 CAM_OWNERS = {}       # abspath(cam_out_dir) -> {image name: worker that made (and still holds) its CAM}
 WALK_STATS = {"fallback_runs": 0}
 

@@ -48,7 +48,13 @@ def _flush_group(model, group, scales, args, writer, store):
     the writer threads wait for each image's copy event — so the next group's passes are queued while this one runs."""
     if not group:
         return
-    outs = [model.forward_batch(torch.cat([g["imgs"][si] for g in group])) for si in range(len(scales))]
+    from ..net import resnet50 as _r50
+    outs = []
+    for si in range(len(scales)):
+        x = torch.cat([g["imgs"][si] for g in group])
+        _common.CAM_STATS["channels_last" if _r50.channels_last_for(x) else "nchw"] += 1
+        outs.append(model.forward_batch(x))
+    _common.CAM_STATS["full_group_flushes" if len(group) >= int(getattr(args, "cam_batch", 0) or 8) else "partial_group_flushes"] += 1
     for i, g in enumerate(group):
         keys_cpu = torch.nonzero(g["label"])[:, 0]
         keys, cam, high_res = merge_scales([o[i] for o in outs], g["size"], g["label"])

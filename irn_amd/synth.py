@@ -89,6 +89,30 @@ def voc_keys(k, seed):
     return np.sort(_rng(seed + 32452843).choice(20, k, replace=False)).astype(np.int64)
 
 
+# (H, W) of VOC12 JPEGs and their share: the longer side is almost always 500 px; 500x375 landscape dominates, then its
+# portrait twin and the 3:2 formats.  No dataset is available in these containers, so this is a coarse stand-in for the
+# size histogram of JPEGImages/ (SURVEY.md §8d "ragged variant": 94x125, 125x84, ... stride-4 grids), not a measurement.
+VOC_SIZES = (((375, 500), 0.50), ((500, 375), 0.14), ((333, 500), 0.12), ((500, 333), 0.05), ((334, 500), 0.04),
+             ((332, 500), 0.03), ((374, 500), 0.03), ((500, 500), 0.02), ((281, 500), 0.02), ((400, 500), 0.02),
+             ((500, 400), 0.01), ((357, 500), 0.01), ((442, 500), 0.01))
+
+
+def voc_image_size(seed):
+    """(H, W) of one synthetic VOC12-shaped image, drawn from `VOC_SIZES`."""
+    u = _rng(seed + 77003).rand()
+    acc = 0.0
+    for size, p in VOC_SIZES:
+        acc += p
+        if u < acc:
+            return size
+    return VOC_SIZES[0][0]
+
+
+def grid_of(size, stride=4):
+    """Stride-4 grid of an image: ((H - 1) // 4 + 1, (W - 1) // 4 + 1) (reference net/resnet50_irn.py:224)."""
+    return (size[0] - 1) // stride + 1, (size[1] - 1) // stride + 1
+
+
 def photo(h, w, seed=0):
     """uint8 [h,w,3] photo-like image: smooth colour fields, hard-edged saturated rectangles (the bicubic
     overshoot there exercises the 0/255 clipping) and sensor-like noise."""

@@ -44,6 +44,7 @@ def main():
     ap.add_argument("--pairs", type=int, default=1)
     ap.add_argument("--repeat", type=int, default=3)
     ap.add_argument("--scales", default="1.0,0.5")
+    ap.add_argument("--deterministic", type=int, default=0, help="torch.backends.cudnn.deterministic (MIOpen's deterministic attribute)")
     a = ap.parse_args()
     import torch
     import torch.nn as nn
@@ -51,6 +52,7 @@ def main():
     from irn_amd.net import resnet50_cam, resnet50_irn, weights
     from irn_amd.step import _common
     dev = torch.device("cuda", 0)
+    torch.backends.cudnn.deterministic = bool(a.deterministic)
     print("miopen db:", _common.miopen_setup(0), "find mode", os.environ.get("MIOPEN_FIND_MODE"),
           "| channels-last", os.environ.get("IRN_CHANNELS_LAST", "auto"), "| fused gemm", os.environ.get("IRN_FUSED_GEMM", "1"))
     cam = resnet50_cam.CAM()
