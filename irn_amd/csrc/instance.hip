@@ -298,22 +298,142 @@ struct DetJob {
     int h, w, n_det;
 };
 
-__global__ __launch_bounds__(256) void det_init_kernel(const DetJob *__restrict__ jobs) {
-    const DetJob J = jobs[blockIdx.y];
-    const int p = blockIdx.x * 256 + threadIdx.x;
-    if (p < J.h * J.w) J.parent[p] = J.cls[p] > 0 ? p : -1;
+// Labelling, stage 1: every 64 x 16 tile is labelled in LDS.  Row runs come from a segmented scan over the 16 lanes of a
+// row (4 pixels per lane) — no atomics; runs of adjacent rows are joined by an LDS union-find ("smaller index wins": local
+// raster order agrees with the image's inside a tile, so a local root is the component's first pixel of the tile), one
+// union per PAIR of touching runs, not per pixel.  Every pixel leaves with parent = its local root's image index.  Per-pixel
+// global atomics over the whole map (round 1-4: 0.056 ms per 512^2 image, the largest item of the instance stage,
+// profiles/r05_s1_ins_breakdown_r5.txt) remain only along the tile borders (stage 2).
+constexpr int kDetTW = 64, kDetTH = 16;
+
+__device__ __forceinline__ int lds_find(volatile int *parent, int a) {
+    int r = a;
+    while (true) {
+        const int q = parent[r];
+        if (q == r) return r;
+        r = q;
+    }
 }
 
-__global__ __launch_bounds__(256) void det_merge_kernel(const DetJob *__restrict__ jobs) {
+__device__ __forceinline__ void lds_union(int *parent, int a, int b) {
+    while (true) {
+        a = lds_find(parent, a);
+        b = lds_find(parent, b);
+        if (a == b) return;
+        if (a > b) {
+            const int t = a;
+            a = b;
+            b = t;
+        }
+        const int old = atomicMin(parent + b, a);
+        if (old == b) return;
+        b = old;
+    }
+}
+
+__global__ __launch_bounds__(256) void det_local_kernel(const DetJob *__restrict__ jobs) {
+    __shared__ int s_cls[kDetTH * kDetTW];
+    __shared__ int s_parent[kDetTH * kDetTW];
     const DetJob J = jobs[blockIdx.y];
-    const int p = blockIdx.x * 256 + threadIdx.x;
-    if (p >= J.h * J.w) return;
+    const int H = J.h, W = J.w;
+    const int tiles_x = (W + kDetTW - 1) / kDetTW, tiles_y = (H + kDetTH - 1) / kDetTH;
+    if ((int)blockIdx.x >= tiles_x * tiles_y) return;
+    const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
+    const int y0 = ty * kDetTH, x0 = tx * kDetTW;
+    const int t = threadIdx.x, ly = t >> 4, lane16 = t & 15, lx0 = lane16 * 4;
+    const int gy = y0 + ly, gx0 = x0 + lx0;
+    const int idx0 = ly * kDetTW + lx0;
+    int c[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) c[j] = (gy < H && gx0 + j < W) ? J.cls[(long)gy * W + gx0 + j] : 0;
+    // links to the left neighbour inside the tile row
+    int left = __shfl_up(c[3], 1, 16);
+    if (lane16 == 0) left = -1;
+    bool link[4];
+    link[0] = c[0] > 0 && c[0] == left;
+#pragma unroll
+    for (int j = 1; j < 4; ++j) link[j] = c[j] > 0 && c[j] == c[j - 1];
+    // run start of the lane's LAST pixel: `pass` = the incoming start runs through all four pixels
+    bool pass = link[0] && link[1] && link[2] && link[3];
+    int val = idx0 + 3;
+#pragma unroll
+    for (int j = 3; j >= 1; --j) {
+        if (!link[j]) break;
+        val = idx0 + j - 1;
+    }
+    // (val is only used when !pass: the start of the run that contains pixel 3)
+    // inclusive segmented scan over the row's 16 lanes
+#pragma unroll
+    for (int d = 1; d < 16; d <<= 1) {
+        const int pv = __shfl_up(val, d, 16);
+        const int pp = __shfl_up((int)pass, d, 16);
+        if (lane16 >= d && pass) {
+            val = pv;
+            pass = pp != 0;
+        }
+    }
+    int incoming = __shfl_up(val, 1, 16);     // run start of the left lane's last pixel (unused when !link[0])
+    int start[4];
+    int cur = link[0] ? incoming : idx0;
+    start[0] = cur;
+#pragma unroll
+    for (int j = 1; j < 4; ++j) {
+        cur = link[j] ? cur : idx0 + j;
+        start[j] = cur;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        s_cls[idx0 + j] = c[j];
+        s_parent[idx0 + j] = c[j] > 0 ? start[j] : -1;
+    }
+    __syncthreads();
+    if (ly > 0) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int up = idx0 + j - kDetTW;
+            if (c[j] > 0 && s_cls[up] == c[j]) {
+                // one union per pair of touching runs: where either run begins
+                const bool here = start[j] == idx0 + j;
+                const bool there = lx0 + j == 0 || s_cls[up - 1] != c[j];
+                if (here || there) lds_union(s_parent, start[j], up);
+            }
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        if (gy < H && gx0 + j < W) {
+            int out = -1;
+            if (c[j] > 0) {
+                const int r = lds_find(s_parent, start[j]);
+                out = (y0 + r / kDetTW) * W + x0 + (r % kDetTW);
+            }
+            J.parent[(long)gy * W + gx0 + j] = out;
+        }
+    }
+}
+
+// Labelling, stage 2: components are joined across tile borders — one global union per pair of touching border runs.
+__global__ __launch_bounds__(256) void det_border_kernel(const DetJob *__restrict__ jobs) {
+    const DetJob J = jobs[blockIdx.y];
+    const int H = J.h, W = J.w;
+    const int rows = (H + kDetTH - 1) / kDetTH - 1, cols = (W + kDetTW - 1) / kDetTW - 1;
+    const int i = blockIdx.x * 256 + threadIdx.x;
     const int32_t *__restrict__ cls = J.cls;
-    const int c = cls[p];
-    if (c <= 0) return;
-    const int y = p / J.w, x = p - y * J.w;
-    if (x > 0 && cls[p - 1] == c) uf_union(J.parent, p, p - 1);
-    if (y > 0 && cls[p - J.w] == c) uf_union(J.parent, p, p - J.w);
+    if (i < rows * W) {
+        const int r = i / W, x = i - r * W;
+        const int p = (r + 1) * kDetTH * W + x;
+        const int c = cls[p];
+        if (c > 0 && cls[p - W] == c && (x == 0 || cls[p - 1] != c || cls[p - W - 1] != c)) uf_union(J.parent, p, p - W);
+        return;
+    }
+    const int k = i - rows * W;
+    if (k < cols * H) {
+        const int q = k / H, y = k - q * H;
+        const int p = y * W + (q + 1) * kDetTW;
+        const int c = cls[p];
+        if (c > 0 && cls[p - 1] == c && (y == 0 || cls[p - W] != c || cls[p - W - 1] != c)) uf_union(J.parent, p, p - 1);
+    }
 }
 
 __global__ __launch_bounds__(256) void det_flatten_kernel(const DetJob *__restrict__ jobs) {
@@ -652,10 +772,18 @@ extern "C" int irn_detect_instance_batch_count(int n_images, const float *const 
     if (rc) return rc;
     IRN_HIP_TRY(hipMemsetAsync(n_det_dev, 0, sizeof(int32_t) * n_images, stream));
     const dim3 px(cdiv(max_n, 256), n_images);
-    hipLaunchKernelGGL(det_init_kernel, px, dim3(256), 0, stream, jd);
-    IRN_LAUNCH_CHECK("det_init_kernel");
-    hipLaunchKernelGGL(det_merge_kernel, px, dim3(256), 0, stream, jd);
-    IRN_LAUNCH_CHECK("det_merge_kernel");
+    int max_tiles = 0, max_border = 0;
+    for (int i = 0; i < n_images; ++i) {
+        const int tx = cdiv(w[i], kDetTW), ty = cdiv(h[i], kDetTH);
+        max_tiles = std::max(max_tiles, tx * ty);
+        max_border = std::max(max_border, (ty - 1) * w[i] + (tx - 1) * h[i]);
+    }
+    hipLaunchKernelGGL(det_local_kernel, dim3(max_tiles, n_images), dim3(256), 0, stream, jd);
+    IRN_LAUNCH_CHECK("det_local_kernel");
+    if (max_border > 0) {
+        hipLaunchKernelGGL(det_border_kernel, dim3(cdiv(max_border, 256), n_images), dim3(256), 0, stream, jd);
+        IRN_LAUNCH_CHECK("det_border_kernel");
+    }
     hipLaunchKernelGGL(det_flatten_kernel, px, dim3(256), 0, stream, jd);
     IRN_LAUNCH_CHECK("det_flatten_kernel");
     hipLaunchKernelGGL(det_roots_kernel, px, dim3(256), 0, stream, jd);

@@ -47,6 +47,7 @@
 // Tiles of an image sit on consecutive slots of one XCD (slot -> block id b = idx*8 + xcd; observed
 // placement, speed only).  No grid-wide barrier exists, so rounds pipeline.
 #include <algorithm>
+#include <mutex>
 
 #include "walk_ctx.hpp"
 
@@ -663,11 +664,15 @@ void resident_destroy(irn_walk_ctx *ctx) {
 // exchange is placement-independent, only the share of same-XCD hand-offs changes) and a line on stderr says so.
 // g_placement[dev]: 0 = not checked, 1 = round robin holds, 2 = it does not.
 static int g_placement[64] = {};
+// both per-device caches (g_placement, g_poll_delay) are written once per process by whichever context gets there first:
+// contexts configured from different host threads take turns (the second one finds the first one's answer)
+static std::mutex g_tune_mu;
 
 int resident_check_placement(irn_walk_ctx *ctx) {
     int dev = 0;
     IRN_HIP_TRY(hipGetDevice(&dev));
     if (dev < 0 || dev >= 64) return IRN_OK;
+    std::lock_guard<std::mutex> lk(g_tune_mu);
     if (g_placement[dev] == 0) {
         const int n_wg = ctx->res_nwg;
         unsigned char *d = nullptr;
@@ -956,6 +961,7 @@ static int resident_probe_poll_delay(irn_walk_ctx *ctx, hipStream_t stream) {
     int dev = 0;
     IRN_HIP_TRY(hipGetDevice(&dev));
     if (dev < 0 || dev >= 64 || ctx->radius != 10 || !ctx->res_poll_auto) return IRN_OK;
+    std::lock_guard<std::mutex> lk(g_tune_mu);
     if (g_poll_delay[dev]) {
         ctx->res_poll_delay = g_poll_delay[dev];
         return IRN_OK;

@@ -224,6 +224,47 @@ def to_transition_matrix(affinity_dense, beta, times):
 # Random walk
 # ------------------------------------------------------------------------------------------------
 
+def _poll_delay_file(device):
+    from ..step import _common
+    base = os.environ.get("IRN_TUNING_CACHE") or os.path.join(os.path.expanduser("~"), ".cache", "irn_amd", "walk")
+    return os.path.join(base, "%s-dev%d.json" % (_common.miopen_cache_key(), torch.device(device).index or 0))
+
+
+def _lib_stamp():
+    from .._lib import LIB_PATH
+    st = os.stat(LIB_PATH)
+    return [st.st_mtime_ns, st.st_size]
+
+
+def _saved_poll_delay(device):
+    """The poll delay an earlier process's start-up probe picked on this device with THIS build of the library (0: none).
+    IRN_POLL_DELAY_CACHE=0 ignores the file."""
+    if os.environ.get("IRN_POLL_DELAY_CACHE", "1") == "0":
+        return 0
+    try:
+        import json
+        with open(_poll_delay_file(device)) as f:
+            d = json.load(f)
+        return int(d["poll_delay"]) if d.get("lib") == _lib_stamp() else 0
+    except Exception:
+        return 0
+
+
+def _save_poll_delay(device, delay):
+    if os.environ.get("IRN_POLL_DELAY_CACHE", "1") == "0":
+        return
+    try:
+        import json
+        path = _poll_delay_file(device)
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        tmp = path + ".tmp%d" % os.getpid()
+        with open(tmp, "w") as f:
+            json.dump({"lib": _lib_stamp(), "poll_delay": int(delay)}, f)
+        os.replace(tmp, path)
+    except Exception:
+        pass
+
+
 class RandomWalk:
     """Batched affinity random walk on one GPU (wraps an ``irn_walk_ctx``).
 
@@ -256,8 +297,16 @@ class RandomWalk:
         if env not in (None, ""):
             self.set_option("accel_tol_exp", int(env))
         env = os.environ.get("IRN_POLL_DELAY")            # pins the single-channel poll delay (no start-up probe)
-        if env not in (None, ""):
+        self._poll_pinned = env not in (None, "")
+        if self._poll_pinned:
             self.set_option("poll_delay", int(env))
+        elif self.radius == 10:
+            # what an earlier process measured on this device with this build of the library: every pool worker would
+            # otherwise run its first representative batch 8 extra times, blocking its host thread
+            d = _saved_poll_delay(self.device)
+            if d:
+                self.set_option("poll_delay", d)
+                self._poll_pinned = True
 
     def close(self):
         if self._ctx:
@@ -385,6 +434,11 @@ class RandomWalk:
         # again, walk.hip x0_kernel): callers routinely drop theirs right after the call, and the caching allocator would
         # hand the blocks to the next batch's uploads
         self._live = (es, cs, keep)
+        if not self._poll_pinned and self.radius == 10:
+            t = self.tuning()
+            if t["probe_ms"] is not None:                 # this run carried the start-up probe: remember its answer
+                _save_poll_delay(self.device, t["poll_delay"])
+                self._poll_pinned = True
         return outs
 
     def export_weights(self, image, n_dirs):

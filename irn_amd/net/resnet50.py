@@ -52,8 +52,7 @@ def tuned_nhwc_shapes():
         try:
             import json
             from ..step import _common
-            path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "data", "miopen",
-                                _common.miopen_cache_key(), "nhwc_shapes.json")
+            path = os.path.join(_common.miopen_seed_root(), _common.miopen_cache_key(), "nhwc_shapes.json")
             if os.path.exists(path) and os.environ.get("IRN_MIOPEN_SEED", "1") != "0":
                 shapes = {tuple(int(v) for v in s) for s in json.load(open(path))}
         except Exception:

@@ -66,11 +66,25 @@ def init_process_group(backend=None, device=None, timeout_s=None):
     return dist
 
 
+# The RCCL sub-group's OWN timeout.  It must never be the deadline that fires: when ProcessGroupNCCL's watchdog sees a
+# collective older than the group timeout it tears the communicator down and, with the default
+# TORCH_NCCL_ASYNC_ERROR_HANDLING, takes the whole process with it — before the ranks could agree on gloo, or minutes later in
+# the middle of the benchmark.  So the group gets a timeout far beyond any run of this job, the watchdog is
+# told not to kill the process, and the only deadline that decides anything is the Python one around the probe thread.
+RCCL_GROUP_TIMEOUT_S = float(os.environ.get("IRN_RCCL_GROUP_TIMEOUT_S", "7200"))
+# gloo control group: ranks may be skewed by minutes (a cold MIOpen find on one of them) without anything being wrong
+CONTROL_TIMEOUT_S = float(os.environ.get("IRN_CONTROL_TIMEOUT_S", "1800"))
+
+
 def _rccl_probe(device, timeout_s):
-    """Create the RCCL sub-group and run one all-reduce on `device`.  -> (group or None, note)."""
+    """Create the RCCL sub-group and run one all-reduce on `device`.  -> group.  `timeout_s` is the caller's (Python)
+    deadline, NOT the group's: see RCCL_GROUP_TIMEOUT_S."""
     import datetime
     import torch.distributed as dist
-    group = dist.new_group(backend="nccl", timeout=datetime.timedelta(seconds=float(timeout_s)))
+    # read by ProcessGroupNCCL's constructor: a timed-out or failed collective is reported to the caller, the process lives
+    os.environ.setdefault("TORCH_NCCL_ASYNC_ERROR_HANDLING", "0")
+    os.environ.setdefault("TORCH_NCCL_ENABLE_MONITORING", "0")      # no heartbeat monitor killing a process whose probe thread is stuck
+    group = dist.new_group(backend="nccl", timeout=datetime.timedelta(seconds=max(RCCL_GROUP_TIMEOUT_S, 4.0 * float(timeout_s))))
     t = torch.ones(1, device=device)
     dist.all_reduce(t, group=group)               # the first collective is where a broken fabric shows
     torch.cuda.synchronize(device)
@@ -142,7 +156,7 @@ def init_process_group_with_fallback(backend="auto", device=None, rank_devices=N
     shared = devices_shared(rank_devices) and os.environ.get("IRN_RCCL_ALLOW_SHARED", "0") != "1"
     if backend == "nccl" and shared:
         raise RuntimeError("backend nccl with two ranks on one device (rank_devices): RCCL needs one device per rank")
-    dist = init_process_group("gloo", None, timeout_s=max(300.0, 4 * probe_timeout_s))
+    dist = init_process_group("gloo", None, timeout_s=max(CONTROL_TIMEOUT_S, 4 * probe_timeout_s))
     want_rccl = backend in ("auto", "nccl") and torch.cuda.is_available() and device is not None and not shared
     if not want_rccl:
         note = "two ranks share a device: RCCL not attempted" if (shared and backend == "auto") else None
@@ -200,11 +214,17 @@ def gather_label_maps(labels, group, dst=0, chunk=32):
     sub = group.rccl if isinstance(group, JobGroup) else None
     on_device = sub is not None or (dist.get_backend() == "nccl")
     rank, world = dist.get_rank(), dist.get_world_size()
-    dev = labels[0].device if (labels and on_device) else torch.device("cpu")
+    # over RCCL every tensor of the exchange lives on THIS rank's device — also on a rank whose shard is empty or whose maps
+    # are on the host (a CPU tensor through the RCCL group errors on that rank and hangs the others)
+    if on_device:
+        dev = group.device if isinstance(group, JobGroup) and group.device is not None else torch.device("cuda", torch.cuda.current_device())
+        dev = torch.device(dev)
+    else:
+        dev = torch.device("cpu")
     kw = {"group": sub} if sub is not None else {}
 
     def pack(ts):
-        return torch.cat([t.reshape(-1) for t in ts]).to(dev) if ts else torch.empty(0, dtype=torch.uint8, device=dev)
+        return torch.cat([t.reshape(-1).to(dev) for t in ts]) if ts else torch.empty(0, dtype=torch.uint8, device=dev)
 
     # phase 1: every rank tells dst how many maps of which shapes follow
     n_max = torch.tensor([len(labels)], dtype=torch.int64, device=dev)

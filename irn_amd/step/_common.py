@@ -136,6 +136,20 @@ def merge_miopen_db(src_dir, dst_dir):
 _MIOPEN_LOCKS = []           # lock files held for the life of the process
 
 
+def miopen_seed_root():
+    """Directory of the find databases shipped with the package (one sub-directory per device / HIP version);
+    IRN_MIOPEN_SEED_DIR names another one (A/B runs of a freshly tuned database)."""
+    return os.environ.get("IRN_MIOPEN_SEED_DIR") or os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "data", "miopen")
+
+
+def deterministic_backbones():
+    """IRN_DETERMINISTIC (default 1): the convolutions run with MIOpen's deterministic attribute
+    (`torch.backends.cudnn.deterministic`), which rules out every solver that accumulates with atomics — the backbones'
+    outputs are then a function of their inputs only, whichever process, worker layout or run computes them (reference
+    step/make_cam.py:67-74: any `n_gpus` must give the same files)."""
+    return os.environ.get("IRN_DETERMINISTIC", "1") != "0"
+
+
 def miopen_setup(device_ordinal):
     """MIOpen's settings for the process that is about to run the backbones on `device_ordinal` — the SAME for a pool
     worker and for the in-process single-GPU path, so that one-GPU and N-GPU runs pick their convolution solvers the
@@ -156,9 +170,10 @@ def miopen_setup(device_ordinal):
     import fcntl
     import shutil
     os.environ.setdefault("MIOPEN_FIND_MODE", "2")
+    torch.backends.cudnn.deterministic = deterministic_backbones()
     marker = os.environ.get("IRN_MIOPEN_DB_SET")
-    if marker and os.environ.get("MIOPEN_USER_DB_PATH") == marker:
-        return marker                                    # this process (or the parent it inherited from, if it holds no lock itself) did it
+    if marker and os.environ.get("MIOPEN_USER_DB_PATH") == marker and os.environ.get("IRN_MIOPEN_DB_DEV", str(int(device_ordinal))) == str(int(device_ordinal)):
+        return marker                                    # this process (or the parent it inherited from, if it holds no lock itself) did it, for this device
     # (IRN_MIOPEN_BASE: the base the first caller of this job resolved — a worker must not take its parent's claimed
     # directory, which it inherits in MIOPEN_USER_DB_PATH, for the user's base)
     base = os.environ.get("IRN_MIOPEN_BASE") or os.environ.get("IRN_MIOPEN_CACHE") or os.environ.get("MIOPEN_USER_DB_PATH") or \
@@ -178,13 +193,44 @@ def miopen_setup(device_ordinal):
         for f in os.listdir(stable):
             if f != ".lock" and os.path.isfile(os.path.join(stable, f)):
                 shutil.copy2(os.path.join(stable, f), os.path.join(use, f))
-        atexit.register(shutil.rmtree, use, True)
-    seed = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "data", "miopen", key)
+        atexit.register(shutil.rmtree, use, True)           # (a pool worker is terminated, not exited: WorkerPool.close() cleans up then)
+    seed = os.path.join(miopen_seed_root(), key)
     if os.environ.get("IRN_MIOPEN_SEED", "1") != "0" and os.path.isdir(seed):
         merge_miopen_db(seed, use)         # (after the claim: nobody else appends to `use` now)
     os.environ["MIOPEN_USER_DB_PATH"] = use
     os.environ["IRN_MIOPEN_DB_SET"] = use
+    os.environ["IRN_MIOPEN_DB_DEV"] = str(int(device_ordinal))
     return use
+
+
+def reap_private_miopen_dbs(pids):
+    """Private database copies (`dev<N>-pid<pid>`) of worker processes that are gone: what they found is merged back into the
+    stable per-device directory (entries it lacks), the copy is removed.  Called by WorkerPool.close() — a terminated daemon
+    process never runs its atexit handlers."""
+    import re
+    import shutil
+    base = os.environ.get("IRN_MIOPEN_BASE")
+    if not base:
+        return 0
+    root = os.path.join(base, miopen_cache_key())
+    n = 0
+    try:
+        entries = os.listdir(root)
+    except OSError:
+        return 0
+    for d in entries:
+        m = re.match(r"^(dev\d+)-pid(\d+)$", d)
+        if not m or int(m.group(2)) not in pids:
+            continue
+        src, stable = os.path.join(root, d), os.path.join(root, m.group(1))
+        try:
+            if os.path.isdir(stable):
+                merge_miopen_db(src, stable)
+            shutil.rmtree(src, ignore_errors=True)
+            n += 1
+        except OSError:
+            pass
+    return n
 
 
 _WORKER_DEVICE = [None]      # set inside a pool worker process
@@ -197,6 +243,7 @@ def _pool_worker(rank, device, n_workers, cmd_q, res_q):
         _WORKER_DEVICE[0] = int(device)
         if int(device) >= 0:                  # negative ordinals: workers without a GPU (the pool's own CPU tests)
             os.environ.pop("IRN_MIOPEN_DB_SET", None)    # the parent's claim is the parent's: this process makes its own
+            os.environ.pop("IRN_MIOPEN_DB_DEV", None)
             miopen_setup(int(device))                    # stable per-device database, never shared by two live processes
             torch.cuda.set_device(int(device))
         res_q.put((rank, "ready", None))
@@ -213,7 +260,7 @@ def _pool_worker(rank, device, n_workers, cmd_q, res_q):
                     torch.cuda.synchronize()
                 res_q.put((rank, "ok", {"cam_store_hits": CAM_STORE.hits, "cam_store_misses": CAM_STORE.misses,
                                         "edge_store_hits": EDGE_STORE.hits, "edge_store_misses": EDGE_STORE.misses,
-                                        "walk_fallback_runs": WALK_STATS["fallback_runs"]}))
+                                        "walk_fallback_runs": WALK_STATS["fallback_runs"], "cam_trunk_passes": dict(CAM_STATS)}))
             except BaseException:
                 res_q.put((rank, "error", traceback.format_exc()))
     except BaseException:
@@ -290,12 +337,20 @@ class WorkerPool:
                     q.put(None)
                 except Exception:
                     pass
+        pids = set()
         for p in self._procs:
             p.join(timeout=0.1 if force else 20.0)
             if p.is_alive():
                 p.terminate()
                 p.join(timeout=5.0)
+            if p.pid is not None and not p.is_alive():
+                pids.add(p.pid)
         self._procs = []
+        if pids:
+            try:
+                reap_private_miopen_dbs(pids)
+            except Exception:
+                pass
 
 
 def get_pool(devices):
@@ -543,7 +598,7 @@ class EdgeStore:
     image with the same weights, in make_sem_seg_labels (step/make_sem_seg_labels.py:28-34): 2 ms of a 2.7 ms image in the
     second step.  Whichever label step runs first puts {edge [1,h,w], dp [2,h,w]} here (196 KB at 512^2; all of VOC12
     train_aug is 1.5 GB), the other one takes them and skips its IRNet forward.  An entry is keyed by the network
-    (class + checkpoint path + the file's mtime and size, or the module's identity), the crop / stride of the forward, and the
+    (class + checkpoint path + the file's mtime and size; a network not built from a ModelSpec gets no hand-off), the crop / stride of the forward, and the
     image FILE (path + mtime + size): other weights or another image under the same name is another key.  A miss is simply
     computed.  `args.keep_edges_on_device = False` (run_sample.py --keep_edges_on_device 0) switches it off.  Results: the
     maps are what the first step computed — identical to a recomputation up to MIOpen's choice of solver for another batch

@@ -88,7 +88,7 @@ def _work(process_id, model, dataset, args):
     spec_key = model.key() if isinstance(model, _common.ModelSpec) else None
     model = _common.materialise(model)      # a network, or the (class, checkpoint) a worker builds it from
     if spec_key is not None:
-        make_sem_seg_labels._MODEL_KEYS[id(model)] = spec_key
+        make_sem_seg_labels.remember_model(model, spec_key)
     databin = dataset[process_id]
     n_gpus = len(dataset)
     loader = _common.make_loader(databin, int(args.num_workers) // n_gpus)

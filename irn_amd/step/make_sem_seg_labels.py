@@ -53,14 +53,33 @@ def edges_for(model, pend, irn_batch, store=None, model_key=None):
                 store.put(key, edge, dp.clone())         # dp is a view into the batch's output: keep 1 image, not 8
 
 
-_MODEL_KEYS = {}          # id(network) -> key of the ModelSpec it was built from (set in _work)
+_MODEL_KEYS = {}          # id(network) -> (weak reference to it, key of the ModelSpec it was built from); set in _work
+
+
+def remember_model(model, spec_key):
+    """Note which checkpoint (class + path + mtime + size) a worker built `model` from: the identity the EdgeStore keys
+    its entries by.  The weak reference guards against a later object reusing the id of a freed network."""
+    import weakref
+    for k in [k for k, (ref, _) in _MODEL_KEYS.items() if ref() is None]:
+        del _MODEL_KEYS[k]
+    _MODEL_KEYS[id(model)] = (weakref.ref(model), spec_key)
+
+
+def model_key(model):
+    hit = _MODEL_KEYS.get(id(model))
+    return hit[1] if hit is not None and hit[0]() is model else None
 
 
 def _edge_store_kw(model, args):
     """Keyword arguments of `edges_for` that switch the device hand-off of the edge maps on (see _common.EdgeStore)."""
     if not _common.keep_edges(args):
         return {}
-    return {"store": _common.EDGE_STORE, "model_key": _MODEL_KEYS.get(id(model), ("module", id(model)))}
+    key = model_key(model)
+    if key is None:
+        # a network handed over as a module (not built from a ModelSpec) has no identity that survives an in-place weight
+        # update or a recycled id(): no hand-off for it, every step computes its own maps (ADVICE round 4)
+        return {}
+    return {"store": _common.EDGE_STORE, "model_key": key}
 
 
 def _start_copy(batch):
@@ -122,7 +141,7 @@ def _work(process_id, model, dataset, args):
     spec_key = model.key() if isinstance(model, _common.ModelSpec) else None
     model = _common.materialise(model)      # a network, or the (class, checkpoint) a worker builds it from
     if spec_key is not None:
-        _MODEL_KEYS[id(model)] = spec_key
+        remember_model(model, spec_key)
     databin = dataset[process_id]
     n_gpus = len(dataset)
     loader = _common.make_loader(databin, int(args.num_workers) // n_gpus)

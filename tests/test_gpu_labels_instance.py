@@ -227,6 +227,55 @@ def test_detect_instance_batch_vs_oracle_incl_empty_and_fragmented():
     assert np.array_equal(one["mask"], got[2]["mask"]) and np.array_equal(one["score"], got[2]["score"])
 
 
+def test_detect_instance_full_size_maps_crossing_many_tiles():
+    """Full-size (512x512 and ragged) class maps whose components wind through many of the labelling's 64 x 16 LDS tiles:
+    nested one-pixel rings with L-shaped spurs, interleaved combs of two classes, a checkerboard of 4-pixel blocks and one region covering the
+    whole map — detections (masks, classes, scores, their ORDER = raster order of first pixels) equal the restatement of
+    step/make_ins_seg_labels.py:82-105."""
+    from irn_amd import ops
+    rng = np.random.RandomState(23)
+
+    def spiral(h, w):
+        m = np.zeros((h, w), np.int32)
+        y0, x0, y1, x1 = 0, 0, h - 1, w - 1
+        k = 1
+        while y0 <= y1 and x0 <= x1:
+            m[y0, x0:x1 + 1] = k
+            m[y0:y1 + 1, x1] = k
+            if y1 > y0:
+                m[y1, x0 + 2:x1 + 1] = k
+            if x1 > x0 + 2:
+                m[y0 + 2:y1 + 1, x0 + 2] = k
+            y0, x0, y1, x1 = y0 + 2, x0 + 2, y1 - 2, x1 - 2
+            k = 1 + (k % 3)
+        return m
+
+    def combs(h, w):
+        m = np.zeros((h, w), np.int32)
+        m[0, :] = 1
+        m[h - 1, :] = 2
+        m[1:h - 2, 0::4] = 1            # teeth hanging from the top bar
+        m[2:h - 1, 2::4] = 2            # teeth standing on the bottom bar
+        return m
+
+    def blocks(h, w):
+        b = rng.randint(0, 4, size=((h + 3) // 4, (w + 3) // 4))
+        return np.kron(b, np.ones((4, 4), int))[:h, :w].astype(np.int32)
+
+    maps = [spiral(512, 512), combs(512, 512), blocks(512, 512), np.full((375, 500), 2, np.int32), combs(333, 500), spiral(130, 67)]
+    scores = [rng.rand(3, *m.shape).astype(np.float32) for m in maps]
+    cids = [np.array([3, 7, 11])] * len(maps)
+    got = ops.detect_instance_batch([torch.from_numpy(s).to(_dev()) for s in scores], [torch.from_numpy(m).to(_dev()) for m in maps],
+                                    cids, [3] * len(maps), [0.0, 10.0, 0.0, 100.0, 0.0, 0.0])
+    for i, m in enumerate(maps):
+        one_hot = np.stack([m == k + 1 for k in range(3)])
+        ref = O.detect_instance(scores[i], one_hot, cids[i], max_fragment_size=[0.0, 10.0, 0.0, 100.0, 0.0, 0.0][i])
+        assert got[i]["mask"].shape == ref["mask"].shape, (i, got[i]["mask"].shape, ref["mask"].shape)
+        assert np.array_equal(got[i]["mask"], ref["mask"].astype(bool)), i
+        assert np.array_equal(got[i]["class"], ref["class"]), i
+        assert np.array_equal(got[i]["score"], np.asarray(ref["score"], np.float32)), i
+
+
 def test_deferred_detections_equal_blocking_and_survive_the_next_batch():
     """detect_instance_batch(deferred=True): the packed transfer of batch A is still in flight on the copy stream while
     batch B (different sizes, so different offsets in its own staging buffer) is counted, emitted and collected; A's

@@ -30,16 +30,23 @@ def main():
     ap.add_argument("--channels-last", type=int, default=0)
     ap.add_argument("--single", type=int, default=1, help="also the one-pair / one-image shapes (the tail of a shard)")
     ap.add_argument("--suffix", default="", help="appended to the output directory's key (e.g. -nhwc)")
+    ap.add_argument("--deterministic", type=int, default=1,
+                    help="tune with MIOpen's deterministic attribute set (what the steps run with, IRN_DETERMINISTIC=1): only solvers "
+                         "without atomic accumulation are timed and recorded")
+    ap.add_argument("--fused-gemm", type=int, default=1, help="the trunk's stride-1 1x1 convolutions are hipBLASLt GEMMs (not MIOpen problems)")
     a = ap.parse_args()
     db = tempfile.mkdtemp(prefix="irn_miopen_warm_")
     os.environ["MIOPEN_USER_DB_PATH"] = db
     os.environ["MIOPEN_FIND_MODE"] = a.find_mode
     os.environ["IRN_MIOPEN_DB_SET"] = db                      # keep miopen_setup out of the way
     os.environ["IRN_CHANNELS_LAST"] = "1" if a.channels_last else "0"
+    os.environ["IRN_FUSED_GEMM"] = "1" if a.fused_gemm else "0"
+    os.environ["IRN_DETERMINISTIC"] = "1" if a.deterministic else "0"
     import torch
     from irn_amd.net import resnet50_cam, resnet50_irn, weights
     from irn_amd.step import _common
     torch.backends.cudnn.benchmark = True
+    torch.backends.cudnn.deterministic = bool(a.deterministic)
     dev = torch.device("cuda", 0)
     cam = resnet50_cam.CAM()
     cam.load_state_dict(weights.random_cam_state(1))
