@@ -424,7 +424,8 @@ __global__ __launch_bounds__(256) void det_border_kernel(const DetJob *__restric
         const int r = i / W, x = i - r * W;
         const int p = (r + 1) * kDetTH * W + x;
         const int c = cls[p];
-        if (c > 0 && cls[p - W] == c && (x == 0 || cls[p - 1] != c || cls[p - W - 1] != c)) uf_union(J.parent, p, p - W);
+        // (a border run restarts at every tile corner: p and p - 1 are only joined inside ONE tile)
+        if (c > 0 && cls[p - W] == c && (x % kDetTW == 0 || cls[p - 1] != c || cls[p - W - 1] != c)) uf_union(J.parent, p, p - W);
         return;
     }
     const int k = i - rows * W;
@@ -432,7 +433,7 @@ __global__ __launch_bounds__(256) void det_border_kernel(const DetJob *__restric
         const int q = k / H, y = k - q * H;
         const int p = y * W + (q + 1) * kDetTW;
         const int c = cls[p];
-        if (c > 0 && cls[p - 1] == c && (y == 0 || cls[p - W] != c || cls[p - W - 1] != c)) uf_union(J.parent, p, p - 1);
+        if (c > 0 && cls[p - 1] == c && (y % kDetTH == 0 || cls[p - W] != c || cls[p - W - 1] != c)) uf_union(J.parent, p, p - 1);
     }
 }
 

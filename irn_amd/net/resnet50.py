@@ -65,6 +65,10 @@ def channels_last_for(x):
     """Does the trunk run channels-last for the network input `x` [n, 3, H, W]?  (inference path only)"""
     if CHANNELS_LAST_MODE == "0" or not x.is_cuda or x.dim() != 4 or torch.is_grad_enabled():
         return False
+    if torch.backends.cudnn.deterministic:
+        # MIOpen's deterministic attribute (IRN_DETERMINISTIC=1, step/_common.deterministic_backbones) leaves no fast NHWC
+        # fp32 solver: the reproducible mode is the NCHW trunk
+        return False
     if CHANNELS_LAST_MODE == "1":
         return True
     # auto: only in a process whose MIOpen user database has been completed from the shipped one (step/_common.miopen_setup:

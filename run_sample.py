@@ -68,6 +68,10 @@ def build_parser():
                         "(misc/indexing.py:136-137).  Unset: the environment variable IRN_WALK_ACCEL, else 1")
     p.add_argument("--walk_accel_tol_exp", default=0, type=int,
                    help="truncation bound 10^-e of the series (0 = the library default, e = 7; 6 = 78 applications: +7 %, may flip an argmax at an exact tie)")
+    p.add_argument("--deterministic", default=None, type=int, choices=(0, 1),
+                   help="1 = bit-reproducible backbones (MIOpen's deterministic attribute, NCHW trunk): any worker layout writes "
+                        "identical files, at ~0.8x the speed (not in the reference).  Unset: the environment variable "
+                        "IRN_DETERMINISTIC, else 0")
     p.add_argument("--step_timeout", default=0.0, type=float,
                    help="seconds a step may take in its worker processes before the pool is stopped and the step raises "
                         "(0 = no limit; also IRN_STEP_TIMEOUT_S)")
@@ -96,6 +100,8 @@ def main(argv=None):
             raise SystemExit("--%s: this step is not part of the MI355X hot-path build; run it with the reference" % name)
     for d in (args.cam_out_dir, args.sem_seg_out_dir, args.ins_seg_out_dir):
         os.makedirs(d, exist_ok=True)
+    if args.deterministic is not None:
+        os.environ["IRN_DETERMINISTIC"] = str(int(args.deterministic))      # read by every process that sets MIOpen up (workers inherit it)
     pyutils.Logger(args.log_name + ".log")
     print(vars(args))
     if args.make_cam_pass is True:

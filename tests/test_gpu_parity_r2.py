@@ -203,9 +203,10 @@ def test_walk_voc_grids_vs_reference_golden(golden, variant):
         n_diff, gap = label_mismatches(lab, want, up, 0.25, lut=np.concatenate([[0], keys + 1]), what=n)
         print("%s variant %d: max |gpu - reference| %.2e, %d of %d label pixels differ (largest top-2 gap %.2e)" %
               (n, variant, np.abs(rw - ref).max(), n_diff, lab.size, gap))
-        # measured: 0 (radius 5) and 1 (radius 10: a tie with a top-2 gap of 7.5e-7).  No head-room beyond that kind of pixel:
-        # at most two, and only ties an order of magnitude below the 1e-4 bar (label_mismatches has checked each one is a tie)
-        assert n_diff <= 2 and (n_diff == 0 or gap < 1e-5), (n, variant, n_diff, gap)
+        # measured: 0 (radius 5) and 1 (radius 10: a tie with a top-2 gap of 7.5e-7).  No allowance on the count: label_mismatches
+        # has proven every differing pixel a tie of the reference's own score stack, and here the ties must be an order of
+        # magnitude below the 1e-4 bar
+        assert n_diff == 0 or gap < 1e-5, (n, variant, n_diff, gap)
         walker.close()
 
 
@@ -235,12 +236,21 @@ def test_walk_128_labels_vs_reference_epilogue(golden):
 # BASELINE configs[4]: 1024^2, 80 classes, radius 10
 # ------------------------------------------------------------------------------------------------
 
-def _argmax_equal_up_to_ties(a, b, tol):
-    """argmax over channels equal wherever the winner leads by more than tol in `b`."""
+def _argmax_mismatches_are_ties(a, b, tol):
+    """Grid argmax over channels of `a` against `b`'s: for EVERY pixel where they differ, b's two best channels are closer than
+    `tol` AND a picked a channel inside that band (b[picked] >= b[best] - tol).  -> number of such pixels (no bound on it:
+    each one is proven)."""
     ia, ib = np.argmax(a, 0), np.argmax(b, 0)
-    top2 = np.sort(b, 0)[-2:]
-    clear = (top2[1] - top2[0]) > tol
-    return bool(np.all(ia[clear] == ib[clear])), float((ia != ib).mean())
+    diff = ia != ib
+    n = int(diff.sum())
+    if n:
+        cols = b[:, diff]
+        best = cols.max(0)
+        srt = np.sort(cols, 0)
+        assert float((srt[-1] - srt[-2]).max()) < tol, "argmax differs at a pixel whose top-2 gap is %.3g" % float((srt[-1] - srt[-2]).max())
+        picked = cols[ia[diff], np.arange(n)]
+        assert bool((picked >= best - tol).all()), "a differing pixel chose a channel outside the tie band"
+    return n
 
 
 @pytest.mark.parametrize("n_sweeps", [16, 256])
@@ -260,8 +270,8 @@ def test_coco_shape_80_channels(n_sweeps):
     d = (a - b).abs().max().item()
     assert d <= (2e-6 if n_sweeps <= 16 else TOL_F64), d
     a_np, b_np = a[:, 0].cpu().numpy(), b[:, 0].cpu().numpy()
-    ok, frac = _argmax_equal_up_to_ties(a_np, b_np, 2e-5)
-    assert ok and frac <= 1e-4, frac
+    n_ties = _argmax_mismatches_are_ties(a_np, b_np, 2e-5)
+    print("80-channel grid argmax, %d sweeps: %d of %d pixels differ from the fp64 kernel's, every one a tie below 2e-5" % (n_sweeps, n_ties, h * w))
     # the C oracle (fp64 stencil, pinned on the reference's outputs) on three of the channels: channels are independent
     lib = build_oracle.load()
     sel = [0, 37, 79]

@@ -187,19 +187,32 @@ def test_steps_end_to_end(tmp_path):
         print("%s: %d of %d instance-class pixels differ from the oracle (largest top-2 gap %.2e)" % (n, n_diff, H * W, gap))
         if len(want["score"]) == len(d["score"]):
             assert np.array_equal(np.asarray(want["class"]), d["class"]), n
-            mask_diff = int((np.asarray(want["mask"]).astype(bool) != d["mask"]).sum())
-            assert mask_diff <= 2 * max(n_diff, 8), (n, mask_diff, n_diff)      # a tied pixel flips in at most two masks
+            # masks: every pixel at which any detection's mask differs is a tie (< 1e-4) between the two best entries of the
+            # oracle's score stack (background included) — proven per pixel, no allowance on the count
+            moved = (np.asarray(want["mask"]).astype(bool) != d["mask"]).any(0)
+            if moved.any():
+                stack = np.sort(np.concatenate([np.full((1, H, W), 0.25, np.float32), up_i], 0)[:, moved], 0)
+                assert float((stack[-1] - stack[-2]).max()) < 1e-4, (n, int(moved.sum()), float((stack[-1] - stack[-2]).max()))
             assert np.abs(np.asarray(want["score"], np.float32) - d["score"]).max() <= 1e-3, n
 
 
-def test_steps_two_worker_processes_on_one_device(tmp_path):
+@pytest.mark.parametrize("mode", ["deterministic", "fast"])
+def test_steps_two_worker_processes_on_one_device(tmp_path, monkeypatch, mode):
     """The N > 1 path of the steps on a one-GPU box: `worker_devices="0,0"` = two persistent worker processes sharing
     GPU 0 (reference: one process per GPU, step/make_cam.py:71-74).  Exercises spawn, model pickling, HIP + MIOpen
     start-up in the children, the CAM hand-off in EACH worker's device memory across steps (CAM-owner aware shards), two
     resident (cooperative, all-CU) walks contending for one GPU — whichever loses its bounded wait is re-run on the
-    streaming sweeps — and compares every output file with the single-process run."""
+    streaming sweeps — and compares every output file with the single-process run:
+      deterministic  (IRN_DETERMINISTIC=1: MIOpen's deterministic attribute, NCHW trunk) — the two layouts write the SAME
+                     bits: CAMs, label maps, detections;
+      fast           (the default: tuned channels-last trunk, split-K solvers) — the CAMs agree to fp32 rounding, and every
+                     label / instance-class pixel of EITHER run that differs from the oracle (fp64 walk + the reference's
+                     epilogue on the one-process run's own CAM files and edge maps) is proven a < 1e-4 tie of the oracle's
+                     score stack.  No allowance on any pixel count."""
     from irn_amd.net import weights
     from irn_amd.step import _common, make_cam, make_ins_seg_labels, make_sem_seg_labels
+    from oracle import build_oracle, irn_oracle as O
+    monkeypatch.setenv("IRN_DETERMINISTIC", "1" if mode == "deterministic" else "0")      # spawned workers inherit it
     root, names, labels = _make_voc(tmp_path, n=6)
     torch.save(weights.random_cam_state(1), tmp_path / "res50_cam.pth")
     torch.save(weights.random_irn_state(2), tmp_path / "res50_irn.pth")
@@ -231,42 +244,66 @@ def test_steps_two_worker_processes_on_one_device(tmp_path):
     assert len(stats) == 2
     hits = sum(s["cam_store_hits"] for s in stats)
     misses = sum(s["cam_store_misses"] for s in stats)
-    print("two workers on device 0: CAM hand-offs in device memory %d, from files %d; walk batches re-run on the streaming "
-          "sweeps: %s" % (hits, misses, [s["walk_fallback_runs"] for s in stats]))
+    print("two workers on device 0 (%s): CAM hand-offs in device memory %d, from files %d; walk batches re-run on the streaming "
+          "sweeps: %s" % (mode, hits, misses, [s["walk_fallback_runs"] for s in stats]))
     assert sum(s["cam_store_hits"] for s in stats_sem) == len(names)      # every CAM was found in its worker's memory
     assert hits == 2 * len(names) and misses == 0
 
     one = make_args("one")
     _common.CAM_STORE.clear()
+    _common.EDGE_STORE.clear()
     hits_before = _common.CAM_STORE.hits
     make_cam.run(one)
-    make_sem_seg_labels.run(one)
-    make_ins_seg_labels.run(one)
+    with _CaptureEdges(make_sem_seg_labels) as cap:
+        make_sem_seg_labels.run(one)
+        make_ins_seg_labels.run(one)
     assert _common.CAM_STORE.hits - hits_before == 2 * len(names)
-    n_px = n_diff = ins_diff = 0
+    assert torch.backends.cudnn.deterministic == (mode == "deterministic")
+    olib = build_oracle.load()
+    paint = lambda det: (np.asarray(det["mask"]).astype(np.int64) * (np.asarray(det["class"], np.int64) + 1)[:, None, None]).sum(0)
+    n_px = sem_two = sem_one = ins_two = ins_one = 0
+    cam_dev = 0.0
     for n in names:
         a = np.load(os.path.join(two.cam_out_dir, n + ".npy"), allow_pickle=True).item()
         b = np.load(os.path.join(one.cam_out_dir, n + ".npy"), allow_pickle=True).item()
         assert torch.equal(a["keys"], b["keys"])
-        # another process may get another MIOpen solver for the same convolution: the CAMs agree to fp32 rounding of the
-        # backbone (measured 1.2e-5), far inside the 1e-4 bar
-        assert (a["cam"] - b["cam"]).abs().max().item() <= 5e-5 and np.abs(a["high_res"] - b["high_res"]).max() <= 5e-5, n
         pa = np.asarray(Image.open(os.path.join(two.sem_seg_out_dir, n + ".png")))
         pb = np.asarray(Image.open(os.path.join(one.sem_seg_out_dir, n + ".png")))
         assert pa.shape == pb.shape
-        n_px += pa.size
-        n_diff += int((pa != pb).sum())
         fa, fb = os.path.join(two.ins_seg_out_dir, n + ".npy"), os.path.join(one.ins_seg_out_dir, n + ".npy")
         assert os.path.exists(fa) == os.path.exists(fb), n
-        if os.path.exists(fa):
-            da, db = np.load(fa, allow_pickle=True).item(), np.load(fb, allow_pickle=True).item()
-            # the two runs' CAMs differ at 1e-5 (another MIOpen solver in another process): an instance fragment whose two
-            # best channels tie at that level may change hands, so the class maps the detections paint are compared
-            paint = lambda det: (np.asarray(det["mask"]).astype(np.int64) * (np.asarray(det["class"], np.int64) + 1)[:, None, None]).sum(0)
-            ins_diff += int((paint(da) != paint(db)).sum())
-    print("two-worker vs one-process: %d of %d semantic label pixels and %d instance-class pixels differ" % (n_diff, n_px, ins_diff))
-    assert n_diff <= 8          # same kernels on the same inputs; MIOpen may pick another solver in another process
-    assert ins_diff <= 0.01 * n_px
+        da = np.load(fa, allow_pickle=True).item() if os.path.exists(fa) else None
+        db = np.load(fb, allow_pickle=True).item() if os.path.exists(fb) else None
+        n_px += pa.size
+        if mode == "deterministic":
+            assert torch.equal(a["cam"], b["cam"]) and np.array_equal(a["high_res"], b["high_res"]), n
+            assert np.array_equal(pa, pb), n
+            if da is not None:
+                assert np.array_equal(da["mask"], db["mask"]) and np.array_equal(da["class"], db["class"]) and np.array_equal(da["score"], db["score"]), n
+            continue
+        # fast mode: the CAMs agree to fp32 rounding of the backbone (split-K accumulation order), far inside the 1e-4 bar ...
+        cam_dev = max(cam_dev, (a["cam"] - b["cam"]).abs().max().item(), float(np.abs(a["high_res"] - b["high_res"]).max()))
+        assert cam_dev <= 5e-5, (n, cam_dev)
+        # ... and every pixel of either run's outputs that differs from the oracle's is a tie of the oracle's own scores
+        H, W = pa.shape
+        keys = b["keys"].numpy()
+        rw = build_oracle.walk(olib, b["cam"].numpy(), cap.edges[n], 10, 10, 256)
+        up, want, _ = O.sem_seg_epilogue(rw, (H, W), keys, 0.25)
+        lut = np.concatenate([[0], keys + 1])
+        sem_two += label_mismatches(pa, want, up, 0.25, lut=lut, what=n + " two-worker labels")[0]
+        sem_one += label_mismatches(pb, want, up, 0.25, lut=lut, what=n + " one-process labels")[0]
+        if da is not None:
+            walk = lambda x, e, radius, beta, exp_times: build_oracle.walk(olib, x, e, radius, beta, 2 ** exp_times)
+            _, inst, rw_i, _, want_i = O.instance_labels(b["cam"].numpy(), keys, cap.edges[n], cap.dps[n], (H, W), walk=walk, radius=10)
+            up_i, _, _ = O.sem_seg_epilogue(rw_i, (H, W), np.zeros(rw_i.shape[0], np.int64), 0.25)
+            chan_class = np.concatenate([[0], np.repeat(keys, inst.shape[0]) + 1])
+            ins_two += label_mismatches(paint(da), paint(want_i), up_i, 0.25, lut=chan_class, what=n + " two-worker instance classes")[0]
+            ins_one += label_mismatches(paint(db), paint(want_i), up_i, 0.25, lut=chan_class, what=n + " one-process instance classes")[0]
+    if mode == "deterministic":
+        print("two-worker vs one-process, deterministic mode: CAMs, label maps and detections of %d images bit-identical (%d label pixels)" % (len(names), n_px))
+    else:
+        print("two-worker vs one-process, fast mode: CAMs within %.1e; pixels differing from the oracle (each proven a < 1e-4 tie): labels %d / %d, "
+              "instance classes %d / %d of %d" % (cam_dev, sem_two, sem_one, ins_two, ins_one, n_px))
 
 
 def test_run_sample_cli_end_to_end(tmp_path):
@@ -321,7 +358,9 @@ def test_run_sample_cli_end_to_end(tmp_path):
         n_px += a.size
         n_diff += int((a != b).sum())
     print("run_sample.py --walk_accel 1 vs 0: %d of %d semantic label pixels differ" % (n_diff, n_px))
-    assert n_diff <= 2                                    # two schedules of the same operator: exact ties only (measured: 0)
+    # two schedules of the same operator on the SAME inputs (the second run takes the first one's edge maps from device
+    # memory, the CAM files are shared): deterministic kernels, measured 0 in every session since round 3
+    assert n_diff == 0
     with pytest.raises(SystemExit):                      # a pass this build does not implement refuses loudly
         run_sample.main(["--voc12_root", str(root), "--train_irn_pass", "True", "--log_name", str(tmp_path / "log2")])
 
