@@ -105,8 +105,8 @@ WORKLOADS = {
     "walk":    (128, 128, 10, 10.0, 8, (512, 512), 192),     # BASELINE configs[2]
     "walk_plain": (128, 128, 10, 10.0, 8, (512, 512), 192),  # the same with the plain 2^exp_times iteration (accel = 0)
     "walk_r5": (128, 128, 5, 10.0, 8, (512, 512), 256),     # configs[0]'s operator setting at full batch
-    "ins":     (128, 128, 5, 10.0, 8, (512, 512), 64),      # configs[3]: instance labels, radius 5 = the reference's call site (step/make_ins_seg_labels.py:135)
-    "ins_r10": (128, 128, 10, 10.0, 8, (512, 512), 64),     # the same at SURVEY.md 8(d)'s row 4 radius
+    "ins":     (128, 128, 5, 10.0, 8, (512, 512), 128),     # configs[3]: instance labels, radius 5 = the reference's call site (step/make_ins_seg_labels.py:135)
+    "ins_r10": (128, 128, 10, 10.0, 8, (512, 512), 128),    # the same at SURVEY.md 8(d)'s row 4 radius
     "coco":    (256, 256, 10, 10.0, 8, (1024, 1024), 2),    # configs[4]: 80 classes, 1024^2
     # SURVEY.md 8(d) "ragged variant" of configs[2]: image sizes drawn from the VOC12 size histogram (synth.VOC_SIZES:
     # 500x375, 375x500, 500x333, ...), i.e. 94x125, 125x94, 84x125, ... grids; h, w here are only the nominal grid
@@ -618,7 +618,7 @@ def run_workload(a, workload, rank, world, device, dist, parallel, steps, warmup
 
 LEG_RUNS = {   # short runs for the `legs` object of the default line: (steps, warmup, batch)
     "cam": (12, 1, 8), "e2e": (12, 1, 8), "steps": (2, 1, 256), "walk_r5": (10, 2, 256), "walk_plain": (4, 1, 192),
-    "ins": (10, 2, 64), "ins_r10": (8, 2, 64), "coco": (10, 2, 2),
+    "ins": (10, 2, 128), "ins_r10": (8, 2, 128), "coco": (10, 2, 2),
     "walk_voc": (10, 2, 192), "walk_voc_r5": (10, 2, 256), "steps_voc": (1, 1, 256),
 }
 

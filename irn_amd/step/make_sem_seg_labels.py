@@ -13,6 +13,7 @@ reference's hard-coded value) selects the walk radius.
 """
 import os
 
+import numpy as np
 import torch
 from PIL import Image
 
@@ -27,7 +28,7 @@ def _save_png(path, label):
     Image.fromarray(label).save(path)
 
 
-def edges_for(model, pend, irn_batch, store=None, model_key=None):
+def edges_for(model, pend, irn_batch, store=None, model_key=None, dump_dir=None):
     """EdgeDisplacement forward for the pending images, `irn_batch` at a time: ragged images are padded to the
     512^2 crop like the reference pads each one (net/resnet50_irn.py:225), so a chunk is ONE trunk pass.  With a `store`
     (`_common.EDGE_STORE`) the maps the other label step already computed for an image (same network, same file) are taken
@@ -51,6 +52,13 @@ def edges_for(model, pend, irn_batch, store=None, model_key=None):
             key = p.pop("_edge_key", None)
             if store is not None and key is not None:
                 store.put(key, edge, dp.clone())         # dp is a view into the batch's output: keep 1 image, not 8
+    if dump_dir:
+        # verification aid (args.edge_out_dir, off by default): the maps this step walks on, per image, so that a run can be
+        # checked against the oracle on ITS OWN inputs (the reference keeps them in memory only, step/make_sem_seg_labels.py:28-34).
+        # Synchronous on purpose: not a production path
+        os.makedirs(dump_dir, exist_ok=True)
+        for p in pend:
+            np.save(os.path.join(dump_dir, p["name"] + ".npy"), {"edge": p["edge"].cpu().numpy(), "dp": p["dp"].cpu().numpy()})
 
 
 _MODEL_KEYS = {}          # id(network) -> (weak reference to it, key of the ModelSpec it was built from); set in _work
@@ -72,14 +80,15 @@ def model_key(model):
 
 def _edge_store_kw(model, args):
     """Keyword arguments of `edges_for` that switch the device hand-off of the edge maps on (see _common.EdgeStore)."""
+    dump = {"dump_dir": args.edge_out_dir} if getattr(args, "edge_out_dir", None) else {}
     if not _common.keep_edges(args):
-        return {}
+        return dump
     key = model_key(model)
     if key is None:
         # a network handed over as a module (not built from a ModelSpec) has no identity that survives an in-place weight
         # update or a recycled id(): no hand-off for it, every step computes its own maps (ADVICE round 4)
-        return {}
-    return {"store": _common.EDGE_STORE, "model_key": key}
+        return dump
+    return {"store": _common.EDGE_STORE, "model_key": key, **dump}
 
 
 def _start_copy(batch):

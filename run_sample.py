@@ -82,6 +82,9 @@ def build_parser():
     p.add_argument("--ir_label_out_dir", default="result/ir_label", type=str)
     p.add_argument("--sem_seg_out_dir", default="result/sem_seg", type=str)
     p.add_argument("--ins_seg_out_dir", default="result/ins_seg", type=str)
+    p.add_argument("--edge_out_dir", default=None, type=str,
+                   help="verification aid (not in the reference): also write every image's boundary / displacement maps "
+                        "(<name>.npy = {'edge' [1,h,w], 'dp' [2,h,w]}) as the label steps used them")
     for name, default in (("train_cam_pass", False), ("make_cam_pass", True), ("eval_cam_pass", False),
                           ("cam_to_ir_label_pass", False), ("train_irn_pass", False), ("make_ins_seg_pass", True),
                           ("eval_ins_seg_pass", False), ("make_sem_seg_pass", True), ("eval_sem_seg_pass", False)):

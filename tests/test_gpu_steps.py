@@ -202,13 +202,17 @@ def test_steps_two_worker_processes_on_one_device(tmp_path, monkeypatch, mode):
     GPU 0 (reference: one process per GPU, step/make_cam.py:71-74).  Exercises spawn, model pickling, HIP + MIOpen
     start-up in the children, the CAM hand-off in EACH worker's device memory across steps (CAM-owner aware shards), two
     resident (cooperative, all-CU) walks contending for one GPU — whichever loses its bounded wait is re-run on the
-    streaming sweeps — and compares every output file with the single-process run:
+    streaming sweeps — and checks every output file of the two-worker layout against the one-worker layout:
       deterministic  (IRN_DETERMINISTIC=1: MIOpen's deterministic attribute, NCHW trunk) — the two layouts write the SAME
-                     bits: CAMs, label maps, detections;
-      fast           (the default: tuned channels-last trunk, split-K solvers) — the CAMs agree to fp32 rounding, and every
-                     label / instance-class pixel of EITHER run that differs from the oracle (fp64 walk + the reference's
-                     epilogue on the one-process run's own CAM files and edge maps) is proven a < 1e-4 tie of the oracle's
-                     score stack.  No allowance on any pixel count."""
+                     bits: CAMs, label maps, detections.  (Both layouts run in fresh worker processes: MIOpen keeps the solvers
+                     it resolved for a problem per process, whatever the attribute says later, so a process that ran the same
+                     convolution shapes in the fast mode before — this pytest process — is not a deterministic one.)
+      fast           (the default: tuned channels-last trunk, split-K solvers) — the CAMs agree to fp32 rounding; the boundary /
+                     displacement maps move by ~1e-5 too, and the instance clustering is discontinuous in them, so the two
+                     runs are not compared with each other: EACH run's labels and instance classes are checked against the
+                     oracle (fp64 walk + the reference's epilogue / clustering) on that run's OWN CAM files and edge maps
+                     (`edge_out_dir`), every differing pixel proven a < 1e-4 tie of the oracle's score stack.
+    No allowance on any pixel count."""
     from irn_amd.net import weights
     from irn_amd.step import _common, make_cam, make_ins_seg_labels, make_sem_seg_labels
     from oracle import build_oracle, irn_oracle as O
@@ -225,22 +229,27 @@ def test_steps_two_worker_processes_on_one_device(tmp_path, monkeypatch, mode):
             irn_network="net.resnet50_irn", irn_weights_name=str(tmp_path / "res50_irn.pth"),
             beta=10, exp_times=8, sem_seg_bg_thres=0.25, ins_seg_bg_thres=0.25, radius=10,
             cam_out_dir=str(tmp_path / (tag + "_cam")), sem_seg_out_dir=str(tmp_path / (tag + "_sem")),
-            ins_seg_out_dir=str(tmp_path / (tag + "_ins")), walk_batch=2, cam_batch=1, irn_batch=1, **kw)
+            ins_seg_out_dir=str(tmp_path / (tag + "_ins")), edge_out_dir=str(tmp_path / (tag + "_edge")),
+            walk_batch=2, cam_batch=1, irn_batch=1, **kw)
         for d in (a.cam_out_dir, a.sem_seg_out_dir, a.ins_seg_out_dir):
             os.makedirs(d)
         return a
 
+    def run_layout(args):
+        try:
+            make_cam.run(args)
+            make_sem_seg_labels.run(args)
+            stats_sem = _common.pool_stats()
+            make_ins_seg_labels.run(args)
+            stats = _common.pool_stats()
+            pool = _common._POOL[0]
+            assert pool is not None and pool.alive() and len(pool.devices) == len(stats)
+        finally:
+            _common.shutdown_workers()
+        return stats_sem, stats
+
     two = make_args("two", worker_devices="0,0")
-    try:
-        make_cam.run(two)
-        make_sem_seg_labels.run(two)
-        stats_sem = _common.pool_stats()
-        make_ins_seg_labels.run(two)
-        stats = _common.pool_stats()
-        pool = _common._POOL[0]
-        assert pool is not None and pool.alive() and len(pool.devices) == 2
-    finally:
-        _common.shutdown_workers()
+    stats_sem, stats = run_layout(two)
     assert len(stats) == 2
     hits = sum(s["cam_store_hits"] for s in stats)
     misses = sum(s["cam_store_misses"] for s in stats)
@@ -249,20 +258,15 @@ def test_steps_two_worker_processes_on_one_device(tmp_path, monkeypatch, mode):
     assert sum(s["cam_store_hits"] for s in stats_sem) == len(names)      # every CAM was found in its worker's memory
     assert hits == 2 * len(names) and misses == 0
 
-    one = make_args("one")
-    _common.CAM_STORE.clear()
-    _common.EDGE_STORE.clear()
-    hits_before = _common.CAM_STORE.hits
-    make_cam.run(one)
-    with _CaptureEdges(make_sem_seg_labels) as cap:
-        make_sem_seg_labels.run(one)
-        make_ins_seg_labels.run(one)
-    assert _common.CAM_STORE.hits - hits_before == 2 * len(names)
-    assert torch.backends.cudnn.deterministic == (mode == "deterministic")
+    one = make_args("one", worker_devices="0", always_use_workers=True)   # ONE worker process: the other layout
+    _, stats1 = run_layout(one)
+    assert len(stats1) == 1 and stats1[0]["cam_store_hits"] == 2 * len(names)
     olib = build_oracle.load()
     paint = lambda det: (np.asarray(det["mask"]).astype(np.int64) * (np.asarray(det["class"], np.int64) + 1)[:, None, None]).sum(0)
-    n_px = sem_two = sem_one = ins_two = ins_one = 0
+    walk = lambda x, e, radius, beta, exp_times: build_oracle.walk(olib, x, e, radius, beta, 2 ** exp_times)
+    n_px = 0
     cam_dev = 0.0
+    ties = {"two labels": 0, "two instance classes": 0, "one labels": 0, "one instance classes": 0}
     for n in names:
         a = np.load(os.path.join(two.cam_out_dir, n + ".npy"), allow_pickle=True).item()
         b = np.load(os.path.join(one.cam_out_dir, n + ".npy"), allow_pickle=True).item()
@@ -271,39 +275,46 @@ def test_steps_two_worker_processes_on_one_device(tmp_path, monkeypatch, mode):
         pb = np.asarray(Image.open(os.path.join(one.sem_seg_out_dir, n + ".png")))
         assert pa.shape == pb.shape
         fa, fb = os.path.join(two.ins_seg_out_dir, n + ".npy"), os.path.join(one.ins_seg_out_dir, n + ".npy")
-        assert os.path.exists(fa) == os.path.exists(fb), n
         da = np.load(fa, allow_pickle=True).item() if os.path.exists(fa) else None
         db = np.load(fb, allow_pickle=True).item() if os.path.exists(fb) else None
+        ea = np.load(os.path.join(two.edge_out_dir, n + ".npy"), allow_pickle=True).item()
+        eb = np.load(os.path.join(one.edge_out_dir, n + ".npy"), allow_pickle=True).item()
         n_px += pa.size
         if mode == "deterministic":
             assert torch.equal(a["cam"], b["cam"]) and np.array_equal(a["high_res"], b["high_res"]), n
+            assert np.array_equal(ea["edge"], eb["edge"]) and np.array_equal(ea["dp"], eb["dp"]), n
             assert np.array_equal(pa, pb), n
+            assert (da is None) == (db is None), n
             if da is not None:
-                assert np.array_equal(da["mask"], db["mask"]) and np.array_equal(da["class"], db["class"]) and np.array_equal(da["score"], db["score"]), n
+                assert da["mask"].shape == db["mask"].shape, (n, da["mask"].shape, db["mask"].shape, da["class"], db["class"])
+                assert np.array_equal(da["class"], db["class"]), (n, da["class"], db["class"])
+                assert np.array_equal(da["mask"], db["mask"]), (n, int((da["mask"] != db["mask"]).sum()))
+                assert np.array_equal(da["score"], db["score"]), (n, da["score"], db["score"])
             continue
-        # fast mode: the CAMs agree to fp32 rounding of the backbone (split-K accumulation order), far inside the 1e-4 bar ...
-        cam_dev = max(cam_dev, (a["cam"] - b["cam"]).abs().max().item(), float(np.abs(a["high_res"] - b["high_res"]).max()))
+        # fast mode: the backbones' outputs agree to fp32 rounding (split-K accumulation order), far inside the 1e-4 bar ...
+        cam_dev = max(cam_dev, (a["cam"] - b["cam"]).abs().max().item(), float(np.abs(a["high_res"] - b["high_res"]).max()),
+                      float(np.abs(ea["edge"] - eb["edge"]).max()))
         assert cam_dev <= 5e-5, (n, cam_dev)
-        # ... and every pixel of either run's outputs that differs from the oracle's is a tie of the oracle's own scores
+        # ... and each run's outputs equal the oracle's on that run's own inputs except at proven ties
         H, W = pa.shape
-        keys = b["keys"].numpy()
-        rw = build_oracle.walk(olib, b["cam"].numpy(), cap.edges[n], 10, 10, 256)
-        up, want, _ = O.sem_seg_epilogue(rw, (H, W), keys, 0.25)
-        lut = np.concatenate([[0], keys + 1])
-        sem_two += label_mismatches(pa, want, up, 0.25, lut=lut, what=n + " two-worker labels")[0]
-        sem_one += label_mismatches(pb, want, up, 0.25, lut=lut, what=n + " one-process labels")[0]
-        if da is not None:
-            walk = lambda x, e, radius, beta, exp_times: build_oracle.walk(olib, x, e, radius, beta, 2 ** exp_times)
-            _, inst, rw_i, _, want_i = O.instance_labels(b["cam"].numpy(), keys, cap.edges[n], cap.dps[n], (H, W), walk=walk, radius=10)
+        for tag, cam_d, edges, png, det in (("two", a, ea, pa, da), ("one", b, eb, pb, db)):
+            keys = cam_d["keys"].numpy()
+            rw = build_oracle.walk(olib, cam_d["cam"].numpy(), edges["edge"][0], 10, 10, 256)
+            up, want, _ = O.sem_seg_epilogue(rw, (H, W), keys, 0.25)
+            ties[tag + " labels"] += label_mismatches(png, want, up, 0.25, lut=np.concatenate([[0], keys + 1]), what="%s %s-worker labels" % (n, tag))[0]
+            if det is None:                          # an image without detections writes no file (the reference would crash)
+                continue
+            _, inst, rw_i, _, want_i = O.instance_labels(cam_d["cam"].numpy(), keys, edges["edge"][0], edges["dp"], (H, W), walk=walk, radius=10)
             up_i, _, _ = O.sem_seg_epilogue(rw_i, (H, W), np.zeros(rw_i.shape[0], np.int64), 0.25)
             chan_class = np.concatenate([[0], np.repeat(keys, inst.shape[0]) + 1])
-            ins_two += label_mismatches(paint(da), paint(want_i), up_i, 0.25, lut=chan_class, what=n + " two-worker instance classes")[0]
-            ins_one += label_mismatches(paint(db), paint(want_i), up_i, 0.25, lut=chan_class, what=n + " one-process instance classes")[0]
+            ties[tag + " instance classes"] += label_mismatches(paint(det), paint(want_i), up_i, 0.25, lut=chan_class,
+                                                                 what="%s %s-worker instance classes" % (n, tag))[0]
     if mode == "deterministic":
-        print("two-worker vs one-process, deterministic mode: CAMs, label maps and detections of %d images bit-identical (%d label pixels)" % (len(names), n_px))
+        print("two workers vs one worker, deterministic mode: CAMs, edge / displacement maps, label maps and detections of %d images "
+              "bit-identical (%d label pixels)" % (len(names), n_px))
     else:
-        print("two-worker vs one-process, fast mode: CAMs within %.1e; pixels differing from the oracle (each proven a < 1e-4 tie): labels %d / %d, "
-              "instance classes %d / %d of %d" % (cam_dev, sem_two, sem_one, ins_two, ins_one, n_px))
+        print("two workers vs one worker, fast mode: backbone outputs within %.1e; pixels differing from the oracle on the run's own inputs "
+              "(each proven a < 1e-4 tie) of %d: %s" % (cam_dev, n_px, ties))
 
 
 def test_run_sample_cli_end_to_end(tmp_path):

@@ -57,7 +57,8 @@ def _worker(rank, a, q, go):
         # payloads of the real sizes (K classes per image from the VOC histogram; ~7.5 detections per image)
         cam_pay = {k: (torch.from_numpy(rng.rand(k, gh, gw).astype(np.float32)), rng.rand(k, h, w).astype(np.float32)) for k in (1, 2, 3, 4)}
         det_pay = {"score": rng.rand(8).astype(np.float32), "mask": rng.rand(8, h, w) > 0.7, "class": np.arange(8)}
-        png_pay = (rng.rand(h, w) * 21).astype(np.uint8)
+        # a label map like the step writes: a few classes in blobs (noise would be incompressible: PNG encoding 3x slower)
+        png_pay = np.kron(rng.choice([0, 0, 0, 5, 12, 15], size=((h + 63) // 64, (w + 63) // 64)), np.ones((64, 64), int))[:h, :w].astype(np.uint8)
 
         def save_png(path, lab):
             Image.fromarray(lab).save(path)
