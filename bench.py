@@ -459,6 +459,14 @@ def run_backbone(a, workload, rank, world, device, dist, parallel, steps, warmup
 
     elapsed, _ = timed_loop(step, steps, warmup, dist, parallel, device)
     out = {"value": steps * batch * world / elapsed, "ms_per_step": 1e3 * elapsed / steps, "batch": batch, "scales": scales}
+    # which trunk ran (a silent fall-back to NCHW / to the unfused 1x1 convolutions would just look slow)
+    from irn_amd.net import resnet50 as _r50
+    with torch.no_grad():
+        probe = torch.empty(2 * batch, 3, H, W, device=device)
+        cl = _r50.channels_last_for(probe)
+    out["trunk"] = {"layout": "channels_last" if cl else "nchw", "fused_1x1_gemm": bool(cl and _r50.FUSED_GEMM and _r50.FUSED_EPILOGUE),
+                    "deterministic": bool(torch.backends.cudnn.deterministic), "tuned_nhwc_shapes": len(_r50.tuned_nhwc_shapes()),
+                    "miopen_db": os.environ.get("MIOPEN_USER_DB_PATH"), "miopen_key": _common.miopen_cache_key()}
     if walker is not None:
         walker.check()                  # raises when a persistent launch gave up (nothing here calls sync(), so nothing re-ran)
         out["walk_fallback_runs"] = walker.fallback_runs
@@ -761,7 +769,7 @@ def main(argv=None):
             res["config"].update({"variant": a.variant, "mean_channels": float(np.mean([s[2] for s in r["shapes"]])),
                                   "walk_self_checks": r.get("tuning")})
             res["label_checksum"] = r["label_checksum"]
-        for k in ("detections_per_image", "fallback_runs", "rounds", "walk_fallback_runs", "cam_trunk_passes", "cam_store_hits", "cam_store_misses", "edge_store_hits", "loader_workers", "pass_seconds", "instance_files", "through"):
+        for k in ("detections_per_image", "fallback_runs", "rounds", "walk_fallback_runs", "trunk", "cam_trunk_passes", "cam_store_hits", "cam_store_misses", "edge_store_hits", "loader_workers", "pass_seconds", "instance_files", "through"):
             if k in r:
                 res["config"][k] = r[k]
         res["cpu_baseline"] = None
@@ -785,7 +793,7 @@ def main(argv=None):
                     if "shapes" in lr:
                         ro = roofline_object(a, name, lr)
                         legs[name]["fp32_vector_frac"] = ro["frac"] if ro.get("bound") == "fp32_vector" else ro["fp32_vector"]["frac"]
-                    for k in ("detections_per_image", "fallback_runs", "rounds", "grid_pixels", "walk_fallback_runs", "cam_trunk_passes", "cam_store_hits", "cam_store_misses", "edge_store_hits", "loader_workers", "pass_seconds", "instance_files", "setup_seconds", "through", "n_applied"):
+                    for k in ("detections_per_image", "fallback_runs", "rounds", "grid_pixels", "walk_fallback_runs", "trunk", "cam_trunk_passes", "cam_store_hits", "cam_store_misses", "edge_store_hits", "loader_workers", "pass_seconds", "instance_files", "setup_seconds", "through", "n_applied"):
                         if k in lr:
                             legs[name][k] = lr[k]
                 except Exception as e:                      # a leg must never cost the headline line

@@ -55,6 +55,10 @@ def tuned_nhwc_shapes():
             path = os.path.join(_common.miopen_seed_root(), _common.miopen_cache_key(), "nhwc_shapes.json")
             if os.path.exists(path) and os.environ.get("IRN_MIOPEN_SEED", "1") != "0":
                 shapes = {tuple(int(v) for v in s) for s in json.load(open(path))}
+            elif torch.cuda.is_available() and CHANNELS_LAST_MODE == "auto":
+                import sys
+                print("irn_amd: no tuned MIOpen database for %s under %s: the trunk runs NCHW without the fused 1x1 GEMMs (~0.8x); "
+                      "tools/miopen_warmup.py --channels-last 1 writes one" % (_common.miopen_cache_key(), _common.miopen_seed_root()), file=sys.stderr)
         except Exception:
             shapes = set()
         _TUNED_SHAPES = shapes

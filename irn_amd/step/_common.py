@@ -100,10 +100,14 @@ def worker_device(process_id, args=None):
 
 
 def miopen_cache_key():
-    """(device name, HIP version) as a directory name: MIOpen's find results are only valid for the chip and library
-    build that measured them."""
+    """(architecture, compute units, HIP version) as a directory name: MIOpen's find results and the GEMM rank table are only
+    valid for the chip and library build that measured them.  From the device PROPERTIES (`gcnArchName`, e.g. gfx950), not from
+    the marketing name: `torch.cuda.get_device_name` is "AMD Radeon Graphics" on boxes without amdgpu.ids and EMPTY under
+    rocprofv3 — a profiled run then found no shipped database and silently ran the NCHW trunk (round 5, session 6)."""
     try:
-        name = torch.cuda.get_device_name(0).replace(" ", "_").replace("/", "_")
+        props = torch.cuda.get_device_properties(0)
+        arch = str(getattr(props, "gcnArchName", "") or "unknown").split(":")[0]
+        name = "%s-cu%d" % (arch, int(props.multi_processor_count))
     except Exception:
         name = "unknown_device"
     return "%s-hip%s" % (name, (torch.version.hip or "none").replace("/", "_"))

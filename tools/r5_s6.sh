@@ -1,0 +1,14 @@
+#!/bin/bash
+# round 5 session 6: kernel-class profile of the cam / e2e legs with the fused GEMMs; default-workload kernel trace + PMC traffic
+set -u
+OUT=gpurun_out/r5_s6; mkdir -p $OUT
+export TMPDIR=/tmp MIOPEN_FIND_MODE=2
+T0=$(date +%s); el() { echo "[$(( $(date +%s) - T0 )) s] $*"; }
+R=$PWD
+for wl in cam e2e; do
+  cd /tmp; timeout 400 rocprofv3 --kernel-trace --stats -d $R/$OUT/prof_$wl -o $wl -f csv -- python $R/bench.py --workload $wl --steps 5 --warmup 2 --no-legs --no-cpu-baseline > $R/$OUT/prof_$wl.log 2>&1; cd $R
+  find $OUT/prof_$wl -name "*kernel_stats*" -exec cp {} $OUT/${wl}_kernel_stats.csv \;
+  python tools/kernel_classes.py $OUT/${wl}_kernel_stats.csv 30 > $OUT/${wl}_kernel_classes.txt 2>&1; head -24 $OUT/${wl}_kernel_classes.txt
+  find $OUT -name "*_kernel_trace.csv" -delete
+done; el "backbone profiles"
+ROUND=5 bash tools/gpu_session.sh 6 prof pmc; el "walk profile + pmc"
