@@ -575,3 +575,48 @@ def test_edge_store_keys_and_cap(tmp_path):
     for i in range(5):
         small.put(("k", i), torch.zeros(1, 4, 5), torch.zeros(2, 4, 5))
     assert len(small) == 3 and small.get(("k", 0), torch.device("cpu")) is None and small.get(("k", 4), torch.device("cpu")) is not None
+
+
+def test_bottleneck_gemm_params_fold_batch_norm_into_weight_and_bias():
+    """Bottleneck.gemm_params: conv -> FrozenBatchNorm == conv with (weight * scale) + shift, shortcut shift merged into conv3's
+    bias; checked on the CPU against the module's own composed forward (reference net/resnet50.py:11-14, :34-54)."""
+    import torch
+    import torch.nn.functional as F
+    from irn_amd.net import resnet50 as r50
+    torch.manual_seed(0)
+    for project in (False, True):
+        c_in = 64 if project else 128
+        unit = r50.Bottleneck(c_in, 32, stride=1, project=project).eval()
+        for m in unit.modules():
+            if isinstance(m, r50.FrozenBatchNorm):
+                m.weight.data.uniform_(0.5, 1.5); m.bias.data.normal_(); m.running_mean.normal_(); m.running_var.uniform_(0.5, 2.0)
+        x = torch.randn(2, c_in, 8, 8)
+        with torch.no_grad():
+            want = unit(x)
+            p = unit.gemm_params()
+            y = F.relu(F.conv2d(x, p["w1"].view(32, c_in, 1, 1), p["b1"]))
+            y = unit.bn2.apply_(unit.conv2(y), relu=True)
+            sc = F.conv2d(x, p["wd"]) if project else x
+            got = F.relu(F.conv2d(y, p["w3"].view(128, 32, 1, 1), p["b3"]) + sc)
+        assert float((got - want).abs().max()) <= 1e-5
+        assert unit.gemm_params() is p                          # cached while the parameters stand
+        with torch.no_grad():
+            unit.bn3.bias.add_(1.0)
+        assert unit.gemm_params() is not p and not torch.equal(unit.gemm_params()["b3"], p["b3"])
+
+
+def test_device_key_comes_from_the_architecture_not_the_marketing_name(monkeypatch):
+    """`torch.cuda.get_device_name` is empty under rocprofv3 and generic without amdgpu.ids: the key of the shipped databases
+    (MIOpen find database, GEMM rank table) is built from gcnArchName + CU count + HIP version."""
+    import types
+    import torch
+    from irn_amd.step import _common
+    monkeypatch.setattr(torch.cuda, "get_device_properties", lambda i: types.SimpleNamespace(gcnArchName="gfx950:sramecc+:xnack-", multi_processor_count=256))
+    monkeypatch.setattr(torch.cuda, "get_device_name", lambda i=0: "")
+    key = _common.miopen_cache_key()
+    assert key.startswith("gfx950-cu256-hip") and " " not in key
+    import os
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "irn_amd", "data")
+    shipped = os.listdir(os.path.join(root, "miopen"))
+    assert any(d.startswith("gfx950-cu256-hip") for d in shipped), shipped
+    assert any(f.startswith("gfx950-cu256-hip") and f.endswith(".json") for f in os.listdir(os.path.join(root, "gemm")))
