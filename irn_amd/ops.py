@@ -381,9 +381,11 @@ def find_centroids_batch(displacements, iterations=300):
     return outs
 
 
-def cluster_centroids_batch(centroids, displacements, thres=2.5):
+def cluster_centroids_batch(centroids, displacements, thres=2.5, k_on_device=False):
     """Batched cluster_centroids: -> (list of GPU int32 [h,w] cluster maps with values 0..K_i-1, list of K_i).
-    One launch sequence for the batch and ONE device-to-host transfer for all the K (irn_cluster_centroids_batch)."""
+    One launch sequence for the batch and ONE device-to-host transfer for all the K (irn_cluster_centroids_batch).
+    `k_on_device`: return the K as the GPU int32 [n] tensor instead — nothing waits for the device, the caller reads them
+    (`.cpu()`) when it needs them (the instance step enqueues a batch's front end and goes on loading the next batch)."""
     n = len(centroids)
     dps = [d.contiguous().float() for d in displacements]
     cens = []
@@ -400,6 +402,8 @@ def cluster_centroids_batch(centroids, displacements, thres=2.5):
                                               ptr_array([d.data_ptr() for d in dps]), hs, ws, float(thres),
                                               ptr_array([m.data_ptr() for m in cmaps]), k_dev.data_ptr(),
                                               scratch.data_ptr(), _stream()))
+    if k_on_device:
+        return cmaps, k_dev
     return cmaps, [int(k) for k in k_dev.cpu().tolist()]
 
 

@@ -466,7 +466,7 @@ def device_preprocess(args):
 _UPLOADS = []            # (event, page-locked staging buffer) of uploads still in flight
 
 
-def upload(t):
+def upload(t, staging=None):
     """Host tensor -> device tensor WITHOUT stalling the host.  `t.cuda()` of pageable memory returns only when the stream has
     drained — in a step's loop that is "when the previous batch's trunk passes have finished", so the host could never
     enqueue the next batch under them and the GPU idled 10 % of make_cam (7.5 ms of host time per image inside `.cuda()`,
@@ -480,8 +480,10 @@ def upload(t):
         PINNED.give(_UPLOADS.pop(0)[1])
     if nbytes == 0:
         return src.cuda()
-    staging = PINNED.take(nbytes)
-    staging[:nbytes].copy_(src.view(-1).view(torch.uint8) if src.dtype != torch.uint8 else src.view(-1))
+    if staging is None:
+        staging = PINNED.take(nbytes)
+        staging[:nbytes].copy_(src.view(-1).view(torch.uint8) if src.dtype != torch.uint8 else src.view(-1))
+    # (else: `t` already lives in the page-locked buffer `staging` — a loader thread put it there, make_loader)
     cs = ops._copy_stream(dev)
     with torch.cuda.stream(cs):
         out = staging[:nbytes].to(dev, non_blocking=True)
@@ -498,10 +500,12 @@ def device_images(pack, scales, normal=None):
     """Loader item -> list over scales of GPU fp32 [2,3,Hs,Ws] (image + horizontal flip).  Raw uint8 items
     (dataset raw=True) go through irn_msf_pack; items already in the reference's format are copied as is."""
     img = pack["img"]
+    if torch.is_tensor(img) and img.dtype == torch.uint8 and img.numel() == 0:
+        return None                                  # the dataset skipped the pixels (VOC12ClassificationDatasetMSF skip_image)
     if torch.is_tensor(img) and img.dtype == torch.uint8:
         from .. import ops
         kw = {} if normal is None else {"mean": normal.mean, "std": normal.std}
-        return ops.msf_pack(upload(img[0]), scales, **kw)
+        return ops.msf_pack(upload(img[0], pack.pop("_staging", None)), scales, **kw)
     imgs = img if isinstance(img, (list, tuple)) else [img]
     return [upload(i[0]) for i in imgs]
 
@@ -626,6 +630,11 @@ class EdgeStore:
         self.misses += 1
         return None
 
+    def peek(self, key, device):
+        """Is the entry there (no hit / miss accounting)?  For the loader threads' `skip_image`."""
+        hit = self._items.get(key)
+        return hit is not None and hit[0].device == device
+
     def put(self, key, edge, dp):
         nbytes = (edge.numel() + dp.numel()) * 4
         old = self._items.pop(key, None)
@@ -687,6 +696,13 @@ def make_walker(args, default_radius):
     return walker
 
 
+def set_skip_image(databin, predicate):
+    """Hand the step's `skip_image` predicate to the dataset behind a shard (a `Subset` of VOC12ClassificationDatasetMSF)."""
+    ds = getattr(databin, "dataset", databin)
+    if hasattr(ds, "skip_image"):
+        ds.skip_image = predicate
+
+
 def make_loader(databin, num_workers, prefetch=4):
     """Items of `databin` in order, each collated like `DataLoader(databin, batch_size=1, shuffle=False)` collates it
     (what the reference's steps iterate over, step/make_cam.py:22).  The reference's loader workers are processes; here
@@ -703,12 +719,27 @@ def make_loader(databin, num_workers, prefetch=4):
     from collections import deque
     pool = ThreadPoolExecutor(max_workers=num_workers)
     pending = deque()
+    pin = torch.cuda.is_available()
+
+    def load(i):
+        pack = default_collate([databin[i]])
+        img = pack.get("img") if isinstance(pack, dict) else None
+        if pin and torch.is_tensor(img) and img.dtype == torch.uint8 and img.numel():
+            # the decoded image goes into page-locked memory HERE, in the loader thread: `upload` then only issues the
+            # asynchronous copy (the 0.8 MB memcpy cost the step's main thread 0.4 ms per image, round 5)
+            nbytes = img.numel()
+            buf = PINNED.take(nbytes)
+            buf[:nbytes].copy_(img.reshape(-1))
+            pack["img"] = buf[:nbytes].view(img.shape)
+            pack["_staging"] = buf
+        return pack
+
     try:
         nxt = 0
         depth = num_workers * prefetch
         while nxt < n or pending:
             while nxt < n and len(pending) < depth:
-                pending.append(pool.submit(lambda i=nxt: default_collate([databin[i]])))
+                pending.append(pool.submit(load, nxt))
                 nxt += 1
             yield pending.popleft().result()
     finally:

@@ -27,16 +27,18 @@ cluster_centroids = ops.cluster_centroids
 detect_instance = ops.detect_instance
 
 
-def instance_labels_batch(walker, items, beta, exp_times, bg_thres, deferred=False):
-    """step/make_ins_seg_labels.py:131-150 for a batch of images.  items: dicts with GPU tensors
-    `edge` [1,h,w], `dp` [2,h,w], `cam` [C,h,w], CPU/GPU `keys` [C] and `size` (H, W).  Every stage runs ONCE for the
-    whole batch — centroid refinement, clustering, random walk (a 128x128 grid is 16 tiles at radius 5: one image uses
-    1/16 of the GPU), label epilogue, detection — with three host round trips per BATCH: the instance counts K (they
-    size the walk's channels), the detection counts, and the packed detections.  Returns a list of detection dicts
-    (or the ValueError of an image without detections, in its slot); with `deferred=True` an `ops.PendingDetections`
-    whose `result()` is that list — the packed transfer then runs under whatever the caller enqueues next."""
+def instance_front(items):
+    """First half of step/make_ins_seg_labels.py:131-150 for a batch: centroid refinement and clustering, ENQUEUED only — the
+    instance counts K stay on the device.  -> what `instance_back` needs."""
     dps = [it["dp"] for it in items]
-    cmaps, ks = ops.cluster_centroids_batch(ops.find_centroids_batch(dps), dps)
+    return ops.cluster_centroids_batch(ops.find_centroids_batch(dps), dps, k_on_device=True)
+
+
+def instance_back(walker, items, front, beta, exp_times, bg_thres, deferred=False):
+    """Second half: reads the K of `instance_front` (the first host round trip of the batch), then the per-instance CAM split +
+    random walk, the label epilogue and the detections."""
+    cmaps, k_dev = front
+    ks = [int(k) for k in k_dev.cpu().tolist()]
     rws = walker([it["edge"] for it in items], [it["cam"] for it in items], beta=beta, exp_times=exp_times,
                  inst_maps=cmaps, k_inst=ks)
     ep = ops.label_epilogue(rws, [it["size"] for it in items], bg_thres, want_labels=False, want_argmax=True,
@@ -48,6 +50,17 @@ def instance_labels_batch(walker, items, beta, exp_times, bg_thres, deferred=Fal
     class_ids = [np.repeat(np.asarray(torch.as_tensor(it["keys"]).cpu()), k) for it, k in zip(items, ks)]
     return ops.detect_instance_batch(ep["rw_up"], ep["argmax"], class_ids, n_ch,
                                      [it["size"][0] * it["size"][1] * 0.01 for it in items], deferred=deferred)
+
+
+def instance_labels_batch(walker, items, beta, exp_times, bg_thres, deferred=False):
+    """step/make_ins_seg_labels.py:131-150 for a batch of images.  items: dicts with GPU tensors
+    `edge` [1,h,w], `dp` [2,h,w], `cam` [C,h,w], CPU/GPU `keys` [C] and `size` (H, W).  Every stage runs ONCE for the
+    whole batch — centroid refinement, clustering, random walk (a 128x128 grid is 16 tiles at radius 5: one image uses
+    1/16 of the GPU), label epilogue, detection — with three host round trips per BATCH: the instance counts K (they
+    size the walk's channels), the detection counts, and the packed detections.  Returns a list of detection dicts
+    (or the ValueError of an image without detections, in its slot); with `deferred=True` an `ops.PendingDetections`
+    whose `result()` is that list — the packed transfer then runs under whatever the caller enqueues next."""
+    return instance_back(walker, items, instance_front(items), beta, exp_times, bg_thres, deferred=deferred)
 
 
 def instance_labels(walker, edge, dp, cams, keys, size, beta, exp_times, bg_thres):
@@ -67,21 +80,30 @@ def _write(names, pending, args, writer):
         writer.submit(np.save, os.path.join(args.ins_seg_out_dir, name + ".npy"), det)
 
 
-def _flush(model, walker, pend, args, writer, in_flight):
-    """Enqueue the batch in `pend`, then collect and write the batch before it (`in_flight`, a one-element list): its
-    detections crossed PCIe while this batch's kernels were being enqueued and run."""
+def _flush(model, walker, pend, args, writer, state):
+    """One turn of the step's three-stage pipeline; `state` = {"front": batch whose IRNet forward + clustering are enqueued,
+    "emit": batch whose detections are crossing PCIe}.  In this order:
+      1. the batch in `front` gets its back half (the K read-back, by now long computed; walk, epilogue, detections) —
+         BEFORE anything of the new batch is enqueued, so that its two small read-backs never queue behind 45 ms of IRNet;
+      2. the batch in `pend` gets its IRNet forward, centroid refinement and clustering enqueued — the GPU works on them while
+         the caller's loop decodes and uploads the next batch (round 5: the K read-back used to stall that loop for the whole
+         forward, 40 % of the step);
+      3. the batch in `emit` is collected and handed to the writer threads."""
+    done = None
+    if state.get("front") is not None:
+        items, front = state["front"]
+        done = ([it["name"] for it in items],
+                instance_back(walker, items, front, float(args.beta), int(args.exp_times), float(args.ins_seg_bg_thres), deferred=True))
+        state["front"] = None
     if pend:
         make_sem_seg_labels.edges_for(model, pend, int(getattr(args, "irn_batch", 0) or 8),
                                       **make_sem_seg_labels._edge_store_kw(model, args))
-        cur = ([it["name"] for it in pend],
-               instance_labels_batch(walker, pend, float(args.beta), int(args.exp_times), float(args.ins_seg_bg_thres),
-                                     deferred=True))
+        items = list(pend)
         pend.clear()
-    else:
-        cur = None
-    if in_flight[0] is not None:
-        _write(*in_flight[0], args, writer)
-    in_flight[0] = cur
+        state["front"] = (items, instance_front(items))
+    if state.get("emit") is not None:
+        _write(*state["emit"], args, writer)
+    state["emit"] = done
 
 
 def _work(process_id, model, dataset, args):
@@ -91,6 +113,8 @@ def _work(process_id, model, dataset, args):
         make_sem_seg_labels.remember_model(model, spec_key)
     databin = dataset[process_id]
     n_gpus = len(dataset)
+    _common.set_skip_image(databin, make_sem_seg_labels.skip_image_predicate(
+        model, args, torch.device("cuda", _common.worker_device(process_id, args))))
     loader = _common.make_loader(databin, int(args.num_workers) // n_gpus)
     batch = int(getattr(args, "walk_batch", 0) or 32)   # images per walk launch (results per image unchanged)
     writer = _common.AsyncWriter(threads=_common.writer_threads(args, n_gpus))
@@ -100,7 +124,7 @@ def _work(process_id, model, dataset, args):
             model.cuda()
             dev = torch.device("cuda", dev_id)
             walker = _common.make_walker(args, RADIUS)
-            pend, in_flight = [], [None]
+            pend, state = [], {}
             cam_run, use_store = _common.current_cam_run(args.cam_out_dir), _common.keep_cams(args)
             for it, pack in enumerate(loader):
                 name = pack["name"][0]
@@ -108,13 +132,15 @@ def _work(process_id, model, dataset, args):
                     name = voc12_dataloader.decode_int_filename(name)
                 size = (int(pack["size"][0]), int(pack["size"][1]))
                 keys, _keys_dev, cam = _common.CAM_STORE.get(name, args.cam_out_dir, dev, cam_run, use_store)
-                pend.append({"name": name, "size": size, "img": _common.device_images(pack, (1.0,))[0],
+                imgs = _common.device_images(pack, (1.0,))
+                pend.append({"name": name, "size": size, "img": None if imgs is None else imgs[0], "dev": dev,
                              "cam": cam, "keys": keys, "stamp": _common.image_stamp(args.voc12_root, name)})
                 if len(pend) == batch:
-                    _flush(model, walker, pend, args, writer, in_flight)
+                    _flush(model, walker, pend, args, writer, state)
                 _common.progress(process_id, n_gpus, it, len(databin))
-            _flush(model, walker, pend, args, writer, in_flight)      # the last batch ...
-            _flush(model, walker, pend, args, writer, in_flight)      # ... and its collection
+            _flush(model, walker, pend, args, writer, state)      # the last batch's front half ...
+            _flush(model, walker, pend, args, writer, state)      # ... its back half ...
+            _flush(model, walker, pend, args, writer, state)      # ... and its collection
             _common.WALK_STATS["fallback_runs"] += walker.fallback_runs
             walker.close()
     finally:

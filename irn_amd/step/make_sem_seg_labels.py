@@ -38,13 +38,20 @@ def edges_for(model, pend, irn_batch, store=None, model_key=None, dump_dir=None)
         todo = []
         for p in pend:
             key = (model_key, getattr(model, "crop_size", None), getattr(model, "stride", None), p.get("stamp"))
-            hit = store.get(key, p["img"].device) if p.get("stamp") is not None else None
+            dev = p["dev"] if "dev" in p else p["img"].device
+            hit = store.get(key, dev) if p.get("stamp") is not None else None
             if hit is not None:
                 p["edge"], p["dp"] = hit
-                p.pop("img")
+                p.pop("img", None)
             else:
                 p["_edge_key"] = key if p.get("stamp") is not None else None
                 todo.append(p)
+    for p in todo:
+        if p.get("img") is None:
+            # the loader skipped this image's pixels because the store held its maps then, and they are gone now (evicted
+            # between the loader's look and this one): decode it here
+            img = torch.from_numpy(np.array(Image.open(p["stamp"][0]).convert("RGB")))
+            p["img"] = _common.device_images({"img": img[None]}, (1.0,))[0]
     for i in range(0, len(todo), irn_batch):
         chunk = todo[i:i + irn_batch]
         for p, (edge, dp) in zip(chunk, model.forward_batch([p.pop("img") for p in chunk])):
@@ -59,6 +66,17 @@ def edges_for(model, pend, irn_batch, store=None, model_key=None, dump_dir=None)
         os.makedirs(dump_dir, exist_ok=True)
         for p in pend:
             np.save(os.path.join(dump_dir, p["name"] + ".npy"), {"edge": p["edge"].cpu().numpy(), "dp": p["dp"].cpu().numpy()})
+
+
+def skip_image_predicate(model, args, device):
+    """`skip_image` for the step's dataset: True for images whose boundary / displacement maps the other label step left on
+    this device (the EdgeStore entry `edges_for` will hit) — their JPEG need not be decoded or uploaded."""
+    kw = _edge_store_kw(model, args)
+    store = kw.get("store")
+    if store is None:
+        return None
+    mk, crop, stride = kw["model_key"], getattr(model, "crop_size", None), getattr(model, "stride", None)
+    return lambda name: store.peek((mk, crop, stride, _common.image_stamp(args.voc12_root, name)), device)
 
 
 _MODEL_KEYS = {}          # id(network) -> (weak reference to it, key of the ModelSpec it was built from); set in _work
@@ -153,6 +171,7 @@ def _work(process_id, model, dataset, args):
         remember_model(model, spec_key)
     databin = dataset[process_id]
     n_gpus = len(dataset)
+    _common.set_skip_image(databin, skip_image_predicate(model, args, torch.device("cuda", _common.worker_device(process_id, args))))
     loader = _common.make_loader(databin, int(args.num_workers) // n_gpus)
     batch = int(getattr(args, "walk_batch", 0) or 64)   # 64 VOC-size images = 3-4 rounds of the resident walk
     writer = _common.AsyncWriter(threads=_common.writer_threads(args, n_gpus))
@@ -173,7 +192,8 @@ def _work(process_id, model, dataset, args):
                 size = (int(pack["size"][0]), int(pack["size"][1]))
                 # CAM of this image: still on the device when make_cam ran in this process, else from its file
                 _keys, keys_dev, cam = _common.CAM_STORE.get(name, args.cam_out_dir, dev, cam_run, use_store)
-                pend.append({"name": name, "size": size, "img": _common.device_images(pack, (1.0,))[0],
+                imgs = _common.device_images(pack, (1.0,))
+                pend.append({"name": name, "size": size, "img": None if imgs is None else imgs[0], "dev": dev,
                              "cam": cam, "keys_dev": keys_dev, "stamp": _common.image_stamp(args.voc12_root, name)})
                 if len(pend) == batch:
                     _collect(walker, running, args, writer)

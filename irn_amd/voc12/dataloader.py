@@ -63,12 +63,16 @@ class VOC12ClassificationDatasetMSF(Dataset):
     loader workers of the bicubic resizes."""
 
     def __init__(self, img_name_list_path, voc12_root, img_normal=TorchvisionNormalize(), scales=(1.0,),
-                 cls_labels=None, raw=False):
+                 cls_labels=None, raw=False, skip_image=None):
         self.img_name_list = load_img_name_list(img_name_list_path)
         self.voc12_root = voc12_root
         self.img_normal = img_normal
         self.scales = scales
         self.raw = raw
+        # raw mode only: `skip_image(name) -> bool` lets a step say that it will not need an image's pixels (the label step that
+        # runs second takes the boundary / displacement maps from device memory): the item then carries an EMPTY uint8 tensor
+        # and the size read from the file header — no JPEG decode, no upload
+        self.skip_image = skip_image
         if cls_labels is None:
             path = os.path.join(os.path.dirname(os.path.abspath(img_name_list_path)), "cls_labels.npy")
             cls_labels = np.load(path, allow_pickle=True).item()
@@ -79,6 +83,11 @@ class VOC12ClassificationDatasetMSF(Dataset):
 
     def __getitem__(self, idx):
         name_str = decode_int_filename(self.img_name_list[idx])
+        if self.raw and self.skip_image is not None and self.skip_image(name_str):
+            with Image.open(get_img_path(name_str, self.voc12_root)) as im:
+                w, h = im.size                       # header only
+            return {"name": name_str, "img": torch.empty((0, 0, 3), dtype=torch.uint8), "size": (h, w),
+                    "label": torch.from_numpy(self.label_list[idx])}
         img = np.asarray(Image.open(get_img_path(name_str, self.voc12_root)).convert("RGB"))
         if self.raw:
             return {"name": name_str, "img": torch.from_numpy(np.array(img)),

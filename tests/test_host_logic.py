@@ -620,3 +620,34 @@ def test_device_key_comes_from_the_architecture_not_the_marketing_name(monkeypat
     shipped = os.listdir(os.path.join(root, "miopen"))
     assert any(d.startswith("gfx950-cu256-hip") for d in shipped), shipped
     assert any(f.startswith("gfx950-cu256-hip") and f.endswith(".json") for f in os.listdir(os.path.join(root, "gemm")))
+
+
+def test_dataset_skips_the_pixels_when_the_step_says_so(tmp_path):
+    """VOC12ClassificationDatasetMSF(raw=True, skip_image=...): an image the step will not need (its edge maps are on the device)
+    comes as an empty uint8 tensor with the size from the file header; `device_images` maps it to None; `EdgeStore.peek` does not
+    count.  (The reference decodes every image in both label steps, step/make_sem_seg_labels.py:24-34.)"""
+    import numpy as np
+    import torch
+    from PIL import Image
+    from torch.utils.data import default_collate
+    from irn_amd.step import _common
+    from irn_amd.voc12 import dataloader
+    root = tmp_path / "voc" / "JPEGImages"
+    root.mkdir(parents=True)
+    for name, (h, w) in (("2008_000001", (30, 44)), ("2008_000002", (37, 21))):
+        Image.fromarray((np.random.RandomState(0).rand(h, w, 3) * 255).astype(np.uint8)).save(root / (name + ".jpg"))
+    (tmp_path / "train.txt").write_text("2008_000001\n2008_000002\n")
+    np.save(tmp_path / "cls_labels.npy", {2008000001: np.eye(20, dtype=np.float32)[3], 2008000002: np.eye(20, dtype=np.float32)[5]})
+    ds = dataloader.VOC12ClassificationDatasetMSF(str(tmp_path / "train.txt"), voc12_root=str(tmp_path / "voc"), raw=True,
+                                                  skip_image=lambda name: name.endswith("2"))
+    a, b = default_collate([ds[0]]), default_collate([ds[1]])
+    assert a["img"].shape == (1, 30, 44, 3) and b["img"].numel() == 0
+    assert (int(b["size"][0]), int(b["size"][1])) == (37, 21) and b["name"][0] == "2008_000002"
+    assert _common.device_images(b, (1.0,)) is None
+    _common.set_skip_image(torch.utils.data.Subset(ds, [0, 1]), None)
+    assert ds.skip_image is None and ds[1]["img"].shape == (37, 21, 3)
+    store = _common.EdgeStore()
+    store.put("k", torch.zeros(1, 2, 2), torch.zeros(2, 2, 2))
+    h0, m0 = store.hits, store.misses
+    assert store.peek("k", torch.device("cpu")) and not store.peek("other", torch.device("cpu"))
+    assert (store.hits, store.misses) == (h0, m0)
