@@ -153,7 +153,7 @@ int irn_walk_fallback_runs(irn_walk_ctx *ctx);
 
 /* Start-up self-checks of the weights-stationary walk's two measured assumptions (speed only, never results; the
  * reference has no counterpart — its walk is dense sgemm, misc/indexing.py:132-139):
- *   placement   0 not checked yet, 1 "block b of a launch runs on XCD b % 8" holds on this device (the tiles of an image are
+ *   placement   0 not checked yet, 1 "blocks with equal b % 8 share an XCD, the eight residues eight XCDs" holds on this device (the tiles of an image are
  *               then packed onto one XCD), 2 it does not (tiles keep launch order; one line on stderr says so);
  *   poll_delay  the delay (units of 64 clocks) between a single-channel tile's stores and its first poll in use now;
  *   probe_ms4   launch times in ms the start-up probe measured for delays 8, 10, 12, 14 on this context's first representative

@@ -658,8 +658,8 @@ void resident_destroy(irn_walk_ctx *ctx) {
 }
 
 // The slot -> block mapping below puts the tiles of an image on consecutive slots of ONE XCD under the assumption that
-// block b of a launch runs on XCD b % 8.  HIP promises nothing of the kind (it is what this driver does on an idle
-// MI355X), so the assumption is CHECKED once per device and process: a 64-thread probe launch of the same grid size
+// blocks b, b + 8, b + 16 ... of a launch run on one XCD (round-robin dispatch).  HIP promises nothing of the kind (it is
+// what this driver does on an idle MI355X), so the assumption is CHECKED once per device and process: a 64-thread probe launch of the same grid size
 // reads HW_REG_XCC_ID per block.  When it does not hold the mapping falls back to slot = block (still correct: the
 // exchange is placement-independent, only the share of same-XCD hand-offs changes) and a line on stderr says so.
 // g_placement[dev]: 0 = not checked, 1 = round robin holds, 2 = it does not.
@@ -684,14 +684,23 @@ int resident_check_placement(irn_walk_ctx *ctx) {
             hipLaunchKernelGGL(xcc_probe_kernel, dim3(n_wg), dim3(64), 0, nullptr, d);
             IRN_LAUNCH_CHECK("xcc_probe_kernel");
             IRN_HIP_TRY(hipMemcpy(hst.data(), d, (size_t)n_wg, hipMemcpyDeviceToHost));
+            // what the slot mapping needs: blocks with equal b % 8 share an XCD and the eight residues sit on eight different
+            // XCDs.  The dispatcher round-robins on from wherever the previous launch stopped, so block 0 may land on any XCD
+            // (round 5: "first blocks on XCDs 7 0 1 2 3 4 5 6" on boxes whose earlier launches were not multiples of 8 blocks
+            // — round 4's check for XCD == b % 8 exactly then switched the packing off for nothing)
             bool ok = n_wg % 8 == 0;
-            for (int b = 0; ok && b < n_wg; ++b) ok = hst[(size_t)b] == (unsigned char)(b % 8);
+            unsigned seen = 0;
+            for (int r = 0; ok && r < 8; ++r) {
+                ok = hst[(size_t)r] < 8 && !(seen & (1u << hst[(size_t)r]));
+                seen |= 1u << (hst[(size_t)r] & 7);
+            }
+            for (int b = 8; ok && b < n_wg; ++b) ok = hst[(size_t)b] == hst[(size_t)(b % 8)];
             votes_ok += ok ? 1 : 0;
         }
         (void)hipFree(d);
         g_placement[dev] = votes_ok == 2 ? 1 : 2;
         if (g_placement[dev] == 2)
-            fprintf(stderr, "irn_hip: device %d: block b -> XCD b %% 8 does not hold here (first blocks on XCDs %d %d %d %d %d %d %d %d); "
+            fprintf(stderr, "irn_hip: device %d: blocks with equal b %% 8 do not share an XCD here (first blocks on XCDs %d %d %d %d %d %d %d %d); "
                             "tiles keep their launch order (speed only)\n", dev, hst[0], hst[1], hst[2], hst[3], hst[4], hst[5], hst[6], hst[7]);
     }
     ctx->res_placement = g_placement[dev];
