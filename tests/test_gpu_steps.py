@@ -418,7 +418,7 @@ def test_bench_contract_one_json_line():
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "2", "--warmup", "1", "--batch", "8",
-                          "--cpu-images", "2", "--ref-grids", "64", "--legs", "coco,ins,walk_plain"], capture_output=True, text=True,
+                          "--cpu-images", "2", "--ref-grids", "64", "--legs", "coco,ins,walk_plain,walk_voc,cam"], capture_output=True, text=True,
                          timeout=900, cwd=root)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
@@ -450,6 +450,16 @@ def test_bench_contract_one_json_line():
     for leg in ("coco", "ins", "walk_plain"):
         assert r["legs"][leg].get("value", 0) > 0, r["legs"][leg]
     assert r["legs"]["walk_plain"]["n_applied"] == 256 and r["legs"]["walk_plain"]["value"] < r["value"]
+    # round 5 hygiene: no image twice in the timed batch, the traffic figure says where it comes from, the CPU is named, the
+    # ragged leg reports how the persistent launch packed it and that nothing fell back, the backbone leg says which trunk ran
+    assert r["config"]["images_per_gpu_per_step"] == 8
+    assert rf["traffic_source"] in (None, "static") and (rf["traffic"] is None) == (rf["traffic_source"] is None)
+    assert isinstance(cb["cpu_model"], str) and cb["cpu_model"]
+    wv = r["legs"]["walk_voc"]
+    assert wv["value"] > 0 and wv["rounds"] > 0 and wv["fallback_runs"] == 0 and wv["grid_pixels"] > 0
+    trunk = r["legs"]["cam"]["trunk"]
+    assert trunk["layout"] in ("channels_last", "nchw") and trunk["fused_1x1_gemm"] == (trunk["layout"] == "channels_last")
+    assert trunk["deterministic"] is False and r["legs"]["cam"]["value"] > 0
 
 
 def test_upload_never_blocks_and_equals_cuda():
