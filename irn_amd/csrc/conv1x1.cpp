@@ -37,6 +37,16 @@ using Key = std::tuple<int, int64_t, int, int, int, int, int, size_t>;
 std::mutex g_mu;
 std::map<int, hipblasLtHandle_t> g_handles;
 std::map<Key, Plan *> g_plans;
+// VOC has hundreds of image sizes, each with its own m per stage and scale: the cache is emptied when it reaches this many
+// plans (a plan is four small descriptors and 16 heuristic records; rebuilding one costs a heuristic query, ~1 ms)
+constexpr size_t kMaxPlans = 8192;
+
+void destroy_plan(Plan *p) {
+    if (p->desc) (void)hipblasLtMatmulDescDestroy(p->desc);
+    for (hipblasLtMatrixLayout_t l : {p->a, p->b, p->c, p->d})
+        if (l) (void)hipblasLtMatrixLayoutDestroy(l);
+    delete p;
+}
 
 #define IRN_LT_TRY(expr)                                                                                         \
     do {                                                                                                         \
@@ -70,6 +80,10 @@ int get_plan(hipblasLtHandle_t handle, int dev, int64_t m, int cin, int cout, bo
         *out = it->second;
         return IRN_OK;
     }
+    if (g_plans.size() >= kMaxPlans) {        // nothing is in flight with a plan: the caller holds g_mu for the whole enqueue
+        for (auto &kv : g_plans) destroy_plan(kv.second);
+        g_plans.clear();
+    }
     Plan *p = new Plan();
     IRN_LT_TRY(hipblasLtMatmulDescCreate(&p->desc, HIPBLAS_COMPUTE_32F, HIP_R_32F));
     const int32_t op_t = HIPBLAS_OP_T, op_n = HIPBLAS_OP_N;
@@ -94,7 +108,7 @@ int get_plan(hipblasLtHandle_t handle, int dev, int64_t m, int cin, int cout, bo
     hipblasStatus_t st = hipblasLtMatmulAlgoGetHeuristic(handle, p->desc, p->a, p->b, p->c, p->d, pref, kMaxAlgos, p->algo, &found);
     (void)hipblasLtMatmulPreferenceDestroy(pref);
     if (st != HIPBLAS_STATUS_SUCCESS || found < 1) {
-        delete p;
+        destroy_plan(p);
         return fail(IRN_ERR_STATE, "hipBLASLt has no fp32 kernel for the 1x1 convolution m=%lld cin=%d cout=%d (status %d, %d found)",
                     (long long)m, cin, cout, (int)st, found);
     }

@@ -276,6 +276,8 @@ class RandomWalk:
     ``k_inst[i]`` instances) channel cls*K+k starts from cam[cls]*(inst==k)
     (reference step/make_ins_seg_labels.py:77-80,:133) and ``outs[i]`` is [C*K,1,h,w]."""
 
+    _warned_fallback = False
+
     def __init__(self, radius=5, device=None):
         self.radius = int(radius)
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
@@ -331,6 +333,12 @@ class RandomWalk:
         with torch.cuda.device(self.device):
             check(lib.irn_walk_sync(self._ctx, C.byref(fell)))
         self._live = None
+        if fell.value and not RandomWalk._warned_fallback:
+            RandomWalk._warned_fallback = True
+            import warnings
+            warnings.warn("irn_amd: a weights-stationary walk launch gave up waiting for a neighbouring tile (the grid was not co-resident "
+                          "in time: another tenant on the GPU, or two workers sharing a device) and the batch was re-run on the streaming "
+                          "sweeps, ~11x slower; results are unaffected.  `fallback_runs` counts these (this warning is shown once).")
         return bool(fell.value)
 
     def steps(self, n_sweeps):

@@ -158,6 +158,15 @@ def deterministic_backbones():
     return os.environ.get("IRN_DETERMINISTIC", "0") == "1"
 
 
+def apply_deterministic_setting():
+    """IRN_DETERMINISTIC=1 / =0 set PyTorch's process-wide `torch.backends.cudnn.deterministic`; when the variable is not set the
+    flag is left as the caller has it (a user who switched it on themselves gets the reproducible NCHW trunk too:
+    net/resnet50.channels_last_for reads the flag, not the variable)."""
+    v = os.environ.get("IRN_DETERMINISTIC")
+    if v in ("0", "1"):
+        torch.backends.cudnn.deterministic = v == "1"
+
+
 def miopen_setup(device_ordinal):
     """MIOpen's settings for the process that is about to run the backbones on `device_ordinal` — the SAME for a pool
     worker and for the in-process single-GPU path, so that one-GPU and N-GPU runs pick their convolution solvers the
@@ -178,7 +187,7 @@ def miopen_setup(device_ordinal):
     import fcntl
     import shutil
     os.environ.setdefault("MIOPEN_FIND_MODE", "2")
-    torch.backends.cudnn.deterministic = deterministic_backbones()
+    apply_deterministic_setting()
     marker = os.environ.get("IRN_MIOPEN_DB_SET")
     if marker and os.environ.get("MIOPEN_USER_DB_PATH") == marker and os.environ.get("IRN_MIOPEN_DB_DEV", str(int(device_ordinal))) == str(int(device_ordinal)):
         return marker                                    # this process (or the parent it inherited from, if it holds no lock itself) did it, for this device
