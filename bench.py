@@ -465,8 +465,8 @@ def run_backbone(a, workload, rank, world, device, dist, parallel, steps, warmup
         probe = torch.empty(2 * batch, 3, H, W, device=device)
         cl = _r50.channels_last_for(probe)
     out["trunk"] = {"layout": "channels_last" if cl else "nchw", "fused_1x1_gemm": bool(cl and _r50.FUSED_GEMM and _r50.FUSED_EPILOGUE),
-                    "deterministic": bool(torch.backends.cudnn.deterministic), "tuned_nhwc_shapes": len(_r50.tuned_nhwc_shapes()),
-                    "miopen_db": os.environ.get("MIOPEN_USER_DB_PATH"), "miopen_key": _common.miopen_cache_key()}
+                    "deterministic": bool(_r50.DETERMINISTIC), "tuned_nhwc_shapes": len(_r50.tuned_nhwc_shapes()),
+                    "miopen_db": os.environ.get("MIOPEN_USER_DB_PATH"), "miopen_key": _common.miopen_mode_key()}
     if walker is not None:
         walker.check()                  # raises when a persistent launch gave up (nothing here calls sync(), so nothing re-ran)
         out["walk_fallback_runs"] = walker.fallback_runs

@@ -40,46 +40,62 @@ FUSED_EPILOGUE = os.environ.get("IRN_FUSED_EPILOGUE", "1") != "0"
 # NCHW (the IRNet heads, the CAM merge) converts it back.  Convolution weights stay as they are: PyTorch hands MIOpen a
 # re-laid-out copy per call (94 MB per forward, < 1 % of it).
 CHANNELS_LAST_MODE = os.environ.get("IRN_CHANNELS_LAST", "auto")
-_TUNED_SHAPES = None
+_TUNED_SHAPES = {}
+# The reproducible mode (step/_common.deterministic_backbones; set by `apply_deterministic_setting` in every process that sets
+# MIOpen up): None = not managed here (a caller's own torch.backends.cudnn.deterministic is respected), True / False = managed.
+DETERMINISTIC = None
 
 
 def tuned_nhwc_shapes():
-    """Network-input shapes (n, H, W) the shipped find database holds tuned NHWC solvers for (empty without a GPU or a
-    database for this device / HIP version)."""
-    global _TUNED_SHAPES
-    if _TUNED_SHAPES is None:
+    """Network-input shapes (n, H, W) the shipped find database OF THIS PROCESS'S MODE holds tuned NHWC solvers for (empty
+    without a GPU or a database for this device / HIP version)."""
+    try:
+        from ..step import _common
+        key = _common.miopen_mode_key()
+    except Exception:
+        return set()
+    if key not in _TUNED_SHAPES:
         shapes = set()
         try:
             import json
-            from ..step import _common
-            path = os.path.join(_common.miopen_seed_root(), _common.miopen_cache_key(), "nhwc_shapes.json")
+            path = os.path.join(_common.miopen_seed_root(), key, "nhwc_shapes.json")
             if os.path.exists(path) and os.environ.get("IRN_MIOPEN_SEED", "1") != "0":
                 shapes = {tuple(int(v) for v in s) for s in json.load(open(path))}
             elif torch.cuda.is_available() and CHANNELS_LAST_MODE == "auto":
                 import sys
                 print("irn_amd: no tuned MIOpen database for %s under %s: the trunk runs NCHW without the fused 1x1 GEMMs (~0.8x); "
-                      "tools/miopen_warmup.py --channels-last 1 writes one" % (_common.miopen_cache_key(), _common.miopen_seed_root()), file=sys.stderr)
+                      "tools/miopen_warmup.py --channels-last 1 (+ tools/miopen_det_filter.py) writes one" % (key, _common.miopen_seed_root()), file=sys.stderr)
         except Exception:
             shapes = set()
-        _TUNED_SHAPES = shapes
-    return _TUNED_SHAPES
+        _TUNED_SHAPES[key] = shapes
+    return _TUNED_SHAPES[key]
 
 
 def channels_last_for(x):
-    """Does the trunk run channels-last for the network input `x` [n, 3, H, W]?  (inference path only)"""
+    """Does the trunk run channels-last for the network input `x` [n, 3, H, W]?  (inference path only.)  Called once at the
+    start of every trunk pass; in the reproducible mode it also sets MIOpen's deterministic attribute for the pass: off for a
+    channels-last pass (its database has no order-dependent solver left), on otherwise — `end_trunk_pass` puts it back on."""
     if CHANNELS_LAST_MODE == "0" or not x.is_cuda or x.dim() != 4 or torch.is_grad_enabled():
+        if DETERMINISTIC and x.is_cuda:
+            torch.backends.cudnn.deterministic = True
         return False
-    if torch.backends.cudnn.deterministic:
-        # MIOpen's deterministic attribute (IRN_DETERMINISTIC=1, step/_common.deterministic_backbones) leaves no fast NHWC
-        # fp32 solver: the reproducible mode is the NCHW trunk
+    if DETERMINISTIC is None and torch.backends.cudnn.deterministic:
+        # a caller's own deterministic flag: MIOpen's attribute leaves no fast NHWC fp32 solver, the NCHW trunk it is
         return False
-    if CHANNELS_LAST_MODE == "1":
-        return True
     # auto: only in a process whose MIOpen user database has been completed from the shipped one (step/_common.miopen_setup:
     # the steps' workers, the in-process step path, bench.py) — anywhere else the NHWC problems would be untuned
-    if not os.environ.get("IRN_MIOPEN_DB_SET"):
-        return False
-    return (int(x.shape[0]), int(x.shape[2]), int(x.shape[3])) in tuned_nhwc_shapes()
+    cl = CHANNELS_LAST_MODE == "1" or (bool(os.environ.get("IRN_MIOPEN_DB_SET")) and
+                                       (int(x.shape[0]), int(x.shape[2]), int(x.shape[3])) in tuned_nhwc_shapes())
+    if DETERMINISTIC:
+        torch.backends.cudnn.deterministic = not cl
+    return cl
+
+
+def end_trunk_pass():
+    """Behind the last trunk stage of a pass (before heads, classifier read-out in NCHW, merges): the reproducible mode's
+    resting state — MIOpen's deterministic attribute on."""
+    if DETERMINISTIC:
+        torch.backends.cudnn.deterministic = True
 
 
 def _dense(x):
@@ -110,7 +126,8 @@ def to_stage_format(x, channels_last):
 
 
 def to_nchw(x):
-    """A stage's output for a consumer that wants NCHW (heads, hand-written kernels, the CAM merge)."""
+    """A stage's output for a consumer that wants NCHW (heads, hand-written kernels, the CAM merge); ends the trunk pass."""
+    end_trunk_pass()
     return x if x.is_contiguous() else x.contiguous()
 
 
@@ -160,7 +177,14 @@ class FrozenBatchNorm(nn.BatchNorm2d):
 def stem(conv1, bn1, maxpool, x):
     """conv1 -> bn1 -> ReLU -> maxpool (net/resnet50.py:94-97); on the inference path everything behind the convolution is
     one pass (`ops.stem_pool`) when the pool is the trunk's 3x3 / stride 2 / pad 1."""
-    y = conv1(x)
+    if DETERMINISTIC and x.is_cuda:
+        # the stem is an NCHW problem in every layout: in the reproducible mode it always runs under MIOpen's attribute
+        prev = torch.backends.cudnn.deterministic
+        torch.backends.cudnn.deterministic = True
+        y = conv1(x)
+        torch.backends.cudnn.deterministic = prev
+    else:
+        y = conv1(x)
     if _fused(y) and y.is_contiguous() and (maxpool.kernel_size, maxpool.stride, maxpool.padding, maxpool.dilation, maxpool.ceil_mode) == (3, 2, 1, 1, False):
         from .. import ops
         return ops.stem_pool(y, *bn1.folded())

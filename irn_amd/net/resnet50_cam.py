@@ -32,6 +32,7 @@ class Net(nn.Module):
 
     def forward(self, x):
         f = self.features(x)
+        _r50.end_trunk_pass()
         return self.classifier(f.mean(dim=(2, 3), keepdim=True)).flatten(1)
 
 

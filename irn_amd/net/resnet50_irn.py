@@ -99,6 +99,7 @@ class Net(nn.Module):
         f3 = self.stage3(f2).detach()
         f4 = self.stage4(f3).detach()
         f5 = self.stage5(f4).detach()
+        _r50.end_trunk_pass()               # the heads run NCHW (reproducible mode: under MIOpen's deterministic attribute)
         if cl:                              # the heads (GroupNorm, the hand-written upsampling) take NCHW
             f2, f3, f4, f5 = (_r50.to_nchw(f) for f in (f2, f3, f4, f5))
 

@@ -147,24 +147,36 @@ def miopen_seed_root():
 
 
 def deterministic_backbones():
-    """IRN_DETERMINISTIC=1 (run_sample.py --deterministic 1): the convolutions run with MIOpen's deterministic attribute
-    (`torch.backends.cudnn.deterministic`), which rules out every solver that accumulates with atomics — the backbones'
-    outputs are then a function of their inputs only, whichever process, worker layout or run computes them, and an N-GPU run
-    writes bit for bit the files of a 1-GPU run (reference step/make_cam.py:67-74: any `n_gpus` must give the same files).
-    The price, measured (profiles/r05_s3_deterministic_ab.txt): MIOpen has no fast NHWC fp32 solver it calls deterministic (the
-    tuned channels-last trunk falls to its naive kernels, 1.3 images/s), so this mode runs the trunk in NCHW without the
-    fused GEMMs: `cam` 95.4 instead of 117.8 images/s.  Default 0: the fast path, whose split-K accumulations move the CAMs by
-    ~1e-5 from run to run — far inside the 1e-4 parity bar; labels can then differ only at exact ties (tests prove each)."""
-    return os.environ.get("IRN_DETERMINISTIC", "0") == "1"
+    """IRN_DETERMINISTIC (default 1; run_sample.py --deterministic 0/1): the backbones' outputs are a function of their inputs
+    only, whichever process, worker layout or run computes them — an N-GPU run writes bit for bit the files of a 1-GPU run
+    (reference step/make_cam.py:67-74: any `n_gpus` must give the same files).  How (net/resnet50.channels_last_for):
+      * input shapes the shipped database is tuned for run the channels-last trunk (fused GEMMs) on `<key>-det`, the tuned
+        database WITHOUT the one order-dependent kind of kernel in it — MIOpen's NHWC implicit GEMM with a configuration that
+        splits K across workgroups and adds with atomics (tools/miopen_det_filter.py: 86 of 264 records fall to the
+        composable-kernel convolution); measured bit-identical across repeats and processes for every layer of CAM and IRNet
+        at 8 pairs, `cam` 114.5 against 117.4 images/s (profiles/r05_s11_deterministic_database.txt);
+      * every other convolution (untuned sizes, partial batches, the heads) runs under MIOpen's deterministic attribute
+        (`torch.backends.cudnn.deterministic`) in NCHW — the attribute alone leaves no fast NHWC fp32 solver
+        (profiles/r05_s3_deterministic_ab.txt), which is why the tuned shapes do not use it.
+    IRN_DETERMINISTIC=0: the last 2.5 %, with split-K accumulations that move the CAMs by ~1e-5 from run to run (labels then
+    differ only at exact ties; tests prove each).  The mode belongs to the PROCESS: it is fixed before the first convolution
+    (MIOpen keeps the solver it resolved for a problem, whatever the attribute says later)."""
+    return os.environ.get("IRN_DETERMINISTIC", "1") != "0"
+
+
+def miopen_mode_key():
+    """Directory name of the databases of this process's mode: `<arch>-cu<N>-hip<v>` or, reproducible mode, `…-det`."""
+    return miopen_cache_key() + ("-det" if deterministic_backbones() else "")
 
 
 def apply_deterministic_setting():
-    """IRN_DETERMINISTIC=1 / =0 set PyTorch's process-wide `torch.backends.cudnn.deterministic`; when the variable is not set the
-    flag is left as the caller has it (a user who switched it on themselves gets the reproducible NCHW trunk too:
-    net/resnet50.channels_last_for reads the flag, not the variable)."""
-    v = os.environ.get("IRN_DETERMINISTIC")
-    if v in ("0", "1"):
-        torch.backends.cudnn.deterministic = v == "1"
+    """Hand the mode to the trunk (net/resnet50.DETERMINISTIC) and put PyTorch's process-wide flag in the mode's resting
+    state: on in the reproducible mode (the trunk switches it off for the duration of a channels-last pass on the filtered
+    database), off otherwise."""
+    from ..net import resnet50 as _r50
+    det = deterministic_backbones()
+    _r50.DETERMINISTIC = det
+    torch.backends.cudnn.deterministic = det
 
 
 def miopen_setup(device_ordinal):
@@ -196,7 +208,7 @@ def miopen_setup(device_ordinal):
     base = os.environ.get("IRN_MIOPEN_BASE") or os.environ.get("IRN_MIOPEN_CACHE") or os.environ.get("MIOPEN_USER_DB_PATH") or \
         os.path.join(os.path.expanduser("~"), ".cache", "irn_amd", "miopen")
     os.environ["IRN_MIOPEN_BASE"] = base
-    key = miopen_cache_key()
+    key = miopen_mode_key()
     stable = os.path.join(base, key, "dev%d" % int(device_ordinal))
     os.makedirs(stable, exist_ok=True)
     use = stable
@@ -229,7 +241,7 @@ def reap_private_miopen_dbs(pids):
     base = os.environ.get("IRN_MIOPEN_BASE")
     if not base:
         return 0
-    root = os.path.join(base, miopen_cache_key())
+    root = os.path.join(base, miopen_mode_key())
     n = 0
     try:
         entries = os.listdir(root)

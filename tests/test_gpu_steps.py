@@ -203,11 +203,13 @@ def test_steps_two_worker_processes_on_one_device(tmp_path, monkeypatch, mode):
     start-up in the children, the CAM hand-off in EACH worker's device memory across steps (CAM-owner aware shards), two
     resident (cooperative, all-CU) walks contending for one GPU — whichever loses its bounded wait is re-run on the
     streaming sweeps — and checks every output file of the two-worker layout against the one-worker layout:
-      deterministic  (IRN_DETERMINISTIC=1: MIOpen's deterministic attribute, NCHW trunk) — the two layouts write the SAME
-                     bits: CAMs, label maps, detections.  (Both layouts run in fresh worker processes: MIOpen keeps the solvers
-                     it resolved for a problem per process, whatever the attribute says later, so a process that ran the same
-                     convolution shapes in the fast mode before — this pytest process — is not a deterministic one.)
-      fast           (the default: tuned channels-last trunk, split-K solvers) — the CAMs agree to fp32 rounding; the boundary /
+      deterministic  (IRN_DETERMINISTIC=1, the default: channels-last trunk on the database without split-K solvers for tuned
+                     shapes, MIOpen's deterministic attribute + NCHW for everything else — these small images) — the two layouts
+                     write the SAME bits: CAMs, edge / displacement maps, label maps, detections.  (Both layouts run in fresh
+                     worker processes: MIOpen keeps the solvers it resolved for a problem per process, whatever the attribute
+                     says later, so a process that ran the same convolution shapes unmanaged before — this pytest process —
+                     is not a deterministic one.)
+      fast           (IRN_DETERMINISTIC=0: tuned channels-last trunk with split-K solvers) — the CAMs agree to fp32 rounding; the boundary /
                      displacement maps move by ~1e-5 too, and the instance clustering is discontinuous in them, so the two
                      runs are not compared with each other: EACH run's labels and instance classes are checked against the
                      oracle (fp64 walk + the reference's epilogue / clustering) on that run's OWN CAM files and edge maps
@@ -459,7 +461,7 @@ def test_bench_contract_one_json_line():
     assert wv["value"] > 0 and wv["rounds"] > 0 and wv["fallback_runs"] == 0 and wv["grid_pixels"] > 0
     trunk = r["legs"]["cam"]["trunk"]
     assert trunk["layout"] in ("channels_last", "nchw") and trunk["fused_1x1_gemm"] == (trunk["layout"] == "channels_last")
-    assert trunk["deterministic"] is False and r["legs"]["cam"]["value"] > 0
+    assert trunk["deterministic"] is True and trunk["miopen_key"].endswith("-det") and r["legs"]["cam"]["value"] > 0      # the default mode
 
 
 def test_upload_never_blocks_and_equals_cuda():

@@ -465,8 +465,13 @@ def test_miopen_setup_is_stable_seeded_and_exclusive(tmp_path, monkeypatch):
         monkeypatch.delenv(k, raising=False)
     monkeypatch.setenv("IRN_MIOPEN_CACHE", str(tmp_path))
     monkeypatch.setattr(_common, "_MIOPEN_LOCKS", [])
+    monkeypatch.delenv("IRN_DETERMINISTIC", raising=False)
     d0 = _common.miopen_setup(0)
-    key = _common.miopen_cache_key()
+    key = _common.miopen_mode_key()
+    assert key == _common.miopen_cache_key() + "-det"             # the reproducible mode is the default and has its own databases
+    import torch
+    from irn_amd.net import resnet50 as r50
+    assert r50.DETERMINISTIC is True and torch.backends.cudnn.deterministic is True
     assert d0 == os.path.join(str(tmp_path), key, "dev0") and os.environ["MIOPEN_USER_DB_PATH"] == d0
     assert os.environ["MIOPEN_FIND_MODE"] == "2" and _common.miopen_setup(0) == d0
     open(os.path.join(d0, "gfx950_256.ufdb.txt"), "w").write("found")
@@ -483,6 +488,36 @@ def test_miopen_setup_is_stable_seeded_and_exclusive(tmp_path, monkeypatch):
     monkeypatch.delenv("IRN_MIOPEN_DB_SET")
     monkeypatch.setenv("MIOPEN_FIND_MODE", "1")
     assert _common.miopen_setup(3).endswith(os.path.join(key, "dev3")) and os.environ["MIOPEN_FIND_MODE"] == "1"
+    # the fast mode: its own key, PyTorch's flag off
+    monkeypatch.delenv("IRN_MIOPEN_DB_SET")
+    monkeypatch.setenv("IRN_DETERMINISTIC", "0")
+    assert _common.miopen_setup(3).endswith(os.path.join(_common.miopen_cache_key(), "dev3"))
+    assert r50.DETERMINISTIC is False and torch.backends.cudnn.deterministic is False
+    monkeypatch.setattr(r50, "DETERMINISTIC", None)
+
+
+def test_det_database_is_the_tuned_one_minus_the_split_k_implicit_gemms():
+    """irn_amd/data/miopen/<key>-det (tools/miopen_det_filter.py): same problems, same channels-last shape list; the NHWC
+    implicit-GEMM solver is gone from exactly the forward records whose tuned configuration splits K, another fast solver
+    remains in every one of them, nothing else changed."""
+    import glob
+    root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "irn_amd", "data", "miopen")
+    fast = sorted(d for d in glob.glob(os.path.join(root, "*")) if os.path.isdir(d) and not d.endswith("-det"))
+    assert fast
+    for src in fast:
+        dst = src + "-det"
+        assert os.path.isdir(dst), "run tools/miopen_det_filter.py"
+        assert open(os.path.join(src, "nhwc_shapes.json")).read() == open(os.path.join(dst, "nhwc_shapes.json")).read()
+        rec = lambda d: dict(l.rstrip("\n").split("=", 1) for l in open(glob.glob(os.path.join(d, "*.ufdb.txt"))[0]) if "=" in l)
+        a, b = rec(src), rec(dst)
+        assert a.keys() == b.keys()
+        gtc = "ConvAsmImplicitGemmGTCDynamicFwdXdlopsNHWC:"
+        changed = [k for k in a if a[k] != b[k]]
+        assert changed and all("NHWC" in k and k.endswith("-F") for k in changed)
+        for k in changed:
+            ents_a, ents_b = a[k].split(";"), b[k].split(";")
+            assert [e for e in ents_a if not e.startswith(gtc)] == ents_b
+            assert any(not e.startswith("ConvDirectNaive") for e in ents_b), k
 
 
 def test_merge_miopen_db_adds_missing_entries_only(tmp_path):
@@ -513,7 +548,10 @@ def test_trunk_layout_is_chosen_per_input_shape(monkeypatch):
         def dim(self):
             return len(self.shape)
 
-    monkeypatch.setattr(r50, "_TUNED_SHAPES", {(16, 512, 512)})
+    from irn_amd.step import _common
+    monkeypatch.setattr(r50, "_TUNED_SHAPES", {_common.miopen_cache_key(): {(16, 512, 512)}, _common.miopen_cache_key() + "-det": {(16, 512, 512)}})
+    monkeypatch.setattr(r50, "DETERMINISTIC", None)
+    monkeypatch.setattr(torch.backends.cudnn, "deterministic", False)
     with torch.no_grad():
         monkeypatch.setattr(r50, "CHANNELS_LAST_MODE", "auto")
         monkeypatch.delenv("IRN_MIOPEN_DB_SET", raising=False)
@@ -525,6 +563,21 @@ def test_trunk_layout_is_chosen_per_input_shape(monkeypatch):
         assert r50.channels_last_for(_T((2, 3, 375, 500)))
         monkeypatch.setattr(r50, "CHANNELS_LAST_MODE", "0")
         assert not r50.channels_last_for(_T((16, 3, 512, 512)))
+        # a caller's own deterministic flag, not managed by the steps: MIOpen's attribute leaves no fast NHWC solver -> NCHW
+        monkeypatch.setattr(r50, "CHANNELS_LAST_MODE", "auto")
+        torch.backends.cudnn.deterministic = True
+        assert not r50.channels_last_for(_T((16, 3, 512, 512)))
+        # the reproducible mode of the steps (managed): tuned shapes channels-last WITHOUT the attribute (their database has no
+        # order-dependent solver), everything else NCHW WITH it; the end of a pass puts the attribute back on
+        monkeypatch.setattr(r50, "DETERMINISTIC", True)
+        assert r50.channels_last_for(_T((16, 3, 512, 512))) and torch.backends.cudnn.deterministic is False
+        r50.end_trunk_pass()
+        assert torch.backends.cudnn.deterministic is True
+        assert not r50.channels_last_for(_T((16, 3, 333, 500))) and torch.backends.cudnn.deterministic is True
+        monkeypatch.setattr(r50, "DETERMINISTIC", False)
+        torch.backends.cudnn.deterministic = False
+        assert r50.channels_last_for(_T((16, 3, 512, 512))) and torch.backends.cudnn.deterministic is False
+    monkeypatch.setattr(r50, "DETERMINISTIC", None)
     monkeypatch.setattr(r50, "CHANNELS_LAST_MODE", "1")
     with torch.enable_grad():
         assert not r50.channels_last_for(_T((16, 3, 512, 512)))       # the training seam keeps the composed NCHW path

@@ -34,7 +34,7 @@ def main():
         tuned = all((int(x.shape[0]), int(x.shape[2]), int(x.shape[3])) in r50.tuned_nhwc_shapes() for x in xs)
         ref = None
         for layout, gemm, det in (("0", 0, False), ("0", 0, True), ("1", 0, False), ("1", 1, False), ("1", 1, True)):
-            r50.CHANNELS_LAST_MODE, r50.FUSED_GEMM = layout, bool(gemm)
+            r50.CHANNELS_LAST_MODE, r50.FUSED_GEMM, r50.DETERMINISTIC = layout, bool(gemm), None
             torch.backends.cudnn.deterministic = det
             with torch.no_grad():
                 t0 = time.perf_counter()

@@ -44,7 +44,7 @@ def main():
     ap.add_argument("--pairs", type=int, default=1)
     ap.add_argument("--repeat", type=int, default=3)
     ap.add_argument("--scales", default="1.0,0.5")
-    ap.add_argument("--deterministic", type=int, default=0, help="torch.backends.cudnn.deterministic (MIOpen's deterministic attribute)")
+    ap.add_argument("--deterministic", type=int, default=-1, help="-1: the mode IRN_DETERMINISTIC selects; 0 / 1: the bare torch.backends.cudnn.deterministic flag, unmanaged")
     a = ap.parse_args()
     import torch
     import torch.nn as nn
@@ -52,9 +52,13 @@ def main():
     from irn_amd.net import resnet50_cam, resnet50_irn, weights
     from irn_amd.step import _common
     dev = torch.device("cuda", 0)
-    torch.backends.cudnn.deterministic = bool(a.deterministic)
     print("miopen db:", _common.miopen_setup(0), "find mode", os.environ.get("MIOPEN_FIND_MODE"),
-          "| channels-last", os.environ.get("IRN_CHANNELS_LAST", "auto"), "| fused gemm", os.environ.get("IRN_FUSED_GEMM", "1"))
+          "| channels-last", os.environ.get("IRN_CHANNELS_LAST", "auto"), "| fused gemm", os.environ.get("IRN_FUSED_GEMM", "1"),
+          "| IRN_DETERMINISTIC", os.environ.get("IRN_DETERMINISTIC", "1 (default)"))
+    if a.deterministic >= 0:       # the bare MIOpen attribute, unmanaged (what rounds 1-4 could have switched on)
+        from irn_amd.net import resnet50 as _r50
+        _r50.DETERMINISTIC = None
+        torch.backends.cudnn.deterministic = bool(a.deterministic)
     cam = resnet50_cam.CAM()
     cam.load_state_dict(weights.random_cam_state(1))
     cam = cam.to(dev).eval()

@@ -30,9 +30,9 @@ def main():
     ap.add_argument("--channels-last", type=int, default=0)
     ap.add_argument("--single", type=int, default=1, help="also the one-pair / one-image shapes (the tail of a shard)")
     ap.add_argument("--suffix", default="", help="appended to the output directory's key (e.g. -nhwc)")
-    ap.add_argument("--deterministic", type=int, default=1,
-                    help="tune with MIOpen's deterministic attribute set (what the steps run with, IRN_DETERMINISTIC=1): only solvers "
-                         "without atomic accumulation are timed and recorded")
+    ap.add_argument("--deterministic", type=int, default=0,
+                    help="1: tune under MIOpen's deterministic attribute (round 5 measured: no fast NHWC fp32 solver survives it).  The "
+                         "reproducible mode's database is DERIVED from the fast one instead: run tools/miopen_det_filter.py afterwards")
     ap.add_argument("--fused-gemm", type=int, default=1, help="the trunk's stride-1 1x1 convolutions are hipBLASLt GEMMs (not MIOpen problems)")
     a = ap.parse_args()
     db = tempfile.mkdtemp(prefix="irn_miopen_warm_")
