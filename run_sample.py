@@ -67,11 +67,12 @@ def build_parser():
                         "operator (84 applications at exp_times 8; the default), 0 = the reference's own 2^exp_times applications "
                         "(misc/indexing.py:136-137).  Unset: the environment variable IRN_WALK_ACCEL, else 1")
     p.add_argument("--walk_accel_tol_exp", default=0, type=int,
-                   help="truncation bound 10^-e of the series (0 = the library default, e = 7; 6 = 78 applications: +7 %, may flip an argmax at an exact tie)")
+                   help="truncation bound 10^-e of the series (0 = the library default, e = 7; 6 = 78 applications: +7 %%, may flip an argmax at an exact tie)")
     p.add_argument("--deterministic", default=None, type=int, choices=(0, 1),
-                   help="1 = bit-reproducible backbones (MIOpen's deterministic attribute, NCHW trunk): any worker layout writes "
-                        "identical files, at ~0.8x the speed (not in the reference).  Unset: the environment variable "
-                        "IRN_DETERMINISTIC, else 0")
+                   help="1 (the default) = bit-reproducible backbones: any worker layout writes identical files (tuned shapes on a "
+                        "find database without split-K solvers, MIOpen's deterministic attribute elsewhere); 0 = the last 2-4 %% of "
+                        "speed, outputs then move by ~1e-5 from run to run (not in the reference).  Unset: the environment "
+                        "variable IRN_DETERMINISTIC, else 1")
     p.add_argument("--step_timeout", default=0.0, type=float,
                    help="seconds a step may take in its worker processes before the pool is stopped and the step raises "
                         "(0 = no limit; also IRN_STEP_TIMEOUT_S)")

@@ -704,3 +704,13 @@ def test_dataset_skips_the_pixels_when_the_step_says_so(tmp_path):
     h0, m0 = store.hits, store.misses
     assert store.peek("k", torch.device("cpu")) and not store.peek("other", torch.device("cpu"))
     assert (store.hits, store.misses) == (h0, m0)
+
+
+def test_run_sample_help_renders_and_deterministic_flag_reaches_the_environment(monkeypatch, tmp_path):
+    """`run_sample.py --help` formats (a bare % in a help string used to crash argparse) and `--deterministic` sets the variable
+    every process that sets MIOpen up reads (workers inherit it)."""
+    import run_sample
+    text = run_sample.build_parser().format_help()
+    assert "--deterministic {0,1}" in text and "--edge_out_dir" in text and "--walk_accel {0,1}" in text
+    a = run_sample.build_parser().parse_args(["--voc12_root", "x", "--deterministic", "0"])
+    assert a.deterministic == 0 and run_sample.build_parser().parse_args(["--voc12_root", "x"]).deterministic is None
