@@ -158,7 +158,7 @@ def bn_act_(x, scale, shift, residual=None, relu=True, residual_affine=None):
     return x
 
 
-_GEMM_WS = {}          # device index -> workspace tensor of the fused 1x1 convolutions (one per device, stream-ordered use)
+_GEMM_WS = {}          # (device index, stream) -> workspace tensor of the fused 1x1 convolutions (stream-ordered use)
 _GEMM_RANKS = None     # (m, cin, cout, bias, residual, relu) -> rank in hipBLASLt's heuristic list, measured once per device
 
 
@@ -207,7 +207,8 @@ def conv1x1_nhwc(x, weight, bias=None, residual=None, relu=False, out=None, algo
     m = n * h * w_
     if m == 0:
         return out
-    dev = x.device.index if x.device.index is not None else torch.cuda.current_device()
+    # one workspace per (device, stream): GEMMs enqueued on different streams may overlap on the device
+    dev = (x.device.index if x.device.index is not None else torch.cuda.current_device(), torch.cuda.current_stream(x.device).cuda_stream)
     ws = _GEMM_WS.get(dev)
     if ws is None:
         ws = _GEMM_WS[dev] = torch.empty(int(lib.irn_conv1x1_workspace_bytes()), dtype=torch.uint8, device=x.device)
