@@ -31,6 +31,15 @@ class _Head(nn.Sequential):
     def forward(self, x):
         mods = list(self)
         i = 0
+        m0 = mods[0]
+        if (isinstance(m0, nn.Conv2d) and m0.kernel_size == (1, 1) and m0.stride == (1, 1) and m0.bias is None and m0.groups == 1
+                and _r50._gemm_path(x)):
+            # a channels-last trunk feature: the head's 1x1 convolution is a GEMM over the activation as it lies (round 5: the
+            # four trunk outputs used to be transposed to NCHW first, 1.2 GB of copies per IRNet pass); its 32-256-channel
+            # result is what goes to NCHW for the GroupNorm
+            from .. import ops
+            x = ops.conv1x1_nhwc(x, m0.weight.detach().flatten(1)).contiguous()
+            i = 1
         while i < len(mods):
             m = mods[i]
             if (isinstance(m, nn.Upsample) and i + 1 < len(mods) and isinstance(mods[i + 1], nn.ReLU) and _r50._fused(x)
@@ -100,8 +109,8 @@ class Net(nn.Module):
         f4 = self.stage4(f3).detach()
         f5 = self.stage5(f4).detach()
         _r50.end_trunk_pass()               # the heads run NCHW (reproducible mode: under MIOpen's deterministic attribute)
-        if cl:                              # the heads (GroupNorm, the hand-written upsampling) take NCHW
-            f2, f3, f4, f5 = (_r50.to_nchw(f) for f in (f2, f3, f4, f5))
+        if cl and not (_r50.FUSED_GEMM and _r50.FUSED_EPILOGUE):
+            f2, f3, f4, f5 = (_r50.to_nchw(f) for f in (f2, f3, f4, f5))      # (else each head's first GEMM reads them channels-last)
 
         e2 = self.fc_edge2(f2)
         eh, ew = e2.shape[2:]
