@@ -232,8 +232,9 @@ class Bottleneck(nn.Module):
         (double precision, rounded once), the shifts as biases; for a projection unit the shortcut's shift rides in
         conv3's bias (the shortcut GEMM has none).  Cached until a parameter or statistic is written or moved."""
         convs = [self.conv1, self.conv3] + ([] if self.downsample is None else [self.downsample[0]])
+        w2 = self.conv2.weight
         bns = [self.bn1, self.bn3] + ([] if self.downsample is None else [self.downsample[1]])
-        src = [c.weight for c in convs] + [t for b in bns for t in (b.weight, b.bias, b.running_mean, b.running_var)]
+        src = [c.weight for c in convs] + [w2] + [t for b in bns for t in (b.weight, b.bias, b.running_mean, b.running_var)]
         key = tuple((t.data_ptr(), _version(t)) for t in src)
         if self._gemm is None or self._gemm[0] != key:
             with torch.no_grad():
@@ -243,10 +244,13 @@ class Bottleneck(nn.Module):
                     shift = b.bias.detach().double() - b.running_mean.detach().double() * scale
                     folded.append(((c.weight.detach().double() * scale.view(-1, 1, 1, 1)).float().contiguous(), shift))
                 p = {"w1": folded[0][0].flatten(1), "b1": folded[0][1].float().contiguous(), "w3": folded[1][0].flatten(1)}
+                # the 3x3 weight in the layout MIOpen's NHWC solvers take: PyTorch otherwise re-lays it out on EVERY call
+                # (1.7 % of the e2e GPU time in strided copy kernels, profiles/r05_s15_e2e_kernel_classes.txt)
+                p["w2"] = self.conv2.weight.detach().contiguous(memory_format=torch.channels_last)
                 if self.downsample is None:
                     p["b3"] = folded[1][1].float().contiguous()
                 else:
-                    p["wd"] = folded[2][0]                                   # [cout, cin, 1, 1]: also MIOpen's operand when strided
+                    p["wd"] = folded[2][0].contiguous(memory_format=torch.channels_last)   # [cout, cin, 1, 1]: also MIOpen's operand when strided
                     p["b3"] = (folded[1][1] + folded[2][1]).float().contiguous()
             self._gemm = (key, p)
         return self._gemm[1]
@@ -268,12 +272,14 @@ class Bottleneck(nn.Module):
         from .. import ops
         p = self.gemm_params()
         y = ops.conv1x1_nhwc(x, p["w1"], p["b1"], relu=True)
-        y = self.bn2.apply_(self.conv2(y), relu=True).contiguous(memory_format=torch.channels_last)
+        c2 = self.conv2
+        y = self.bn2.apply_(F.conv2d(y, p["w2"], None, c2.stride, c2.padding, c2.dilation, c2.groups), relu=True)
+        y = y.contiguous(memory_format=torch.channels_last)
         if self.downsample is None:
             return ops.conv1x1_nhwc(y, p["w3"], p["b3"], residual=x, relu=True)
         ds = self.downsample[0]
         if tuple(ds.stride) == (1, 1):
-            sc = ops.conv1x1_nhwc(x, p["wd"].flatten(1))
+            sc = ops.conv1x1_nhwc(x, p["wd"].reshape(p["wd"].shape[0], -1))
         else:                   # a strided shortcut is not a matrix view of x: MIOpen, with the folded weight
             sc = F.conv2d(x, p["wd"], None, ds.stride).contiguous(memory_format=torch.channels_last)
         return ops.conv1x1_nhwc(y, p["w3"], p["b3"], residual=sc, relu=True, out=sc)

@@ -1,7 +1,7 @@
 #!/bin/bash
 # round 5 session 8: kernel-class profiles of cam / e2e (the profiled run now finds the shipped database), walk trace + PMC traffic
 set -u
-OUT=gpurun_out/r5_s8; mkdir -p $OUT
+OUT=gpurun_out/${S:-r5_s8}; mkdir -p $OUT
 export TMPDIR=/tmp MIOPEN_FIND_MODE=2
 T0=$(date +%s); el() { echo "[$(( $(date +%s) - T0 )) s] $*"; }
 R=$PWD
