@@ -70,6 +70,9 @@ def _worker(rank, a, q, go):
             for pack in _common.make_loader(ds, a.loader_threads):
                 name = pack["name"][0]
                 k = int(pack["label"][0].sum())
+                staging = pack.pop("_staging", None)          # the loader staged the image in page-locked memory (as for a real step):
+                if staging is not None:                       # there the upload recycles the buffer, here nothing uploads
+                    _common.PINNED.give(staging)
                 if kind == "make_cam":
                     cam, hi = cam_pay[min(max(k, 1), 4)]
                     writer.submit(np.save, os.path.join(out, name + ".npy"), {"keys": torch.arange(k), "cam": cam.clone(), "high_res": hi})
