@@ -98,6 +98,9 @@ def _work(process_id, model, dataset, args):
                 if float(label.sum()) == 0:
                     # the reference would write an empty dictionary here and crash later in the label steps
                     warnings.warn("%s: no positive class in the image-level label, skipped" % img_name)
+                    staging = pack.pop("_staging", None) if isinstance(pack, dict) else None
+                    if staging is not None:                  # the loader thread's page-locked copy of an image nobody uploads
+                        _common.PINNED.give(staging)
                     continue
                 group = groups.setdefault(size, [])
                 imgs = _common.device_images(pack, scales)
