@@ -419,9 +419,10 @@ def test_bench_contract_one_json_line():
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k != "IRN_DETERMINISTIC"}        # the line of the DEFAULT mode, whatever this suite runs under
     out = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "2", "--warmup", "1", "--batch", "8",
                           "--cpu-images", "2", "--ref-grids", "64", "--legs", "coco,ins,walk_plain,walk_voc,cam"], capture_output=True, text=True,
-                         timeout=900, cwd=root)
+                         timeout=900, cwd=root, env=env)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1

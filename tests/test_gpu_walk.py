@@ -218,12 +218,20 @@ def test_edge_to_affinity_is_differentiable_like_the_reference(golden, r):
     b, hp, wp = edge_np.shape
     edge = torch.from_numpy(edge_np).to(_dev()).requires_grad_(True)
     aff = indexing.edge_to_affinity(edge[:, None], radius=r, size=(hp, wp))
-    assert np.array_equal(aff.detach().cpu().numpy(), ag["r%d_aff" % r])
+    fwd = aff.detach().cpu().numpy()
+    assert np.array_equal(fwd, ag["r%d_aff" % r]), ("forward", int((fwd != ag["r%d_aff" % r]).sum()), float(np.abs(fwd - ag["r%d_aff" % r]).max()))
     (aff * torch.from_numpy(gout).to(_dev())).sum().backward()
     ge = edge.grad.cpu().numpy()
     ref = ag["r%d_gedge" % r]
-    assert np.abs(ge - ref).max() <= 1e-5 * np.abs(ref).max()
-    assert np.abs(ge - O.edge_to_affinity_backward(edge_np, gout, r)).max() <= 1e-5 * np.abs(ref).max()
+    # The gradients of a cell meet in fp32 atomics (LDS, then one global atomic per touched cell): their ORDER is not fixed, so
+    # the comparison is against a per-cell rounding bound, not a global tolerance (a global 1e-5 x max failed once in ~15
+    # sessions): |error| <= c * eps * sum of |addends| of that cell, the sum taken from the oracle's routing of |gout|
+    eps = float(np.finfo(np.float32).eps)
+    bound = 64 * eps * np.abs(O.edge_to_affinity_backward(edge_np, np.abs(gout), r)) + 1e-7
+    err = np.abs(ge - O.edge_to_affinity_backward(edge_np, gout, r))
+    assert (err <= bound).all(), ("vs oracle", float(err.max()), float((err / bound).max()), int((err > bound).sum()))
+    err = np.abs(ge - ref)
+    assert (err <= 2 * bound).all(), ("vs reference autograd", float(err.max()), float((err / bound).max()))     # its own fp32 index_add rounds too
     # a larger ragged batch against the oracle, radius 10 included
     for rr, (hh, ww) in ((10, (40, 61)), (5, (33, 70))):
         from irn_amd import synth
@@ -234,7 +242,9 @@ def test_edge_to_affinity_is_differentiable_like_the_reference(golden, r):
         a = indexing.edge_to_affinity(e[:, None], radius=rr, size=(hh, ww))
         (a * torch.from_numpy(g_np).to(_dev())).sum().backward()
         want = O.edge_to_affinity_backward(e_np, g_np, rr)
-        assert np.abs(e.grad.cpu().numpy() - want).max() <= 2e-5 * np.abs(want).max()
+        bound = 64 * eps * np.abs(O.edge_to_affinity_backward(e_np, np.abs(g_np), rr)) + 1e-7
+        err = np.abs(e.grad.cpu().numpy() - want)
+        assert (err <= bound).all(), (rr, float((err / bound).max()))
 
 
 @pytest.mark.parametrize("r", [3, 5, 10])
