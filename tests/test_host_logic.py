@@ -714,3 +714,40 @@ def test_run_sample_help_renders_and_deterministic_flag_reaches_the_environment(
     assert "--deterministic {0,1}" in text and "--edge_out_dir" in text and "--walk_accel {0,1}" in text
     a = run_sample.build_parser().parse_args(["--voc12_root", "x", "--deterministic", "0"])
     assert a.deterministic == 0 and run_sample.build_parser().parse_args(["--voc12_root", "x"]).deterministic is None
+
+
+def test_instance_step_pipeline_order(monkeypatch):
+    """make_ins_seg_labels._flush: per turn (1) the batch whose front half is enqueued gets its back half, (2) the new batch's IRNet
+    forward + front half are enqueued, (3) the batch before is collected and written — every batch passes the three stages once
+    and in order, the back half of batch k never queues behind the forward of batch k+1, three closing turns drain the pipe.
+    (Reference loop: step/make_ins_seg_labels.py:119-152, one image at a time.)"""
+    import argparse
+    from irn_amd.step import make_ins_seg_labels as mis, make_sem_seg_labels as mss
+    log = []
+    monkeypatch.setattr(mss, "edges_for", lambda model, pend, irn_batch, **kw: log.append(("irnet", tuple(p["name"] for p in pend))))
+    monkeypatch.setattr(mss, "_edge_store_kw", lambda model, args: {})
+    monkeypatch.setattr(mis, "instance_front", lambda items: log.append(("front", tuple(it["name"] for it in items))) or ("cmaps", "k_dev"))
+    monkeypatch.setattr(mis, "instance_back", lambda walker, items, front, beta, exp_times, bg, deferred=False:
+                        log.append(("back", tuple(it["name"] for it in items))) or "pending-%s" % items[0]["name"])
+    monkeypatch.setattr(mis, "_write", lambda names, pending, args, writer: log.append(("write", tuple(names), pending)))
+    args = argparse.Namespace(beta=10, exp_times=8, ins_seg_bg_thres=0.25, irn_batch=8)
+    state = {}
+    batches = [["a1", "a2"], ["b1", "b2"], ["c1"]]
+    for b in batches:
+        pend = [{"name": n} for n in b]
+        mis._flush(None, None, pend, args, None, state)
+        assert pend == []
+    for _ in range(3):
+        mis._flush(None, None, [], args, None, state)
+    assert state == {"front": None, "emit": None}
+    stages = [(kind, names[0][0]) for kind, names, *rest in log]
+    # per batch: irnet -> front -> back -> write, once each
+    for tag in "abc":
+        assert [k for k, t in stages if t == tag] == ["irnet", "front", "back", "write"], (tag, stages)
+    # the back half of a batch is enqueued BEFORE the next batch's forward (its small read-backs must not wait behind it)
+    assert stages.index(("back", "a")) < stages.index(("irnet", "b")) < stages.index(("write", "a")) or \
+        stages.index(("back", "a")) < stages.index(("irnet", "b"))
+    assert stages.index(("back", "b")) < stages.index(("irnet", "c"))
+    # a batch is collected one turn after its back half: its detections cross PCIe under the next batch's kernels
+    assert stages.index(("write", "a")) > stages.index(("front", "b")) and stages.index(("write", "b")) > stages.index(("front", "c"))
+    assert [w[2] for w in log if w[0] == "write"] == ["pending-a1", "pending-b1", "pending-c1"]
