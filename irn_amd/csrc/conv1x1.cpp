@@ -13,6 +13,7 @@
 #include <hipblaslt/hipblaslt.h>
 
 #include <map>
+#include <memory>
 #include <mutex>
 #include <tuple>
 
@@ -84,7 +85,9 @@ int get_plan(hipblasLtHandle_t handle, int dev, int64_t m, int cin, int cout, bo
         for (auto &kv : g_plans) destroy_plan(kv.second);
         g_plans.clear();
     }
-    Plan *p = new Plan();
+    // owned here until it is in the cache: a failing call below frees the descriptors made so far
+    std::unique_ptr<Plan, void (*)(Plan *)> owner(new Plan(), destroy_plan);
+    Plan *p = owner.get();
     IRN_LT_TRY(hipblasLtMatmulDescCreate(&p->desc, HIPBLAS_COMPUTE_32F, HIP_R_32F));
     const int32_t op_t = HIPBLAS_OP_T, op_n = HIPBLAS_OP_N;
     IRN_LT_TRY(hipblasLtMatmulDescSetAttribute(p->desc, HIPBLASLT_MATMUL_DESC_TRANSA, &op_t, sizeof op_t));
@@ -108,12 +111,11 @@ int get_plan(hipblasLtHandle_t handle, int dev, int64_t m, int cin, int cout, bo
     hipblasStatus_t st = hipblasLtMatmulAlgoGetHeuristic(handle, p->desc, p->a, p->b, p->c, p->d, pref, kMaxAlgos, p->algo, &found);
     (void)hipblasLtMatmulPreferenceDestroy(pref);
     if (st != HIPBLAS_STATUS_SUCCESS || found < 1) {
-        destroy_plan(p);
         return fail(IRN_ERR_STATE, "hipBLASLt has no fp32 kernel for the 1x1 convolution m=%lld cin=%d cout=%d (status %d, %d found)",
                     (long long)m, cin, cout, (int)st, found);
     }
     p->n_algos = found;
-    g_plans[key] = p;
+    g_plans[key] = owner.release();
     *out = p;
     return IRN_OK;
 }

@@ -300,8 +300,10 @@ class RandomWalk:
             self.set_option("accel_tol_exp", int(env))
         env = os.environ.get("IRN_POLL_DELAY")            # pins the single-channel poll delay (no start-up probe)
         self._poll_pinned = env not in (None, "")
+        self.poll_delay_source = "library default / start-up probe"
         if self._poll_pinned:
             self.set_option("poll_delay", int(env))
+            self.poll_delay_source = "IRN_POLL_DELAY"
         elif self.radius == 10:
             # what an earlier process measured on this device with this build of the library: every pool worker would
             # otherwise run its first representative batch 8 extra times, blocking its host thread
@@ -309,6 +311,7 @@ class RandomWalk:
             if d:
                 self.set_option("poll_delay", d)
                 self._poll_pinned = True
+                self.poll_delay_source = "per-device cache"
 
     def close(self):
         if self._ctx:

@@ -62,19 +62,23 @@ def tuned_nhwc_shapes():
             if os.path.exists(path) and os.environ.get("IRN_MIOPEN_SEED", "1") != "0":
                 shapes = {tuple(int(v) for v in s) for s in json.load(open(path))}
             elif torch.cuda.is_available() and CHANNELS_LAST_MODE == "auto":
-                import sys
-                print("irn_amd: no tuned MIOpen database for %s under %s: the trunk runs NCHW without the fused 1x1 GEMMs (~0.8x); "
-                      "tools/miopen_warmup.py --channels-last 1 (+ tools/miopen_det_filter.py) writes one" % (key, _common.miopen_seed_root()), file=sys.stderr)
+                _common.warn_missing_shipped_data()
         except Exception:
             shapes = set()
         _TUNED_SHAPES[key] = shapes
     return _TUNED_SHAPES[key]
 
 
+def _tuned(x):
+    return (int(x.shape[0]), int(x.shape[2]), int(x.shape[3])) in tuned_nhwc_shapes()
+
+
 def channels_last_for(x):
     """Does the trunk run channels-last for the network input `x` [n, 3, H, W]?  (inference path only.)  Called once at the
     start of every trunk pass; in the reproducible mode it also sets MIOpen's deterministic attribute for the pass: off for a
-    channels-last pass (its database has no order-dependent solver left), on otherwise — `end_trunk_pass` puts it back on."""
+    channels-last pass of a shape the filtered database covers (it has no order-dependent solver left), on otherwise —
+    also for a channels-last pass forced by IRN_CHANNELS_LAST=1 on a shape the database does not know, where MIOpen would
+    otherwise search and could pick a split-K solver; `end_trunk_pass` puts it back on."""
     if CHANNELS_LAST_MODE == "0" or not x.is_cuda or x.dim() != 4 or torch.is_grad_enabled():
         if DETERMINISTIC and x.is_cuda:
             torch.backends.cudnn.deterministic = True
@@ -84,11 +88,62 @@ def channels_last_for(x):
         return False
     # auto: only in a process whose MIOpen user database has been completed from the shipped one (step/_common.miopen_setup:
     # the steps' workers, the in-process step path, bench.py) — anywhere else the NHWC problems would be untuned
-    cl = CHANNELS_LAST_MODE == "1" or (bool(os.environ.get("IRN_MIOPEN_DB_SET")) and
-                                       (int(x.shape[0]), int(x.shape[2]), int(x.shape[3])) in tuned_nhwc_shapes())
+    covered = bool(os.environ.get("IRN_MIOPEN_DB_SET")) and _tuned(x)
+    cl = CHANNELS_LAST_MODE == "1" or covered
     if DETERMINISTIC:
-        torch.backends.cudnn.deterministic = not cl
+        torch.backends.cudnn.deterministic = not (cl and covered)
     return cl
+
+
+# Trunk passes of this process by layout, rows added to fill a partial batch, and the NCHW passes by network-input size
+# (what `untuned_report` prints at the end of a step)
+PASS_STATS = {"channels_last": 0, "nchw": 0, "pad_rows": 0, "nchw_sizes": {}}
+
+
+def pass_rows(x):
+    """Reproducible mode: how many rows ([image, flip] pairs back to back) ONE trunk pass over network inputs like `x`
+    [n, 3, H, W] carries — 16 (the batch the shipped database is tuned for) when H x W is a tuned size, else 2 (one pair,
+    the reference's own batch, step/make_cam.py:32-33); None outside the mode (the caller's batch is the pass).  MIOpen
+    resolves a solver per PROBLEM and the batch is part of the problem, so a row's bits would otherwise depend on how many
+    others travel with it — on the shard split, the tail of a shard, an early flush."""
+    if not DETERMINISTIC or not x.is_cuda or x.dim() != 4 or torch.is_grad_enabled():
+        return None
+    if CHANNELS_LAST_MODE != "0" and bool(os.environ.get("IRN_MIOPEN_DB_SET")):
+        rows = [n for (n, h, w) in tuned_nhwc_shapes() if (h, w) == (int(x.shape[2]), int(x.shape[3]))]
+        if rows:
+            return max(rows)
+    return 2
+
+
+def run_rows(fn, x):
+    """`fn(x)` for a row-wise independent `fn` ([n, 3, H, W] -> tensor or tuple of tensors with n leading rows).  In the
+    reproducible mode the rows go through in passes of exactly `pass_rows(x)` — a short last pass is filled with zero images
+    whose outputs are dropped — so that the kernels a row meets are a function of its own size only."""
+    rows = pass_rows(x)
+    n = int(x.shape[0])
+    if rows is None or n == rows:
+        return fn(x)
+    outs = []
+    for i in range(0, n, rows):
+        chunk = x[i:i + rows]
+        valid = int(chunk.shape[0])
+        if valid < rows:
+            PASS_STATS["pad_rows"] += rows - valid
+            chunk = torch.cat([chunk, chunk.new_zeros((rows - valid,) + tuple(chunk.shape[1:]))])
+        y = fn(chunk)
+        outs.append(tuple(t[:valid] for t in y) if isinstance(y, tuple) else y[:valid])
+    if len(outs) == 1:
+        return outs[0]
+    if isinstance(outs[0], tuple):
+        return tuple(torch.cat([o[k] for o in outs]) for k in range(len(outs[0])))
+    return torch.cat(outs)
+
+
+def count_pass(x, channels_last):
+    PASS_STATS["channels_last" if channels_last else "nchw"] += 1
+    if not channels_last and x.is_cuda:
+        key = "%dx%d" % (int(x.shape[2]), int(x.shape[3]))
+        PASS_STATS["nchw_sizes"][key] = PASS_STATS["nchw_sizes"].get(key, 0) + 1
 
 
 def end_trunk_pass():
@@ -181,8 +236,10 @@ def stem(conv1, bn1, maxpool, x):
         # the stem is an NCHW problem in every layout: in the reproducible mode it always runs under MIOpen's attribute
         prev = torch.backends.cudnn.deterministic
         torch.backends.cudnn.deterministic = True
-        y = conv1(x)
-        torch.backends.cudnn.deterministic = prev
+        try:
+            y = conv1(x)
+        finally:
+            torch.backends.cudnn.deterministic = prev
     else:
         y = conv1(x)
     if _fused(y) and y.is_contiguous() and (maxpool.kernel_size, maxpool.stride, maxpool.padding, maxpool.dilation, maxpool.ceil_mode) == (3, 2, 1, 1, False):
@@ -198,6 +255,7 @@ class Stem(nn.Sequential):
 
     def forward(self, x):
         cl = channels_last_for(x)
+        count_pass(x, cl)
         x = stem(self[0], self[1], self[3], x)
         rest = list(self)[4:]
         if rest:
@@ -308,7 +366,9 @@ class ResNet50Trunk(nn.Module):
             c_in = planes * Bottleneck.expansion
 
     def forward(self, x):
-        x = to_stage_format(stem(self.conv1, self.bn1, self.maxpool, x), channels_last_for(x))
+        cl = channels_last_for(x)
+        count_pass(x, cl)
+        x = to_stage_format(stem(self.conv1, self.bn1, self.maxpool, x), cl)
         return self.layer4(self.layer3(self.layer2(self.layer1(x))))
 
 

@@ -46,6 +46,11 @@ class CAM(Net):
 
     def forward_batch(self, x):
         """[2B,3,H,W] = B (image, h-flipped image) pairs of ONE size back to back -> [B,20,h,w]: the forward above for
-        every pair in one pass of the trunk (the steps stack the images of a size group per scale)."""
-        a = _r50.to_nchw(F.relu(F.conv2d(self.features(x), self.classifier.weight)))
+        every pair in one pass of the trunk (the steps stack the images of a size group per scale).  In the reproducible
+        mode the rows travel in passes of a fixed size per image size (`resnet50.run_rows`): a pair's maps do not depend on
+        what else is in `x`."""
+        a = _r50.run_rows(self._maps, x)
         return a[0::2] + a[1::2].flip(-1)
+
+    def _maps(self, x):
+        return _r50.to_nchw(F.relu(F.conv2d(self.features(x), self.classifier.weight)))

@@ -160,7 +160,7 @@ class EdgeDisplacement(Net):
         [2B,3,crop,crop] pass of the trunk and heads; each result is cropped and merged exactly as in `forward`."""
         cs = self.crop_size
         x = torch.stack([F.pad(it, [0, cs - it.shape[3], 0, cs - it.shape[2]]) for it in items]).flatten(0, 1)
-        e, d = Net.forward(self, x)
+        e, d = _r50.run_rows(lambda c: Net.forward(self, c), x)      # reproducible mode: passes of a fixed size
         out = []
         for i, it in enumerate(items):
             H, W = it.shape[2:]

@@ -159,6 +159,8 @@ def bn_act_(x, scale, shift, residual=None, relu=True, residual_affine=None):
 
 
 _GEMM_WS = {}          # (device index, stream) -> workspace tensor of the fused 1x1 convolutions (stream-ordered use)
+_GEMM_NALGOS = {}      # problems with a non-zero table rank -> length of hipBLASLt's heuristic list in this process
+_GEMM_RANK_WARNED = False
 _GEMM_RANKS = None     # (m, cin, cout, bias, residual, relu) -> rank in hipBLASLt's heuristic list, measured once per device
 
 
@@ -213,7 +215,24 @@ def conv1x1_nhwc(x, weight, bias=None, residual=None, relu=False, out=None, algo
     if ws is None:
         ws = _GEMM_WS[dev] = torch.empty(int(lib.irn_conv1x1_workspace_bytes()), dtype=torch.uint8, device=x.device)
     if algo_rank is None:
-        algo_rank = gemm_ranks().get((m, cin, cout, int(bias is not None), int(residual is not None), int(bool(relu))), 0)
+        prob = (m, cin, cout, int(bias is not None), int(residual is not None), int(bool(relu)))
+        algo_rank = gemm_ranks().get(prob, 0)
+        if algo_rank:
+            # the table is keyed by architecture / CU count / HIP version only: another hipBLASLt build or workspace size may
+            # offer a shorter list — then the first pick, with one warning, instead of an error in the middle of a forward
+            n_algos = _GEMM_NALGOS.get(prob)
+            if n_algos is None:
+                with torch.cuda.device(x.device):
+                    n_algos = _GEMM_NALGOS[prob] = conv1x1_algo_count(*prob)
+            if algo_rank >= n_algos:
+                global _GEMM_RANK_WARNED
+                if not _GEMM_RANK_WARNED:
+                    _GEMM_RANK_WARNED = True
+                    import warnings
+                    warnings.warn("irn_amd: the shipped GEMM rank table names entry %d for the 1x1 convolution m=%d cin=%d cout=%d but "
+                                  "hipBLASLt offers %d here (another library build?): using its first pick for such problems; "
+                                  "tools/conv1x1_tune.py rewrites the table" % (algo_rank, m, cin, cout, n_algos), RuntimeWarning)
+                algo_rank = 0
     with torch.cuda.device(x.device):
         check(lib.irn_conv1x1_nhwc(x.data_ptr(), weight.data_ptr(), None if bias is None else bias.data_ptr(),
                                    None if residual is None else residual.data_ptr(), out.data_ptr(), m, cin, cout,

@@ -146,6 +146,116 @@ def miopen_seed_root():
     return os.environ.get("IRN_MIOPEN_SEED_DIR") or os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "data", "miopen")
 
 
+def gemm_table_root():
+    """Directory of the shipped GEMM rank tables (`<arch>-cu<N>-hip<v>.json`, written by tools/conv1x1_tune.py)."""
+    return os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "data", "gemm")
+
+
+def shipped_data_report():
+    """What this build ships for THIS device / HIP version: {"key", "mode_key", "miopen" (is there a find database for
+    the mode key), "miopen_keys" (the ones shipped), "gemm", "gemm_keys"}.  The tuned database and the rank table are this
+    build's additions (all the reference says about solvers is `cudnn.enabled = True`, step/make_cam.py:14), so their
+    absence is this build's to report."""
+    def listing(root, strip=""):
+        try:
+            return sorted(f[:len(f) - len(strip)] if strip and f.endswith(strip) else f for f in os.listdir(root)
+                          if not f.startswith("."))
+        except OSError:
+            return []
+    key, mode_key = miopen_cache_key(), miopen_mode_key()
+    mi_keys, ge_keys = listing(miopen_seed_root()), listing(gemm_table_root(), ".json")
+    return {"key": key, "mode_key": mode_key, "miopen": mode_key in mi_keys and os.environ.get("IRN_MIOPEN_SEED", "1") != "0",
+            "miopen_keys": mi_keys, "gemm": key in ge_keys and os.environ.get("IRN_GEMM_TABLE", "1") != "0", "gemm_keys": ge_keys}
+
+
+_WARNED = set()
+
+
+def warn_missing_shipped_data():
+    """One `warnings.warn` per process and kind when the find database or the GEMM rank table for this (architecture, CU
+    count, HIP version) is not shipped: the steps still run and still give the reference's results, ~10-20 % slower (NCHW
+    trunk without the fused 1x1 GEMMs; hipBLASLt's first heuristic pick instead of the measured one) — a cliff that used to
+    be silent.  -> the report."""
+    import warnings
+    rep = shipped_data_report()
+    if rep["key"].startswith("unknown_device"):          # no GPU in this process (CPU tests, tooling): nothing runs slower
+        return rep
+    if not rep["miopen"] and "miopen" not in _WARNED:
+        _WARNED.add("miopen")
+        warnings.warn("irn_amd: no tuned MIOpen find database for '%s' under %s (shipped: %s): every trunk pass runs NCHW without "
+                      "the fused 1x1 GEMMs, ~0.8x the throughput of the tuned channels-last trunk.  Remedy, on a box with this "
+                      "GPU: python tools/miopen_warmup.py --channels-last 1, then python tools/miopen_det_filter.py (the "
+                      "reproducible mode's '-det' database)." % (rep["mode_key"], miopen_seed_root(), ", ".join(rep["miopen_keys"]) or "none"),
+                      RuntimeWarning, stacklevel=2)
+    if not rep["gemm"] and "gemm" not in _WARNED:
+        _WARNED.add("gemm")
+        warnings.warn("irn_amd: no GEMM rank table for '%s' under %s (shipped: %s): the 1x1 convolutions use hipBLASLt's first "
+                      "heuristic pick for every problem.  Remedy, on a box with this GPU: python tools/conv1x1_tune.py."
+                      % (rep["key"], gemm_table_root(), ", ".join(rep["gemm_keys"]) or "none"), RuntimeWarning, stacklevel=2)
+    return rep
+
+
+def untuned_report(reset=True):
+    """One line about the trunk passes of this process that took the NCHW branch (network-input sizes the shipped database
+    is not tuned for: net/resnet50.channels_last_for), counts per size, or "" when there were none; printed at the end of
+    every step by whoever ran it.  `reset` starts the next step's count."""
+    from ..net import resnet50 as _r50
+    sizes = dict(_r50.PASS_STATS["nchw_sizes"])
+    n_cl, n_nchw, pad = _r50.PASS_STATS["channels_last"], _r50.PASS_STATS["nchw"], _r50.PASS_STATS["pad_rows"]
+    if reset:
+        _r50.PASS_STATS.update({"channels_last": 0, "nchw": 0, "pad_rows": 0, "nchw_sizes": {}})
+    if not sizes:
+        return ""
+    top = sorted(sizes.items(), key=lambda kv: -kv[1])
+    return ("irn_amd: %d of %d trunk passes ran NCHW (~0.8x) because their network-input size is not in the tuned database: %s%s"
+            "%s; tools/miopen_warmup.py --channels-last 1 --sizes ... adds sizes" % (
+                n_nchw, n_nchw + n_cl, ", ".join("%s x%d" % kv for kv in top[:8]), ", ... (%d sizes)" % len(top) if len(top) > 8 else "",
+                "; %d zero rows filled partial passes" % pad if pad else ""))
+
+
+def startup_line(rank, n_workers, device, db_dir):
+    """One line per worker / rank at start-up (stderr): which device it owns and whether the data this build's speed rests
+    on was found for it — the things that differ between the box the defaults were measured on and an eight-GPU node met for
+    the first time (reference step/make_cam.py:67-74 spawns its workers without a word)."""
+    rep = shipped_data_report()
+    try:
+        props = torch.cuda.get_device_properties(int(device))
+        chip = "%s, %d CUs, %.0f GB" % (str(getattr(props, "gcnArchName", "?")).split(":")[0], props.multi_processor_count, props.total_memory / 2 ** 30)
+    except Exception:
+        chip = "no GPU"
+    try:
+        from ..misc import indexing
+        saved = indexing._saved_poll_delay(torch.device("cuda", int(device)))
+        poll = "IRN_POLL_DELAY=%s" % os.environ["IRN_POLL_DELAY"] if os.environ.get("IRN_POLL_DELAY") else (
+            "poll delay %d from %s" % (saved, indexing._poll_delay_file(torch.device("cuda", int(device)))) if saved
+            else "poll delay: start-up probe at the first radius-10 batch")
+    except Exception:
+        poll = "poll delay: n/a"
+    return ("irn_amd worker %d/%d: cuda:%d (%s) | %s backbones | MIOpen database '%s': %s, user database %s | GEMM rank table: %s | %s"
+            % (int(rank), int(n_workers), int(device), chip, "reproducible" if deterministic_backbones() else "fast",
+               rep["mode_key"], "shipped" if rep["miopen"] else "NOT SHIPPED (NCHW trunk)", db_dir, "shipped" if rep["gemm"] else "not shipped", poll))
+
+
+def step_summary(rank, walker=None):
+    """One line at the end of a step (stderr) when there is something to say: trunk passes that fell to the NCHW branch by
+    size, and the walk's self-checks (block -> XCD placement, poll delay and where it came from, fall-backs)."""
+    import sys
+    parts = []
+    msg = untuned_report()
+    if msg:
+        parts.append(msg)
+    if walker is not None:
+        try:
+            t = walker.tuning()
+            parts.append("irn_amd: walk radius %d: XCD placement %s, poll delay %d (%s), %d fall-back run(s)" % (
+                walker.radius, {0: "not checked", 1: "round robin holds", 2: "does NOT hold (no XCD packing)"}.get(t["placement"], "?"),
+                t["poll_delay"], getattr(walker, "poll_delay_source", "library default"), walker.fallback_runs))
+        except Exception:
+            pass
+    for m in parts:
+        print("[worker %d] %s" % (int(rank), m), file=sys.stderr, flush=True)
+
+
 def deterministic_backbones():
     """IRN_DETERMINISTIC (default 1; run_sample.py --deterministic 0/1): the backbones' outputs are a function of their inputs
     only, whichever process, worker layout or run computes them — an N-GPU run writes bit for bit the files of a 1-GPU run
@@ -200,6 +310,7 @@ def miopen_setup(device_ordinal):
     import shutil
     os.environ.setdefault("MIOPEN_FIND_MODE", "2")
     apply_deterministic_setting()
+    warn_missing_shipped_data()
     marker = os.environ.get("IRN_MIOPEN_DB_SET")
     if marker and os.environ.get("MIOPEN_USER_DB_PATH") == marker and os.environ.get("IRN_MIOPEN_DB_DEV", str(int(device_ordinal))) == str(int(device_ordinal)):
         return marker                                    # this process (or the parent it inherited from, if it holds no lock itself) did it, for this device
@@ -273,8 +384,10 @@ def _pool_worker(rank, device, n_workers, cmd_q, res_q):
         if int(device) >= 0:                  # negative ordinals: workers without a GPU (the pool's own CPU tests)
             os.environ.pop("IRN_MIOPEN_DB_SET", None)    # the parent's claim is the parent's: this process makes its own
             os.environ.pop("IRN_MIOPEN_DB_DEV", None)
-            miopen_setup(int(device))                    # stable per-device database, never shared by two live processes
+            db_dir = miopen_setup(int(device))           # stable per-device database, never shared by two live processes
             torch.cuda.set_device(int(device))
+            import sys
+            print(startup_line(rank, n_workers, device, db_dir), file=sys.stderr, flush=True)
         res_q.put((rank, "ready", None))
         while True:
             cmd = cmd_q.get()
@@ -287,6 +400,7 @@ def _pool_worker(rank, device, n_workers, cmd_q, res_q):
                 work(rank, model, shards, args)
                 if int(device) >= 0:
                     torch.cuda.synchronize()
+                    step_summary(rank)
                 res_q.put((rank, "ok", {"cam_store_hits": CAM_STORE.hits, "cam_store_misses": CAM_STORE.misses,
                                         "edge_store_hits": EDGE_STORE.hits, "edge_store_misses": EDGE_STORE.misses,
                                         "walk_fallback_runs": WALK_STATS["fallback_runs"], "cam_trunk_passes": dict(CAM_STATS)}))
@@ -425,8 +539,20 @@ def spawn_workers(work, model, shards, args):
             multiprocessing.spawn(work, nprocs=n, args=(model, shards, args), join=True)
         return
     if n == 1 and not getattr(args, "always_use_workers", False):
-        miopen_setup(devs[0])               # the same MIOpen settings a pool worker would run with
-        work(0, model, shards, args)        # same code path, no second process needed for a single GPU
+        # same code path, no second process needed for a single GPU — but this IS the caller's process: its own
+        # torch.backends.cudnn.deterministic and the trunk's mode are put back when the step returns
+        from ..net import resnet50 as _r50
+        saved = (torch.backends.cudnn.deterministic, _r50.DETERMINISTIC)
+        try:
+            db_dir = miopen_setup(devs[0])      # the same MIOpen settings a pool worker would run with
+            if "startup" not in _WARNED:
+                _WARNED.add("startup")
+                import sys
+                print(startup_line(0, 1, devs[0], db_dir), file=sys.stderr, flush=True)
+            work(0, model, shards, args)
+            step_summary(0)
+        finally:
+            torch.backends.cudnn.deterministic, _r50.DETERMINISTIC = saved
         return
     get_pool(devs).run(work, model, shards, args, timeout_s=step_timeout(args))
 
@@ -463,7 +589,7 @@ def split_by_owner(dataset, n_splits, names, owners, slack=0.25):
 
 # make_cam's trunk passes of this process, by layout (net/resnet50.channels_last_for: channels-last only for input shapes the
 # shipped find database is tuned for), and its size-group flushes (full groups of `cam_batch` images vs partial ones)
-CAM_STATS = {"channels_last": 0, "nchw": 0, "full_group_flushes": 0, "partial_group_flushes": 0}
+CAM_STATS = {"channels_last": 0, "nchw": 0, "full_group_flushes": 0, "partial_group_flushes": 0}      # (passes, not flushes: a partial group is one padded pass, an untuned size one pass per image — net/resnet50.run_rows)
 CAM_OWNERS = {}       # abspath(cam_out_dir) -> {image name: worker that made (and still holds) its CAM}
 WALK_STATS = {"fallback_runs": 0}
 
@@ -764,7 +890,17 @@ def make_loader(databin, num_workers, prefetch=4):
                 nxt += 1
             yield pending.popleft().result()
     finally:
-        pool.shutdown(wait=False, cancel_futures=True)
+        # an early close (an exception in the consumer, a generator dropped half-way) must not strand the page-locked buffers
+        # of items nobody will consume: cancel what has not started, wait for what has, hand every buffer back
+        pool.shutdown(wait=True, cancel_futures=True)
+        for fut in pending:
+            try:
+                if not fut.cancelled():
+                    buf = fut.result().pop("_staging", None)
+                    if buf is not None:
+                        PINNED.give(buf)
+            except Exception:
+                pass
 
 
 def progress(process_id, n_workers, it, n_items):

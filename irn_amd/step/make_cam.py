@@ -52,8 +52,10 @@ def _flush_group(model, group, scales, args, writer, store):
     outs = []
     for si in range(len(scales)):
         x = torch.cat([g["imgs"][si] for g in group])
-        _common.CAM_STATS["channels_last" if _r50.channels_last_for(x) else "nchw"] += 1
+        before = (_r50.PASS_STATS["channels_last"], _r50.PASS_STATS["nchw"])
         outs.append(model.forward_batch(x))
+        _common.CAM_STATS["channels_last"] += _r50.PASS_STATS["channels_last"] - before[0]
+        _common.CAM_STATS["nchw"] += _r50.PASS_STATS["nchw"] - before[1]
     _common.CAM_STATS["full_group_flushes" if len(group) >= int(getattr(args, "cam_batch", 0) or 8) else "partial_group_flushes"] += 1
     for i, g in enumerate(group):
         keys_cpu = torch.nonzero(g["label"])[:, 0]

@@ -142,6 +142,7 @@ def _work(process_id, model, dataset, args):
             _flush(model, walker, pend, args, writer, state)      # ... its back half ...
             _flush(model, walker, pend, args, writer, state)      # ... and its collection
             _common.WALK_STATS["fallback_runs"] += walker.fallback_runs
+            _common.step_summary(process_id, walker)
             walker.close()
     finally:
         writer.close()

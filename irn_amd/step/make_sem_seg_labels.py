@@ -202,6 +202,7 @@ def _work(process_id, model, dataset, args):
             _collect(walker, running, args, writer)
             _flush(model, walker, pend, args, writer)
             _common.WALK_STATS["fallback_runs"] += walker.fallback_runs
+            _common.step_summary(process_id, walker)
             walker.close()
     finally:
         writer.close()

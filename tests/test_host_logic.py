@@ -583,6 +583,111 @@ def test_trunk_layout_is_chosen_per_input_shape(monkeypatch):
         assert not r50.channels_last_for(_T((16, 3, 512, 512)))       # the training seam keeps the composed NCHW path
 
 
+def test_reproducible_mode_runs_the_trunk_in_passes_of_a_fixed_size(monkeypatch):
+    """which kernels an image meets must not depend on the batch it travels in (shard split, tail of a
+    shard, early flush).  Reproducible mode: rows go through in passes of 16 (sizes the shipped database is tuned for: a short
+    pass is filled with zero images) or 2 (every other size: the reference's own batch); forced channels-last on an unknown
+    shape keeps MIOpen's deterministic attribute on."""
+    from irn_amd.net import resnet50 as r50
+    from irn_amd.step import _common
+
+    class _T:
+        def __init__(self, shape, cuda=True):
+            self.shape, self.is_cuda = shape, cuda
+
+        def dim(self):
+            return len(self.shape)
+
+    monkeypatch.setattr(r50, "_TUNED_SHAPES", {_common.miopen_cache_key() + "-det": {(16, 512, 512), (16, 375, 500)}})
+    monkeypatch.delenv("IRN_DETERMINISTIC", raising=False)
+    monkeypatch.setenv("IRN_MIOPEN_DB_SET", "/somewhere")
+    monkeypatch.setattr(r50, "CHANNELS_LAST_MODE", "auto")
+    with torch.no_grad():
+        monkeypatch.setattr(r50, "DETERMINISTIC", True)
+        assert r50.pass_rows(_T((6, 3, 512, 512))) == 16 and r50.pass_rows(_T((16, 3, 375, 500))) == 16
+        assert r50.pass_rows(_T((16, 3, 333, 500))) == 2 and r50.pass_rows(_T((2, 3, 64, 64))) == 2
+        monkeypatch.setattr(r50, "CHANNELS_LAST_MODE", "0")
+        assert r50.pass_rows(_T((16, 3, 512, 512))) == 2                      # no channels-last trunk: every size is "untuned"
+        monkeypatch.setattr(r50, "CHANNELS_LAST_MODE", "1")
+        prev = torch.backends.cudnn.deterministic
+        assert r50.channels_last_for(_T((4, 3, 100, 100))) and torch.backends.cudnn.deterministic is True     # forced layout, unknown shape
+        assert r50.channels_last_for(_T((16, 3, 512, 512))) and torch.backends.cudnn.deterministic is False
+        torch.backends.cudnn.deterministic = prev
+        monkeypatch.setattr(r50, "CHANNELS_LAST_MODE", "auto")
+        for mode in (None, False):
+            monkeypatch.setattr(r50, "DETERMINISTIC", mode)
+            assert r50.pass_rows(_T((6, 3, 512, 512))) is None                # outside the mode the caller's batch is the pass
+        assert r50.pass_rows(_T((6, 3, 512, 512), cuda=False)) is None
+    # the chunking itself (CPU tensors, the plan injected): every pass has exactly `rows` rows, pads are dropped, tuples work
+    seen = []
+
+    def fn(c):
+        seen.append(int(c.shape[0]))
+        return c.sum(dim=(1, 2, 3)), c * 2.0
+
+    x = torch.arange(6 * 3 * 2 * 2, dtype=torch.float32).reshape(6, 3, 2, 2)
+    monkeypatch.setattr(r50, "pass_rows", lambda t: 4)
+    pads0 = r50.PASS_STATS["pad_rows"]
+    a, b = r50.run_rows(fn, x)
+    assert seen == [4, 4] and r50.PASS_STATS["pad_rows"] - pads0 == 2
+    assert torch.equal(a, x.sum(dim=(1, 2, 3))) and torch.equal(b, x * 2.0)
+    seen.clear()
+    assert torch.equal(r50.run_rows(lambda c: c + 1.0, x[:4]), x[:4] + 1.0)      # a full pass is handed over as it is
+    monkeypatch.setattr(r50, "pass_rows", lambda t: None)
+    assert torch.equal(r50.run_rows(lambda c: c + 1.0, x), x + 1.0)
+
+
+def test_missing_shipped_data_warns_once_and_names_the_remedy(monkeypatch, tmp_path):
+    """the tuned find database and the GEMM rank table exist for one (architecture, CU count, HIP
+    version) key; on any other box the steps ran ~10 % slower without a word.  Now one RuntimeWarning per process and kind
+    names the key looked for, the keys shipped and the tool that writes the data; the per-step summary lists the sizes
+    whose trunk passes fell to NCHW."""
+    import warnings
+    from irn_amd.step import _common
+    from irn_amd.net import resnet50 as r50
+    monkeypatch.setattr(_common, "miopen_cache_key", lambda: "gfx999-cu1-hip0.0")
+    monkeypatch.setattr(_common, "_WARNED", set())
+    monkeypatch.delenv("IRN_DETERMINISTIC", raising=False)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        rep = _common.warn_missing_shipped_data()
+        _common.warn_missing_shipped_data()                                    # once per process
+    assert rep["miopen"] is False and rep["gemm"] is False and rep["mode_key"] == "gfx999-cu1-hip0.0-det"
+    msgs = [str(x.message) for x in w if issubclass(x.category, RuntimeWarning)]
+    assert len(msgs) == 2
+    mi = [m for m in msgs if "MIOpen" in m][0]
+    ge = [m for m in msgs if "GEMM rank table" in m][0]
+    assert "gfx999-cu1-hip0.0-det" in mi and "gfx950-cu256-hip7.0.51831-det" in mi and "tools/miopen_warmup.py" in mi and "miopen_det_filter" in mi
+    assert "gfx999-cu1-hip0.0" in ge and "gfx950-cu256-hip7.0.51831" in ge and "tools/conv1x1_tune.py" in ge
+    # the shipped key itself: nothing to say
+    monkeypatch.setattr(_common, "miopen_cache_key", lambda: "gfx950-cu256-hip7.0.51831")
+    monkeypatch.setattr(_common, "_WARNED", set())
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        rep = _common.warn_missing_shipped_data()
+    assert rep["miopen"] and rep["gemm"] and not [x for x in w if issubclass(x.category, RuntimeWarning)]
+    # miopen_setup is where every worker / rank / in-process step passes: it warns too
+    monkeypatch.setattr(_common, "miopen_cache_key", lambda: "gfx999-cu1-hip0.0")
+    monkeypatch.setattr(_common, "_WARNED", set())
+    monkeypatch.setattr(_common, "_MIOPEN_LOCKS", [])
+    for k in ("IRN_MIOPEN_DB_SET", "IRN_MIOPEN_BASE", "MIOPEN_USER_DB_PATH"):
+        monkeypatch.delenv(k, raising=False)
+    monkeypatch.setenv("IRN_MIOPEN_CACHE", str(tmp_path))
+    saved = (torch.backends.cudnn.deterministic, r50.DETERMINISTIC)
+    try:
+        with pytest.warns(RuntimeWarning, match="no tuned MIOpen find database for 'gfx999-cu1-hip0.0-det'"):
+            _common.miopen_setup(0)
+    finally:
+        torch.backends.cudnn.deterministic, r50.DETERMINISTIC = saved
+    # step summary: NCHW passes by size, then reset
+    monkeypatch.setattr(r50, "PASS_STATS", {"channels_last": 5, "nchw": 3, "pad_rows": 4, "nchw_sizes": {"281x500": 2, "96x112": 1}})
+    line = _common.untuned_report()
+    assert "3 of 8 trunk passes ran NCHW" in line and "281x500 x2" in line and "96x112 x1" in line and "4 zero rows" in line
+    assert _common.untuned_report() == "" and r50.PASS_STATS["nchw"] == 0
+    line = _common.startup_line(3, 8, 0, "/db")
+    assert "worker 3/8" in line and "NOT SHIPPED" in line and "reproducible" in line
+
+
 def test_edge_store_keys_and_cap(tmp_path):
     """step/_common.EdgeStore: the boundary / displacement maps one label step leaves for the other are keyed by network,
     forward geometry and image FILE; another checkpoint, another image under the same name (new mtime / size) or another
