@@ -51,6 +51,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8 TB/s peak (6.3 TB/s achievable)
 FP32_VECTOR_PEAK_TFLOPS = 157.3   # same guide: fp32 vector FMA peak, 256 CUs x 128 lanes x 2 flop x 2.4 GHz
+FP32_MATRIX_PEAK_TFLOPS = 157.3   # same guide: dense fp32 MFMA peak (equal to the vector peak on gfx950)
 N_DIRS = {5: 34, 10: 152}
 METRIC = "images/sec for CAM+random-walk label gen, VOC12 512^2"
 
@@ -222,11 +223,45 @@ def cpu_baseline(a, workload, n_images, seed0, gpu_labels=None):
         tot["criterion"] = "a pixel may differ only where the two best entries of the oracle's normalised score stack are closer than 1e-4"
         res["label_parity"] = tot
     try:
+        res["cam"] = cpu_baseline_cam(threads)
+    except Exception as e:
+        res["cam"] = {"error": repr(e)[:200]}
+    try:
         res["reference_algorithm"] = reference_algorithm_baseline(radius, beta, exp_times, h, seed0, threads,
                                                                   [int(g) for g in a.ref_grids.split(",") if g])
     except Exception as e:                                   # never lose the bench line to the baseline
         res["reference_algorithm"] = {"error": repr(e)[:200]}
     return res
+
+
+def cpu_baseline_cam(threads):
+    """The CAM half of the metric on the host cores: the reference's `CAM.forward` (net/resnet50_cam.py:55-70, restated as
+    plain torch functional ops in oracle/cam_ref.py and pinned bit for bit on the reference's own output) over the four
+    scales + flips of ONE 512x512 image — what step/make_cam.py:26-37 runs per image before its merge — with seeded random
+    weights of the architecture.  Bounded: one image (974 GFLOP), a few seconds on a host with many cores."""
+    from irn_amd import synth
+    from irn_amd.net import weights
+    from oracle import cam_ref
+    torch.set_num_threads(threads)
+    sd = weights.random_cam_state(1)
+    img = torch.from_numpy(synth.photo(512, 512, seed=1234)).permute(2, 0, 1).float().div_(255.0)
+    scales = (1.0, 0.5, 1.5, 2.0)
+    pairs = []
+    for sc in scales:
+        hs = int(round(512 * sc))
+        x = torch.nn.functional.interpolate(img[None], (hs, hs), mode="bicubic", align_corners=False)[0]
+        pairs.append(torch.stack([x, x.flip(-1)]))
+    with torch.no_grad():
+        cam_ref.cam_forward(sd, pairs[1])                                    # warm (threads, allocator): the 256^2 pair
+        t0 = time.perf_counter()
+        for x in pairs:
+            cam_ref.cam_forward(sd, x)
+        dt = time.perf_counter() - t0
+    gflop = sum(cam_ref.flops_per_pair(int(round(512 * sc)), int(round(512 * sc))) for sc in scales) / 1e9
+    return {"value": 1.0 / dt, "unit": "images/s", "cores": threads, "kind": "port",
+            "seconds_per_image": dt, "gflop_per_image": gflop, "host_tflops": gflop / dt / 1e3,
+            "sample": "1 image of 512x512: CAM.forward on 4 scales x (image, flip), torch CPU fp32, %d threads, %.2f s "
+                      "(oracle/cam_ref.py = net/resnet50_cam.py:55-70 + net/resnet50.py:17-108); compare with legs.cam" % (threads, dt)}
 
 
 def reference_algorithm_baseline(radius, beta, exp_times, grid_target, seed0, threads, grids):
@@ -459,6 +494,14 @@ def run_backbone(a, workload, rank, world, device, dist, parallel, steps, warmup
 
     elapsed, _ = timed_loop(step, steps, warmup, dist, parallel, device)
     out = {"value": steps * batch * world / elapsed, "ms_per_step": 1e3 * elapsed / steps, "batch": batch, "scales": scales}
+    # convolution flops per image (counted on meta tensors: nothing is computed) against the fp32 matrix peak: the backbones
+    # are library kernels (MIOpen, hipBLASLt), so this is a utilisation figure, not a roofline claim of a kernel of ours
+    try:
+        gflop = backbone_gflop_per_image(scales, H, workload == "e2e")
+        out["gflop_per_image"] = gflop
+        out["matrix_fp32_frac"] = gflop * 1e9 * (steps * batch / elapsed) / (FP32_MATRIX_PEAK_TFLOPS * 1e12)
+    except Exception as e:                  # noqa: BLE001
+        out["gflop_per_image"] = {"error": repr(e)[:120]}
     # which trunk ran (a silent fall-back to NCHW / to the unfused 1x1 convolutions would just look slow)
     from irn_amd.net import resnet50 as _r50
     with torch.no_grad():
@@ -474,6 +517,35 @@ def run_backbone(a, workload, rank, world, device, dist, parallel, steps, warmup
         if out["walk_fallback_runs"] and not a.allow_walk_fallback:
             raise RuntimeError("e2e leg: %d walk batch(es) fell back to the streaming sweeps" % out["walk_fallback_runs"])
     return out
+
+
+_GFLOP = {}
+
+
+def backbone_gflop_per_image(scales, size, with_irn):
+    """Multiply-add flops (2 per MAC) of the product's own networks per image: CAM on every scale x (image, flip), plus the
+    EdgeDisplacement pass on the 512x512 crop pair for `e2e` — 974.0 + 149.6 GFLOP.  Counted by PyTorch's flop counter on META
+    tensors (shapes only, no arithmetic, no GPU)."""
+    key = (tuple(scales), size, with_irn)
+    if key not in _GFLOP:
+        from torch.utils.flop_counter import FlopCounterMode
+        from irn_amd.net import resnet50_cam, resnet50_irn
+        total = 0
+        with torch.no_grad():
+            with torch.device("meta"):
+                cam = resnet50_cam.CAM().eval()
+                irn = resnet50_irn.EdgeDisplacement().eval() if with_irn else None
+            for sc in scales:
+                hs = int(round(size * sc))
+                with FlopCounterMode(display=False) as fc:
+                    cam(torch.empty(2, 3, hs, hs, device="meta"))
+                total += fc.get_total_flops()
+            if irn is not None:
+                with FlopCounterMode(display=False) as fc:
+                    irn(torch.empty(2, 3, size, size, device="meta"))
+                total += fc.get_total_flops()
+        _GFLOP[key] = total / 1e9
+    return _GFLOP[key]
 
 
 def run_steps(a, rank, world, device, dist, parallel, steps, warmup, batch=0, voc_sizes=False):
@@ -736,6 +808,10 @@ def main(argv=None):
                          (rank, ordinal, torch.cuda.device_count()))
     torch.cuda.set_device(ordinal)
     device = torch.device("cuda", ordinal)
+    if world > 1:          # one line per rank: which device, which shipped data it found (an 8-GPU node met for the first time)
+        from irn_amd.step import _common
+        print(_common.startup_line(rank, world, ordinal, os.environ.get("MIOPEN_USER_DB_PATH") or "(claimed at the first backbone pass)"),
+              file=sys.stderr, flush=True)
     # nccl == RCCL on ROCm.  The data path has no collective — the group only serves the contract's barrier and
     # max-over-ranks — so an RCCL start-up that fails or hangs must not cost the line: `auto` probes it under a deadline,
     # the ranks agree over a gloo control group, and the line says which backend served it
@@ -769,7 +845,7 @@ def main(argv=None):
             res["config"].update({"variant": a.variant, "mean_channels": float(np.mean([s[2] for s in r["shapes"]])),
                                   "walk_self_checks": r.get("tuning")})
             res["label_checksum"] = r["label_checksum"]
-        for k in ("detections_per_image", "fallback_runs", "rounds", "walk_fallback_runs", "trunk", "cam_trunk_passes", "cam_store_hits", "cam_store_misses", "edge_store_hits", "loader_workers", "pass_seconds", "instance_files", "through"):
+        for k in ("detections_per_image", "fallback_runs", "rounds", "walk_fallback_runs", "trunk", "cam_trunk_passes", "cam_store_hits", "cam_store_misses", "edge_store_hits", "loader_workers", "pass_seconds", "instance_files", "through", "gflop_per_image", "matrix_fp32_frac"):
             if k in r:
                 res["config"][k] = r[k]
         res["cpu_baseline"] = None
@@ -793,7 +869,7 @@ def main(argv=None):
                     if "shapes" in lr:
                         ro = roofline_object(a, name, lr)
                         legs[name]["fp32_vector_frac"] = ro["frac"] if ro.get("bound") == "fp32_vector" else ro["fp32_vector"]["frac"]
-                    for k in ("detections_per_image", "fallback_runs", "rounds", "grid_pixels", "walk_fallback_runs", "trunk", "cam_trunk_passes", "cam_store_hits", "cam_store_misses", "edge_store_hits", "loader_workers", "pass_seconds", "instance_files", "setup_seconds", "through", "n_applied"):
+                    for k in ("detections_per_image", "fallback_runs", "rounds", "grid_pixels", "walk_fallback_runs", "trunk", "cam_trunk_passes", "cam_store_hits", "cam_store_misses", "edge_store_hits", "loader_workers", "pass_seconds", "instance_files", "setup_seconds", "through", "n_applied", "gflop_per_image", "matrix_fp32_frac"):
                         if k in lr:
                             legs[name][k] = lr[k]
                 except Exception as e:                      # a leg must never cost the headline line

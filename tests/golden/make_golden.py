@@ -159,6 +159,13 @@ WALK_CASES = [
     ("r5_b10_e8_rand", 32, 32, 3, 5, 10, 8, 9),      # iid-random edge (the SURVEY probe input)
     ("r5_b10_e8_ck", 28, 36, 6, 5, 10, 8, 10),       # 4-D x [C,K,h,w] like the instance path
     ("r5_b10_e8_64", 64, 64, 3, 5, 10, 8, 11),
+    # round 6, the degenerate corner on the reference itself (misc/indexing.py:123-126,135: an isolated pixel keeps a non-zero
+    # column sum only through the unit diagonal): 0/1 Bernoulli edges (affinities exactly 0 or 1), and edge = 1 on a block
+    # larger than the radius (every pixel inside has no neighbour at all)
+    ("r5_b10_e8_bern", 32, 32, 3, 5, 10, 8, 12),
+    ("r10_b10_e8_bern", 32, 32, 2, 10, 10, 8, 13),
+    ("r5_b10_e8_block", 40, 36, 3, 5, 10, 8, 14),
+    ("r10_b10_e8_block", 40, 44, 2, 10, 10, 8, 15),
 ]
 
 
@@ -192,9 +199,15 @@ def gen_walk(only=None, cases=None, fname="walk.npz"):
             g = torch.Generator().manual_seed(seed)
             edge = torch.sigmoid(2 * torch.randn(1, h, w, generator=g))
             cam = torch.rand(C, h, w, generator=g)
+        elif name.endswith("_bern"):
+            g = torch.Generator().manual_seed(seed)
+            edge = (torch.rand(1, h, w, generator=g) < 0.3).float()
+            cam = torch.from_numpy(synth.cam_blobs(C, h, w, seed=seed))
         else:
             edge = torch.from_numpy(synth.edge_field(h, w, seed=seed))[None]
             cam = torch.from_numpy(synth.cam_blobs(C, h, w, seed=seed))
+            if name.endswith("_block"):
+                edge[0, 8:8 + 2 * r + 4, 6:6 + 2 * r + 2] = 1.0
         x = cam
         if name.endswith("_ck"):
             x = cam.view(2, C // 2, h, w)

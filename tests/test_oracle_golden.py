@@ -285,3 +285,21 @@ def test_trunk_tails_vs_reference_modules(golden):
         close(O.stem_pool(g["stem_x_" + tag], s, b), g["stem_out_" + tag])
     for tag in ("u2", "u4", "u2b"):
         close(O.head_upsample_relu(g["up_x_" + tag], int(g["up_f_" + tag])), g["up_out_" + tag], 3e-7)
+
+
+def test_cam_ref_is_the_reference_forward_bit_for_bit(golden):
+    """oracle/cam_ref.py (bench.py's `cpu_baseline.cam`): the functional restatement of net/resnet50.py:17-108 +
+    net/resnet50_cam.py:55-70 gives the reference's own output on the reference's input with the same seeded weights —
+    max-abs 0.0, not a tolerance; its flop count is what the product's networks count on meta tensors."""
+    import torch
+    from irn_amd.net import weights
+    from oracle import cam_ref
+    g = golden("nets")
+    with torch.no_grad():
+        y = cam_ref.cam_forward(weights.random_cam_state(seed=1), torch.from_numpy(g["cam_in"]))
+    assert y.shape == g["cam_out"].shape and np.array_equal(y.numpy(), g["cam_out"])
+    gflop = sum(cam_ref.flops_per_pair(s, s) for s in (512, 256, 768, 1024)) / 1e9
+    assert abs(gflop - 974.04) < 0.01
+    import bench
+    assert abs(bench.backbone_gflop_per_image((1.0, 0.5, 1.5, 2.0), 512, False) - gflop) < 1e-6
+    assert abs(bench.backbone_gflop_per_image((1.0, 0.5, 1.5, 2.0), 512, True) - gflop - 149.61) < 0.01
