@@ -287,6 +287,31 @@ int irn_conv1x1_nhwc(const float *x_dev, const float *w_dev, const float *bias_d
                      int64_t m, int cin, int cout, int relu, int algo_rank, void *workspace_dev, size_t workspace_bytes,
                      void *stream);
 
+/* Split-precision form of the same layers (round 6): the fp32 GEMM runs at <= 0.9 of the 157 TFLOP/s fp32 matrix peak; an fp16
+ * MFMA GEMM with fp32 accumulation runs ~2.5x faster over a 3x longer K, and two fp16 numbers carry 22 mantissa bits:
+ *       x = x_hi + 2^-11 x_lo',  x_hi = fp16(x),  x_lo' = fp16((x - x_hi) 2^11)          (irn_split16, per element)
+ *       x . w ~ x_hi w_hi + x_hi w_lo + x_lo' (w_hi 2^-11)                                (the dropped term: 2^-22 |x w|)
+ * Measured on every 1x1 layer of the CAM network: 5.4e-6 / 9.2e-6 from fp64 on the normalised CAM where the fp32 GEMMs give
+ * 5.9e-6 / 7.6e-6 (tools/bf16x3_cam_error.py; bar 1e-4); per layer 3.4e-7 .. 1.9e-6 against 2.6e-7 .. 1.3e-6 (profiles/r06_s2_*).
+ * Same reference lines as irn_conv1x1_nhwc (net/resnet50.py:34-54).
+ *
+ * irn_split16: x dev fp32 [n_pixels, n_channels] (channels-last activation, n_channels a multiple of 8, 16-byte aligned)
+ *   -> out dev fp16 [n_pixels, 3 n_channels] = [hi | hi | lo'] per pixel.  With scale / shift (dev fp32 [n_channels], both or
+ *   neither) the element is first y = x * scale[c] + shift[c] (one fmaf, the FixedBatchNorm of the 3x3 convolution in front,
+ *   net/resnet50.py:40-42) and, with relu, max(y, 0) — the fp32 tensor is read once and never written back.  overflow_dev
+ *   (dev uint32, may be NULL) has bit 0 set when an element was beyond fp16's range (|y| > 65504) or NaN: the caller's
+ *   signal that this activation needs the fp32 path.
+ * irn_gemm16_nhwc: a16 dev fp16 [m, k] (irn_split16's output, k = 3 cin), b16 dev fp16 [cout, k] = [w_hi | w_lo | w_hi 2^-11] of
+ *   the batch-norm-folded weight scaled by 2^p (prepared by the caller in double precision), alpha = 2^-p:
+ *       out = act(alpha a16 . b16^T + bias (+ residual)),  fp32 [m, cout]; algo_rank / workspace as irn_conv1x1_nhwc. */
+int irn_split16(const float *x_dev, const float *scale_dev, const float *shift_dev, int relu, void *out_dev, int64_t n_pixels,
+                int n_channels, unsigned *overflow_dev, void *stream);
+int irn_gemm16_algo_count(int64_t m, int k, int cout, int has_bias, int has_residual, int relu, size_t workspace_bytes,
+                          int *count_out);
+int irn_gemm16_nhwc(const void *a16_dev, const void *b16_dev, const float *bias_dev, const float *residual_dev, float *out_dev,
+                    int64_t m, int k, int cout, int relu, float alpha, int algo_rank, void *workspace_dev, size_t workspace_bytes,
+                    void *stream);
+
 /* Stem: batch norm + ReLU + max pool 3x3 / stride 2 / pad 1 in one pass (reference net/resnet50.py:94-97; the nets'
  * stage1, net/resnet50_cam.py:14, net/resnet50_irn.py:15).
  *   x dev fp32 [n_images, n_channels, h, w] (conv1's output) -> out dev fp32 [n_images, n_channels, (h-1)/2+1, (w-1)/2+1]

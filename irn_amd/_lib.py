@@ -62,6 +62,9 @@ _SIGS = {
     "irn_conv1x1_workspace_bytes": (sz, []),
     "irn_conv1x1_algo_count": (i32, [i64, i32, i32, i32, i32, i32, sz, C.POINTER(i32)]),
     "irn_conv1x1_nhwc": (i32, [vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, vp, sz, vp]),
+    "irn_split16": (i32, [vp, vp, vp, i32, vp, i64, i32, vp, vp]),
+    "irn_gemm16_algo_count": (i32, [i64, i32, i32, i32, i32, i32, sz, C.POINTER(i32)]),
+    "irn_gemm16_nhwc": (i32, [vp, vp, vp, vp, vp, i64, i32, i32, i32, f32, i32, vp, sz, vp]),
     "irn_stem_pool": (i32, [vp, vp, vp, i64, i32, i32, i32, vp, vp]),
     "irn_upsample_bilinear": (i32, [vp, i64, i32, i32, i32, i32, vp, vp]),
     "irn_find_centroids": (i32, [vp, i32, i32, i32, vp, vp]),

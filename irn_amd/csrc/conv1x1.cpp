@@ -32,8 +32,8 @@ struct Plan {
     int n_algos = 0;
 };
 
-// (device, m, cin, cout, bias, residual, relu, workspace)
-using Key = std::tuple<int, int64_t, int, int, int, int, int, size_t>;
+// (device, m, cin, cout, bias, residual, relu, workspace, operand type: 0 fp32 / 1 fp16)
+using Key = std::tuple<int, int64_t, int, int, int, int, int, size_t, int>;
 
 std::mutex g_mu;
 std::map<int, hipblasLtHandle_t> g_handles;
@@ -74,8 +74,9 @@ int epilogue_of(bool bias, bool relu) {
 
 // caller holds g_mu
 int get_plan(hipblasLtHandle_t handle, int dev, int64_t m, int cin, int cout, bool bias, bool residual, bool relu,
-             size_t workspace_bytes, Plan **out) {
-    Key key(dev, m, cin, cout, bias, residual, relu, workspace_bytes);
+             size_t workspace_bytes, Plan **out, int f16 = 0) {
+    Key key(dev, m, cin, cout, bias, residual, relu, workspace_bytes, f16);
+    const hipDataType ab_type = f16 ? HIP_R_16F : HIP_R_32F;      // operands; C / D / bias / scale stay fp32, fp32 accumulation
     auto it = g_plans.find(key);
     if (it != g_plans.end()) {
         *out = it->second;
@@ -99,8 +100,8 @@ int get_plan(hipblasLtHandle_t handle, int dev, int64_t m, int cin, int cout, bo
         IRN_LT_TRY(hipblasLtMatmulDescSetAttribute(p->desc, HIPBLASLT_MATMUL_DESC_BIAS_DATA_TYPE, &bt, sizeof bt));
     }
     // stored shapes (column-major): A = w [cin x cout], B = x [cin x m], C / D = [cout x m]
-    IRN_LT_TRY(hipblasLtMatrixLayoutCreate(&p->a, HIP_R_32F, (uint64_t)cin, (uint64_t)cout, (int64_t)cin));
-    IRN_LT_TRY(hipblasLtMatrixLayoutCreate(&p->b, HIP_R_32F, (uint64_t)cin, (uint64_t)m, (int64_t)cin));
+    IRN_LT_TRY(hipblasLtMatrixLayoutCreate(&p->a, ab_type, (uint64_t)cin, (uint64_t)cout, (int64_t)cin));
+    IRN_LT_TRY(hipblasLtMatrixLayoutCreate(&p->b, ab_type, (uint64_t)cin, (uint64_t)m, (int64_t)cin));
     IRN_LT_TRY(hipblasLtMatrixLayoutCreate(&p->c, HIP_R_32F, (uint64_t)cout, (uint64_t)m, (int64_t)cout));
     IRN_LT_TRY(hipblasLtMatrixLayoutCreate(&p->d, HIP_R_32F, (uint64_t)cout, (uint64_t)m, (int64_t)cout));
     hipblasLtMatmulPreference_t pref = nullptr;
@@ -111,8 +112,8 @@ int get_plan(hipblasLtHandle_t handle, int dev, int64_t m, int cin, int cout, bo
     hipblasStatus_t st = hipblasLtMatmulAlgoGetHeuristic(handle, p->desc, p->a, p->b, p->c, p->d, pref, kMaxAlgos, p->algo, &found);
     (void)hipblasLtMatmulPreferenceDestroy(pref);
     if (st != HIPBLAS_STATUS_SUCCESS || found < 1) {
-        return fail(IRN_ERR_STATE, "hipBLASLt has no fp32 kernel for the 1x1 convolution m=%lld cin=%d cout=%d (status %d, %d found)",
-                    (long long)m, cin, cout, (int)st, found);
+        return fail(IRN_ERR_STATE, "hipBLASLt has no %s kernel for the 1x1 convolution m=%lld cin=%d cout=%d (status %d, %d found)",
+                    f16 ? "fp16 -> fp32" : "fp32", (long long)m, cin, cout, (int)st, found);
     }
     p->n_algos = found;
     g_plans[key] = owner.release();
@@ -170,6 +171,49 @@ int irn_conv1x1_nhwc(const float *x_dev, const float *w_dev, const float *bias_d
     const float alpha = 1.0f, beta = residual_dev ? 1.0f : 0.0f;
     const float *c = residual_dev ? residual_dev : out_dev;
     IRN_LT_TRY(hipblasLtMatmul(handle, p->desc, &alpha, w_dev, p->a, x_dev, p->b, &beta, c, p->c, out_dev, p->d, &p->algo[algo_rank].algo,
+                               workspace_dev, workspace_bytes, (hipStream_t)stream));
+    return IRN_OK;
+}
+
+// The split-precision form: a16 = [x_hi | x_hi | x_lo'] fp16 [m, k] (irn_split16, k = 3 cin), b16 = [w_hi | w_lo | w_hi 2^-11]
+// fp16 [cout, k]; one fp16 MFMA GEMM with fp32 accumulation, the same epilogue.
+int irn_gemm16_algo_count(int64_t m, int k, int cout, int has_bias, int has_residual, int relu, size_t workspace_bytes, int *count_out) {
+    using namespace irn;
+    if (!count_out) return fail(IRN_ERR_ARG, "gemm16_algo_count: count_out is NULL");
+    if (int rc = check_shape(m, k, cout)) return rc;
+    int dev = 0;
+    IRN_HIP_TRY(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lk(g_mu);
+    hipblasLtHandle_t handle;
+    if (int rc = get_handle(dev, &handle)) return rc;
+    Plan *p = nullptr;
+    if (int rc = get_plan(handle, dev, m, k, cout, has_bias != 0, has_residual != 0, relu != 0, workspace_bytes, &p, 1)) return rc;
+    *count_out = p->n_algos;
+    return IRN_OK;
+}
+
+int irn_gemm16_nhwc(const void *a16_dev, const void *b16_dev, const float *bias_dev, const float *residual_dev, float *out_dev,
+                    int64_t m, int k, int cout, int relu, float alpha, int algo_rank, void *workspace_dev, size_t workspace_bytes,
+                    void *stream) {
+    using namespace irn;
+    if (!a16_dev || !b16_dev || !out_dev) return fail(IRN_ERR_ARG, "gemm16: a, b and out must not be NULL");
+    if (int rc = check_shape(m, k, cout)) return rc;
+    if (k & 7) return fail(IRN_ERR_ARG, "gemm16: k = %d must be a multiple of 8 (16-byte rows)", k);
+    if (workspace_bytes && !workspace_dev) return fail(IRN_ERR_ARG, "gemm16: workspace_bytes > 0 with a NULL workspace");
+    int dev = 0;
+    IRN_HIP_TRY(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lk(g_mu);
+    hipblasLtHandle_t handle;
+    if (int rc = get_handle(dev, &handle)) return rc;
+    Plan *p = nullptr;
+    if (int rc = get_plan(handle, dev, m, k, cout, bias_dev != nullptr, residual_dev != nullptr, relu != 0, workspace_bytes, &p, 1)) return rc;
+    if (algo_rank < 0 || algo_rank >= p->n_algos)
+        return fail(IRN_ERR_ARG, "gemm16: algo_rank %d outside hipBLASLt's list of %d for m=%lld k=%d cout=%d", algo_rank, p->n_algos,
+                    (long long)m, k, cout);
+    if (bias_dev) IRN_LT_TRY(hipblasLtMatmulDescSetAttribute(p->desc, HIPBLASLT_MATMUL_DESC_BIAS_POINTER, &bias_dev, sizeof bias_dev));
+    const float beta = residual_dev ? 1.0f : 0.0f;
+    const float *c = residual_dev ? residual_dev : out_dev;
+    IRN_LT_TRY(hipblasLtMatmul(handle, p->desc, &alpha, b16_dev, p->a, a16_dev, p->b, &beta, c, p->c, out_dev, p->d, &p->algo[algo_rank].algo,
                                workspace_dev, workspace_bytes, (hipStream_t)stream));
     return IRN_OK;
 }

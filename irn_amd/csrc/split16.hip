@@ -1,0 +1,87 @@
+// fp16 hi/lo split of a channels-last fp32 activation: the A operand of the split-precision 1x1 convolutions
+// (irn_gemm16_nhwc, conv1x1.cpp; reference net/resnet50.py:34-54).
+//
+//     x = hi + 2^-11 lo',   hi = fp16(x),   lo' = fp16((x - hi) 2^11)            (11 + 11 mantissa bits)
+//     out[p, 0:c] = hi,  out[p, c:2c] = hi,  out[p, 2c:3c] = lo'                 (fp16 [n_pixels, 3c])
+//
+// The GEMM multiplies this row with [w_hi | w_lo | w_hi 2^-11] (prepared once per layer on the host, in fp64), i.e.
+// x_hi w_hi + x_hi w_lo + x_lo w_hi in one fp16 MFMA product over 3c with fp32 accumulation; the dropped term is
+// x_lo w_lo ~ 2^-22 |x w|.  Scaling lo' by 2^11 keeps it a NORMAL fp16 number for every |x| above 1.2e-4 (unscaled it
+// would be subnormal below |x| ~ 0.12).  With `scale` / `shift` the pass is the inference batch norm + ReLU of the 3x3
+// convolution in front (net/resnet50.py:40-42) at the same time: that convolution's output is read once as fp32 and
+// never written back.  HBM-bound: 4 bytes read, 6 written per element.
+#include "common.hpp"
+#include "kernels.hpp"
+
+namespace irn {
+namespace {
+
+typedef float f4v __attribute__((ext_vector_type(4)));
+typedef _Float16 h8v __attribute__((ext_vector_type(8)));
+constexpr int kThreads = 256;
+constexpr float kFp16Max = 65504.f;
+
+// one thread = 8 consecutive channels of one pixel: two 16-byte loads, three 16-byte stores
+template <bool BN, bool RELU>
+__global__ __launch_bounds__(kThreads) void split16_kernel(const float *__restrict__ x, const float *__restrict__ scale,
+                                                           const float *__restrict__ shift, _Float16 *__restrict__ out,
+                                                           unsigned n_pieces, unsigned n_ch, unsigned pieces_per_row,
+                                                           unsigned *__restrict__ overflow) {
+    const unsigned p = blockIdx.x * (unsigned)kThreads + threadIdx.x;
+    if (p >= n_pieces) return;
+    const unsigned row = p / pieces_per_row, c0 = (p - row * pieces_per_row) * 8u;
+    const f4v *src = reinterpret_cast<const f4v *>(x + (size_t)p * 8u);
+    f4v a = __builtin_nontemporal_load(src), b = __builtin_nontemporal_load(src + 1);
+    float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    if (BN) {
+        const f4v s0 = *reinterpret_cast<const f4v *>(scale + c0), s1 = *reinterpret_cast<const f4v *>(scale + c0 + 4);
+        const f4v t0 = *reinterpret_cast<const f4v *>(shift + c0), t1 = *reinterpret_cast<const f4v *>(shift + c0 + 4);
+        const float sc[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w}, sh[8] = {t0.x, t0.y, t0.z, t0.w, t1.x, t1.y, t1.z, t1.w};
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            float y = fmaf(v[k], sc[k], sh[k]);          // the same fmaf as irn_bn_act_nhwc
+            if (RELU) y = y < 0.f ? 0.f : y;
+            v[k] = y;
+        }
+    }
+    h8v hi, lo;
+    bool bad = false;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const _Float16 h = (_Float16)v[k];
+        hi[k] = h;
+        lo[k] = (_Float16)((v[k] - (float)h) * 2048.f);
+        bad |= !(fabsf(v[k]) <= kFp16Max);               // beyond fp16's range, or NaN
+    }
+    _Float16 *dst = out + (size_t)row * (3u * n_ch) + c0;
+    *reinterpret_cast<h8v *>(dst) = hi;
+    *reinterpret_cast<h8v *>(dst + n_ch) = hi;
+    *reinterpret_cast<h8v *>(dst + 2u * n_ch) = lo;
+    if (bad && overflow) atomicOr(overflow, 1u);
+}
+
+}  // namespace
+}  // namespace irn
+
+extern "C" int irn_split16(const float *x_dev, const float *scale_dev, const float *shift_dev, int relu, void *out_dev,
+                           int64_t n_pixels, int n_channels, unsigned *overflow_dev, void *stream) {
+    using namespace irn;
+    if (!x_dev || !out_dev) return fail(IRN_ERR_ARG, "irn_split16: null pointer");
+    if ((scale_dev != nullptr) != (shift_dev != nullptr)) return fail(IRN_ERR_ARG, "irn_split16: scale and shift come together");
+    if (relu && !scale_dev) return fail(IRN_ERR_ARG, "irn_split16: relu only with the batch norm in front of it");
+    if (n_pixels < 0 || n_channels <= 0 || (n_channels & 7)) return fail(IRN_ERR_ARG, "irn_split16: n_channels must be a positive multiple of 8");
+    if (((uintptr_t)x_dev | (uintptr_t)out_dev | (uintptr_t)scale_dev | (uintptr_t)shift_dev) & 15u)
+        return fail(IRN_ERR_ARG, "irn_split16: tensors and constants must be 16-byte aligned");
+    const int64_t numel = n_pixels * n_channels;
+    if (numel == 0) return IRN_OK;
+    if (numel >= (1ll << 31)) return fail(IRN_ERR_ARG, "irn_split16: %lld elements; at most 2^31 - 1 per call", (long long)numel);
+    const unsigned n_pieces = (unsigned)(numel / 8), ppr = (unsigned)n_channels / 8u;
+    const dim3 grid((n_pieces + kThreads - 1) / kThreads), block(kThreads);
+    hipStream_t s = (hipStream_t)stream;
+    _Float16 *out = (_Float16 *)out_dev;
+    if (!scale_dev) hipLaunchKernelGGL((split16_kernel<false, false>), grid, block, 0, s, x_dev, scale_dev, shift_dev, out, n_pieces, (unsigned)n_channels, ppr, overflow_dev);
+    else if (relu) hipLaunchKernelGGL((split16_kernel<true, true>), grid, block, 0, s, x_dev, scale_dev, shift_dev, out, n_pieces, (unsigned)n_channels, ppr, overflow_dev);
+    else hipLaunchKernelGGL((split16_kernel<true, false>), grid, block, 0, s, x_dev, scale_dev, shift_dev, out, n_pieces, (unsigned)n_channels, ppr, overflow_dev);
+    IRN_LAUNCH_CHECK("split16_kernel");
+    return IRN_OK;
+}

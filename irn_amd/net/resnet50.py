@@ -168,6 +168,19 @@ def _fused(x):
 FUSED_GEMM = os.environ.get("IRN_FUSED_GEMM", "1") != "0"
 
 
+# Split-precision form of those GEMMs (round 6, include/irn_hip.h irn_split16 / irn_gemm16_nhwc): fp16 hi/lo operands carry 22
+# mantissa bits, the fp16 matrix pipe is ~2.5x faster over a 3x longer K, and the result is as close to fp64 as the fp32 GEMM's
+# (tools/bf16x3_cam_error.py: 5.4e-6 / 9.2e-6 on the normalised CAM against 5.9e-6 / 7.6e-6).  IRN_SPLIT_GEMM=0 switches it off.
+#   conv3's operand comes out of the 3x3 convolution's own tail (batch norm + ReLU + split in ONE pass, nothing extra): every
+#       unit with at least SPLIT_MIN_PLANES planes;
+#   conv1's / the stride-1 shortcut's operand is the block input, which must also stay fp32 (it is the residual): a split pass
+#       of its own (10 bytes per element), worth it only where the GEMMs it feeds are large — cin * (sum of their cout) >=
+#       SPLIT_MIN_INPUT (stage 4 of the trunk; profiles/r06_s2_split_gemm_fp16_note.txt).
+SPLIT_GEMM = os.environ.get("IRN_SPLIT_GEMM", "1") != "0"
+SPLIT_MIN_PLANES = int(os.environ.get("IRN_SPLIT_MIN_PLANES", "64"))
+SPLIT_MIN_INPUT = int(os.environ.get("IRN_SPLIT_MIN_INPUT", str(1 << 20)))
+
+
 def _gemm_path(x):
     """A bottleneck's 1x1 convolutions run as hipBLASLt GEMMs with a fused epilogue when its input is a channels-last
     activation on the inference path (the layout in which the activation IS the GEMM's operand)."""
@@ -296,11 +309,12 @@ class Bottleneck(nn.Module):
         key = tuple((t.data_ptr(), _version(t)) for t in src)
         if self._gemm is None or self._gemm[0] != key:
             with torch.no_grad():
-                folded = []
+                folded, folded64 = [], []
                 for c, b in zip(convs, bns):
                     scale = b.weight.detach().double() / torch.sqrt(b.running_var.detach().double() + b.eps)
                     shift = b.bias.detach().double() - b.running_mean.detach().double() * scale
-                    folded.append(((c.weight.detach().double() * scale.view(-1, 1, 1, 1)).float().contiguous(), shift))
+                    folded64.append(c.weight.detach().double() * scale.view(-1, 1, 1, 1))
+                    folded.append((folded64[-1].float().contiguous(), shift))
                 p = {"w1": folded[0][0].flatten(1), "b1": folded[0][1].float().contiguous(), "w3": folded[1][0].flatten(1)}
                 # the 3x3 weight in the layout MIOpen's NHWC solvers take: PyTorch otherwise re-lays it out on EVERY call
                 # (1.7 % of the e2e GPU time in strided copy kernels, profiles/r05_s15_e2e_kernel_classes.txt)
@@ -310,6 +324,19 @@ class Bottleneck(nn.Module):
                 else:
                     p["wd"] = folded[2][0].contiguous(memory_format=torch.channels_last)   # [cout, cin, 1, 1]: also MIOpen's operand when strided
                     p["b3"] = (folded[1][1] + folded[2][1]).float().contiguous()
+                if SPLIT_GEMM and self.conv1.weight.is_cuda:
+                    # fp16 hi/lo operands of the split-precision GEMMs, from the weights folded in double precision; bn2's
+                    # constants ride in the split pass that feeds conv3
+                    from .. import ops
+                    planes, cin = self.conv3.weight.shape[1], self.conv1.weight.shape[1]
+                    couts = self.conv1.weight.shape[0] + (self.downsample[0].weight.shape[0] if self.downsample is not None and tuple(self.downsample[0].stride) == (1, 1) else 0)
+                    if planes >= SPLIT_MIN_PLANES:
+                        p["w3_16"], p["a3"] = ops.split_weight(folded64[1].flatten(1))
+                        p["s2"], p["t2"] = self.bn2.folded()
+                    if cin * couts >= SPLIT_MIN_INPUT and cin % 8 == 0:
+                        p["w1_16"], p["a1"] = ops.split_weight(folded64[0].flatten(1))
+                        if self.downsample is not None and tuple(self.downsample[0].stride) == (1, 1):
+                            p["wd_16"], p["ad"] = ops.split_weight(folded64[2].flatten(1))
             self._gemm = (key, p)
         return self._gemm[1]
 
@@ -329,18 +356,31 @@ class Bottleneck(nn.Module):
         left around them; the 3x3 convolution stays on MIOpen with its one in-place `bn_act_` pass."""
         from .. import ops
         p = self.gemm_params()
-        y = ops.conv1x1_nhwc(x, p["w1"], p["b1"], relu=True)
+        x3 = ops.split16(x) if "w1_16" in p else None                     # the block input as fp16 hi/lo (it stays fp32 too: the residual)
+        if x3 is not None:
+            y = ops.gemm16_nhwc(x3, p["w1_16"], (x.shape[0], p["w1"].shape[0], x.shape[2], x.shape[3]), p["b1"], relu=True, alpha=p["a1"])
+        else:
+            y = ops.conv1x1_nhwc(x, p["w1"], p["b1"], relu=True)
         c2 = self.conv2
-        y = self.bn2.apply_(F.conv2d(y, p["w2"], None, c2.stride, c2.padding, c2.dilation, c2.groups), relu=True)
+        y = F.conv2d(y, p["w2"], None, c2.stride, c2.padding, c2.dilation, c2.groups)
         y = y.contiguous(memory_format=torch.channels_last)
-        if self.downsample is None:
-            return ops.conv1x1_nhwc(y, p["w3"], p["b3"], residual=x, relu=True)
-        ds = self.downsample[0]
-        if tuple(ds.stride) == (1, 1):
-            sc = ops.conv1x1_nhwc(x, p["wd"].reshape(p["wd"].shape[0], -1))
-        else:                   # a strided shortcut is not a matrix view of x: MIOpen, with the folded weight
-            sc = F.conv2d(x, p["wd"], None, ds.stride).contiguous(memory_format=torch.channels_last)
-        return ops.conv1x1_nhwc(y, p["w3"], p["b3"], residual=sc, relu=True, out=sc)
+        ds = self.downsample[0] if self.downsample is not None else None
+        sc = None
+        if ds is not None:
+            if tuple(ds.stride) != (1, 1):      # a strided shortcut is not a matrix view of x: MIOpen, with the folded weight
+                sc = F.conv2d(x, p["wd"], None, ds.stride).contiguous(memory_format=torch.channels_last)
+            elif "wd_16" in p:
+                sc = ops.gemm16_nhwc(x3, p["wd_16"], (x.shape[0], p["wd"].shape[0], x.shape[2], x.shape[3]), alpha=p["ad"])
+            else:
+                sc = ops.conv1x1_nhwc(x, p["wd"].reshape(p["wd"].shape[0], -1))
+        res = x if ds is None else sc
+        if "w3_16" in p and y.shape[1] % 8 == 0:
+            # bn2 + ReLU + split in one pass over the 3x3 convolution's output, then ONE fp16 GEMM with the unit's whole tail
+            y3 = ops.split16(y, p["s2"], p["t2"], relu=True)
+            return ops.gemm16_nhwc(y3, p["w3_16"], (y.shape[0], p["w3"].shape[0], y.shape[2], y.shape[3]), p["b3"], residual=res, relu=True,
+                                   alpha=p["a3"], out=sc)
+        y = self.bn2.apply_(y, relu=True)
+        return ops.conv1x1_nhwc(y, p["w3"], p["b3"], residual=res, relu=True, out=sc)
 
 
 def _stage(c_in, planes, n_blocks, stride, dilation):

@@ -240,6 +240,103 @@ def conv1x1_nhwc(x, weight, bias=None, residual=None, relu=False, out=None, algo
     return out
 
 
+# ---- split-precision 1x1 convolutions (round 6): fp16 hi/lo operands, fp32 accumulation ----
+_SPLIT_FLAGS = {}      # device index -> uint32 [1] device tensor: bit 0 = an activation left fp16's range in irn_split16
+
+
+def _split_flag(device):
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    f = _SPLIT_FLAGS.get(idx)
+    if f is None:
+        f = _SPLIT_FLAGS[idx] = torch.zeros(1, dtype=torch.int32, device=device)
+    return f
+
+
+def split_overflowed(reset=True):
+    """Did any activation handed to `split16` since the last call exceed fp16's range (|x| > 65504) or hold a NaN, on any
+    device of this process?  Reads the device flags (synchronises).  The steps check it at the end of every step and raise:
+    such a network needs IRN_SPLIT_GEMM=0 (trained ResNet-50 activations stay below a few hundred)."""
+    bad = False
+    for f in _SPLIT_FLAGS.values():
+        if int(f.item()) != 0:
+            bad = True
+            if reset:
+                f.zero_()
+    return bad
+
+
+def split16(x, scale=None, shift=None, relu=False):
+    """fp32 channels-last activation [N, C, H, W] -> fp16 [N*H*W, 3C] = [hi | hi | lo'] per pixel (irn_split16), the A operand
+    of `gemm16_nhwc`; with `scale` / `shift` (fp32 [C]) the inference batch norm (+ ReLU) of the convolution that produced
+    `x` is applied on the way (reference net/resnet50.py:40-42) and `x` is never written back."""
+    _need_cuda(x, "x")
+    if x.dtype != torch.float32 or x.dim() != 4 or not x.is_contiguous(memory_format=torch.channels_last):
+        raise ValueError("split16: x must be a channels-last fp32 [N, C, H, W] tensor, got %s %s %s" % (x.dtype, tuple(x.shape), x.stride()))
+    n, c, h, w_ = (int(v) for v in x.shape)
+    if c % 8:
+        raise ValueError("split16: %d channels; a multiple of 8 is needed" % c)
+    m = n * h * w_
+    out = torch.empty((m, 3 * c), dtype=torch.float16, device=x.device)
+    if m == 0:
+        return out
+    for name, t in (("scale", scale), ("shift", shift)):
+        if t is not None and (t.dtype != torch.float32 or t.device != x.device or not t.is_contiguous() or t.numel() != c):
+            raise ValueError("split16: %s must be a contiguous fp32 [%d] tensor on %s" % (name, c, x.device))
+    with torch.cuda.device(x.device):
+        per = max(1, (2 ** 31 - 1) // c)
+        for i in range(0, m, per):                       # at most 2^31 - 1 elements per call
+            rows = min(per, m - i)
+            check(lib.irn_split16(x.data_ptr() + 4 * i * c, None if scale is None else scale.data_ptr(), None if shift is None else shift.data_ptr(),
+                                  1 if relu else 0, out.data_ptr() + 2 * i * 3 * c, rows, c, _split_flag(x.device).data_ptr(), _stream()))
+    return out
+
+
+def gemm16_nhwc(a16, b16, shape, bias=None, residual=None, relu=False, alpha=1.0, out=None, algo_rank=0):
+    """act(alpha * a16 . b16^T + bias (+ residual)) as a channels-last fp32 [N, cout, H, W] tensor of `shape` (irn_gemm16_nhwc):
+    a16 fp16 [N*H*W, k] from `split16`, b16 fp16 [cout, k] = [w_hi | w_lo | w_hi 2^-11] of the weight scaled by 1 / alpha."""
+    _need_cuda(a16, "a16")
+    n, cout, h, w_ = (int(v) for v in shape)
+    m, k = int(a16.shape[0]), int(a16.shape[1])
+    if a16.dtype != torch.float16 or not a16.is_contiguous() or m != n * h * w_:
+        raise ValueError("gemm16_nhwc: a16 must be a contiguous fp16 [%d, k] matrix" % (n * h * w_))
+    if b16.dtype != torch.float16 or b16.device != a16.device or not b16.is_contiguous() or tuple(b16.shape) != (cout, k):
+        raise ValueError("gemm16_nhwc: b16 must be a contiguous fp16 [%d, %d] matrix on %s" % (cout, k, a16.device))
+    if bias is not None and (bias.dtype != torch.float32 or bias.device != a16.device or not bias.is_contiguous() or bias.numel() != cout):
+        raise ValueError("gemm16_nhwc: bias must be a contiguous fp32 [%d] tensor on %s" % (cout, a16.device))
+    for name, t in (("residual", residual), ("out", out)):
+        if t is not None and (tuple(t.shape) != (n, cout, h, w_) or t.dtype != torch.float32 or t.device != a16.device
+                              or not t.is_contiguous(memory_format=torch.channels_last)):
+            raise ValueError("gemm16_nhwc: %s must be a channels-last fp32 %s tensor on %s" % (name, (n, cout, h, w_), a16.device))
+    if out is None:
+        out = torch.empty((n, cout, h, w_), dtype=torch.float32, device=a16.device, memory_format=torch.channels_last)
+    if m == 0:
+        return out
+    dev = (a16.device.index if a16.device.index is not None else torch.cuda.current_device(), torch.cuda.current_stream(a16.device).cuda_stream)
+    ws = _GEMM_WS.get(dev)
+    if ws is None:
+        ws = _GEMM_WS[dev] = torch.empty(int(lib.irn_conv1x1_workspace_bytes()), dtype=torch.uint8, device=a16.device)
+    with torch.cuda.device(a16.device):
+        check(lib.irn_gemm16_nhwc(a16.data_ptr(), b16.data_ptr(), None if bias is None else bias.data_ptr(),
+                                  None if residual is None else residual.data_ptr(), out.data_ptr(), m, k, cout,
+                                  1 if relu else 0, float(alpha), int(algo_rank), ws.data_ptr(), ws.numel(), _stream()))
+    return out
+
+
+def split_weight(w64):
+    """Weight [cout, cin] (float64, batch norm folded in) -> (b16 fp16 [cout, 3 cin] = [w_hi | w_lo | w_hi 2^-11] of w 2^p, alpha =
+    2^-p): p puts the largest |w 2^p| into [2^13, 2^14), so that w_lo = fp16(w 2^p - w_hi) <= 8 stays a normal fp16 number for
+    every weight above 2^-17 of the largest (smaller ones contribute below the fp32 rounding of the sum)."""
+    import math
+    w64 = w64.detach().double()
+    top = float(w64.abs().max())
+    p = 13 - int(math.floor(math.log2(top))) if top > 0 else 0
+    ws = w64 * (2.0 ** p)
+    hi = ws.to(torch.float16)
+    lo = (ws - hi.double()).to(torch.float16)
+    hi_s = (hi.double() * 2.0 ** -11).to(torch.float16)
+    return torch.cat([hi, lo, hi_s], dim=1).contiguous(), 2.0 ** -p
+
+
 def conv1x1_algo_count(m, cin, cout, bias, residual, relu):
     """How many kernels hipBLASLt's heuristic offers for the problem (tools/conv1x1_tune.py times each of them once)."""
     n = C.c_int(0)

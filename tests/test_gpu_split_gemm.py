@@ -1,0 +1,137 @@
+"""Split-precision 1x1 convolutions (round 6; irn_split16 + irn_gemm16_nhwc, irn_amd/csrc/split16.hip, conv1x1.cpp): fp16 hi/lo
+operands with 2^-11-scaled low parts, one fp16 MFMA GEMM over 3 cin with fp32 accumulation, the same epilogue as the fp32 GEMM —
+conv -> FixedBatchNorm -> (+ residual) -> ReLU of reference net/resnet50.py:11-14,34-54.
+
+Checked against the exact (fp64) value of the same expression at the accuracy of the fp32 GEMM they replace, bit for bit against a
+host model of the split, for the bits being the same on every call (what the reproducible mode rests on), and through a whole
+bottleneck unit against the composed PyTorch modules."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev():
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    return torch.device("cuda", 0)
+
+
+def _cl(t):
+    return t.contiguous(memory_format=torch.channels_last)
+
+
+def test_split16_is_the_host_model_bit_for_bit():
+    """hi = fp16(y), lo' = fp16((y - hi) 2^11) with y = x or relu(fmaf(x, scale, shift)); layout [hi | hi | lo'] per pixel; the
+    overflow flag trips on |y| > 65504 and on NaN only."""
+    from irn_amd import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(3)
+    for (n, c, h, w) in ((2, 64, 7, 9), (1, 8, 1, 1), (3, 2048, 4, 5), (1, 128, 33, 17)):
+        x = torch.randn(n, c, h, w, generator=g) * torch.tensor([1e-6, 1e-3, 1.0, 300.0])[torch.randint(0, 4, (n, c, h, w), generator=g)]
+        scale, shift = torch.rand(c, generator=g) + 0.5, torch.randn(c, generator=g)
+        for bn, relu in ((False, False), (True, True), (True, False)):
+            got = ops.split16(_cl(x.to(dev)), scale.to(dev) if bn else None, shift.to(dev) if bn else None, relu).cpu()
+            y = x.permute(0, 2, 3, 1).reshape(-1, c)
+            if bn:
+                y = (y.double() * scale.double() + shift.double()).float()        # (the kernel's fmaf rounds once: within an fp32 ulp of this)
+                if relu:
+                    y = y.clamp_min(0)
+            hi = y.to(torch.float16)
+            lo = ((y - hi.float()) * 2048.0).to(torch.float16)
+            assert got.shape == (n * h * w, 3 * c) and got.dtype == torch.float16
+            if not bn:          # (with the batch norm in front the host's fmaf may not be a single rounding: compared below)
+                assert torch.equal(got[:, :c], hi) and torch.equal(got[:, c:2 * c], hi) and torch.equal(got[:, 2 * c:], lo), (n, c, bn)
+            else:
+                assert torch.equal(got[:, :c], got[:, c:2 * c])
+            # hi + 2^-11 lo' reproduces y to 22 bits wherever lo' is a normal number
+            rec = got[:, :c].double() + got[:, 2 * c:].double() / 2048.0
+            big = y.abs() > 1e-3
+            assert float(((rec - y.double()).abs() / y.abs().double().clamp_min(1e-30))[big].max()) <= 2.0 ** -21
+    assert not ops.split_overflowed()
+    bad = torch.ones(1, 8, 2, 2)
+    bad[0, 3, 1, 1] = 7e4
+    ops.split16(_cl(bad.to(dev)))
+    assert ops.split_overflowed() and not ops.split_overflowed()            # reported once, then reset
+    bad[0, 3, 1, 1] = float("nan")
+    ops.split16(_cl(bad.to(dev)))
+    assert ops.split_overflowed()
+
+
+CASES = [(2, 64, 256, 24, 32), (2, 256, 64, 24, 32), (3, 128, 512, 13, 19), (2, 2048, 512, 6, 8), (1, 1024, 2048, 8, 8), (16, 64, 64, 32, 32), (1, 8, 12, 1, 1)]
+
+
+@pytest.mark.parametrize("case", CASES)
+@pytest.mark.parametrize("bias,residual,relu", [(True, False, True), (True, True, True), (False, False, False)])
+def test_split_gemm_equals_the_exact_expression_like_the_fp32_gemm(case, bias, residual, relu):
+    from irn_amd import ops
+    n, cin, cout, h, w = case
+    dev = _dev()
+    g = torch.Generator().manual_seed(n * 1000 + cin + cout + h)
+    x = torch.relu(torch.randn(n, cin, h, w, generator=g)) * 3.0
+    wt = torch.randn(cout, cin, generator=g) / cin ** 0.5 * 0.05            # folded-batch-norm-sized weights
+    b = torch.randn(cout, generator=g) if bias else None
+    r = torch.randn(n, cout, h, w, generator=g) if residual else None
+    want = torch.einsum("nchw,oc->nohw", x.double(), wt.double())
+    if bias:
+        want = want + b.double().view(1, -1, 1, 1)
+    if residual:
+        want = want + r.double()
+    if relu:
+        want = want.clamp_min(0)
+    b16, alpha = ops.split_weight(wt.double().to(dev))
+    assert b16.shape == (cout, 3 * cin) and float(b16.float().abs().max()) < 2.0 ** 14
+    a16 = ops.split16(_cl(x.to(dev)))
+    got = ops.gemm16_nhwc(a16, b16, (n, cout, h, w), None if b is None else b.to(dev), None if r is None else _cl(r.to(dev)), relu, alpha)
+    assert got.shape == (n, cout, h, w) and got.is_contiguous(memory_format=torch.channels_last) and got.dtype == torch.float32
+    err = float((got.cpu().double() - want).abs().max())
+    f32 = ops.conv1x1_nhwc(_cl(x.to(dev)), wt.to(dev), None if b is None else b.to(dev), None if r is None else _cl(r.to(dev)), relu)
+    err32 = float((f32.cpu().double() - want).abs().max())
+    scale = float(want.abs().max())
+    print("%s bias %d residual %d relu %d: split %.2e, fp32 GEMM %.2e (max |value| %.2f)" % (case, bias, residual, relu, err, err32, scale))
+    assert err <= 4e-7 * scale * max(1.0, cin ** 0.5 / 8) + 1e-6, (case, err, err32)      # the bound the fp32 GEMM is held to, scaled to these magnitudes
+    assert err <= 4.0 * err32 + 1e-6, (case, err, err32)
+    # same bits on every call, and in place over the residual
+    again = ops.gemm16_nhwc(a16, b16, (n, cout, h, w), None if b is None else b.to(dev), None if r is None else _cl(r.to(dev)), relu, alpha)
+    assert torch.equal(got, again)
+    if residual:
+        buf = _cl(r.to(dev)).clone(memory_format=torch.channels_last)
+        out = ops.gemm16_nhwc(a16, b16, (n, cout, h, w), None if b is None else b.to(dev), buf, relu, alpha, out=buf)
+        assert out.data_ptr() == buf.data_ptr() and torch.equal(out, got)
+
+
+def test_bottleneck_split_path_vs_composed_modules_and_fp32_gemm_path(monkeypatch):
+    """A whole unit (identity and projection, stride 1) on the channels-last inference path with IRN_SPLIT_GEMM on: against the
+    composed PyTorch modules (conv -> FrozenBatchNorm -> ReLU ... in NCHW, what the reference runs) and against the fp32-GEMM
+    path, at the accuracy the fp32 path itself has; the same bits on every call."""
+    from irn_amd.net import resnet50 as r50
+    dev = _dev()
+    torch.manual_seed(11)
+    for (c_in, planes, project) in ((256, 64, False), (1024, 512, True), (2048, 512, False), (64, 64, True)):
+        unit = r50.Bottleneck(c_in, planes, stride=1, project=project).to(dev).eval()
+        with torch.no_grad():
+            for m in unit.modules():
+                if isinstance(m, r50.FrozenBatchNorm):
+                    m.weight.uniform_(0.5, 1.5)
+                    m.bias.normal_(0, 0.2)
+                    m.running_mean.normal_(0, 0.2)
+                    m.running_var.uniform_(0.5, 2.0)
+            x = torch.relu(torch.randn(2, c_in, 12, 10, device=dev))
+            monkeypatch.setattr(r50, "SPLIT_GEMM", True)
+            monkeypatch.setattr(r50, "SPLIT_MIN_PLANES", 64)
+            monkeypatch.setattr(r50, "SPLIT_MIN_INPUT", 1 << 20)
+            unit._gemm = None
+            y_split = unit(_cl(x))
+            p = unit.gemm_params()
+            assert "w3_16" in p and (("w1_16" in p) == (c_in * (planes + (4 * planes if project else 0)) >= 1 << 20))
+            assert torch.equal(y_split, unit(_cl(x)))
+            monkeypatch.setattr(r50, "SPLIT_GEMM", False)
+            unit._gemm = None
+            y_f32 = unit(_cl(x))
+            assert "w3_16" not in unit.gemm_params()
+            y_ref = unit.double()(x.double())                      # NCHW, fp64: the composed modules
+            unit.float()
+        e_split, e_f32 = float((y_split.double() - y_ref).abs().max()), float((y_f32.double() - y_ref).abs().max())
+        scale = float(y_ref.abs().max())
+        print("unit %d -> %d planes, project %s: split path %.2e, fp32 GEMM path %.2e from fp64 (max |value| %.2f)" % (c_in, planes, project, e_split, e_f32, scale))
+        assert e_split <= 4.0 * e_f32 + 1e-6 * scale and e_split <= 2e-5 * max(1.0, scale)
