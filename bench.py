@@ -493,9 +493,12 @@ def run_backbone(a, workload, rank, world, device, dist, parallel, steps, warmup
             return ops.label_epilogue(rws, [(H, W)] * batch, 0.25, keys=[c[0] for c in cams])["labels"]
 
     elapsed, _ = timed_loop(step, steps, warmup, dist, parallel, device)
+    _common.check_split_overflow("bench.py %s" % workload)        # an activation beyond fp16's range would invalidate the run
     out = {"value": steps * batch * world / elapsed, "ms_per_step": 1e3 * elapsed / steps, "batch": batch, "scales": scales}
     # convolution flops per image (counted on meta tensors: nothing is computed) against the fp32 matrix peak: the backbones
-    # are library kernels (MIOpen, hipBLASLt), so this is a utilisation figure, not a roofline claim of a kernel of ours
+    # are library kernels (MIOpen, hipBLASLt), so this is a utilisation figure, not a roofline claim of a kernel of ours — and
+    # an fp32-EQUIVALENT one: with the split-precision 1x1 convolutions part of the work runs on the fp16 matrix pipe (3 fp16
+    # flops per fp32 flop counted here), which is how it can approach 1
     try:
         gflop = backbone_gflop_per_image(scales, H, workload == "e2e")
         out["gflop_per_image"] = gflop
@@ -508,6 +511,7 @@ def run_backbone(a, workload, rank, world, device, dist, parallel, steps, warmup
         probe = torch.empty(2 * batch, 3, H, W, device=device)
         cl = _r50.channels_last_for(probe)
     out["trunk"] = {"layout": "channels_last" if cl else "nchw", "fused_1x1_gemm": bool(cl and _r50.FUSED_GEMM and _r50.FUSED_EPILOGUE),
+                    "split_precision_1x1": bool(cl and _r50.FUSED_GEMM and _r50.FUSED_EPILOGUE and _r50.SPLIT_GEMM),
                     "deterministic": bool(_r50.DETERMINISTIC), "tuned_nhwc_shapes": len(_r50.tuned_nhwc_shapes()),
                     "miopen_db": os.environ.get("MIOPEN_USER_DB_PATH"), "miopen_key": _common.miopen_mode_key()}
     if walker is not None:

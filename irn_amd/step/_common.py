@@ -256,6 +256,16 @@ def step_summary(rank, walker=None):
         print("[worker %d] %s" % (int(rank), m), file=sys.stderr, flush=True)
 
 
+def check_split_overflow(what):
+    """End of a step: did an activation leave fp16's range inside the split-precision 1x1 convolutions (net/resnet50.py
+    SPLIT_GEMM)?  Then this step's outputs are invalid and the step raises — loudly, like a worker's exception."""
+    from .. import ops
+    if ops.split_overflowed():
+        raise RuntimeError("%s: an activation of the backbone was beyond fp16's range (|x| > 65504) or NaN inside the split-precision "
+                           "1x1 convolutions; the outputs of this step are INVALID.  Run with IRN_SPLIT_GEMM=0 (run_sample.py "
+                           "--split_gemm 0): the fp32 GEMMs have no such limit." % what)
+
+
 def deterministic_backbones():
     """IRN_DETERMINISTIC (default 1; run_sample.py --deterministic 0/1): the backbones' outputs are a function of their inputs
     only, whichever process, worker layout or run computes them — an N-GPU run writes bit for bit the files of a 1-GPU run
@@ -401,6 +411,7 @@ def _pool_worker(rank, device, n_workers, cmd_q, res_q):
                 if int(device) >= 0:
                     torch.cuda.synchronize()
                     step_summary(rank)
+                    check_split_overflow("%s.%s" % (mod, fn))
                 res_q.put((rank, "ok", {"cam_store_hits": CAM_STORE.hits, "cam_store_misses": CAM_STORE.misses,
                                         "edge_store_hits": EDGE_STORE.hits, "edge_store_misses": EDGE_STORE.misses,
                                         "walk_fallback_runs": WALK_STATS["fallback_runs"], "cam_trunk_passes": dict(CAM_STATS)}))
@@ -550,7 +561,9 @@ def spawn_workers(work, model, shards, args):
                 import sys
                 print(startup_line(0, 1, devs[0], db_dir), file=sys.stderr, flush=True)
             work(0, model, shards, args)
+            torch.cuda.synchronize()
             step_summary(0)
+            check_split_overflow("%s.%s" % (work.__module__, work.__name__))
         finally:
             torch.backends.cudnn.deterministic, _r50.DETERMINISTIC = saved
         return

@@ -38,6 +38,7 @@ def test_tuned_channels_last_trunk_has_the_same_bits_in_every_process(tmp_path):
     rec_b = b[tag]
     assert len(rec_a) == len(rec_b) > 120
     assert sum(1 for name, _ in rec_a if name.startswith("gemm ")) >= 60               # the channels-last trunk with fused GEMMs ran
+    assert sum(1 for name, _ in rec_a if name.startswith("gemm split ")) >= 30         # ... conv3 of every unit in the split-precision form
     diff = [name for (name, x), (_, y) in zip(rec_a, rec_b) if x != y]
     print("reproducible mode, 375x500 x 8 pairs: %d layer outputs of CAM (2 scales) + IRNet, %d differ between two processes" % (len(rec_a), len(diff)))
     assert not diff, diff[:5]

@@ -88,6 +88,14 @@ def main():
         return out
 
     ops.conv1x1_nhwc = spy
+    real16 = ops.gemm16_nhwc
+
+    def spy16(a16, b16, shape, *args, **kw):            # the split-precision form of the same layers (fp16 hi/lo operands)
+        out = real16(a16, b16, shape, *args, **kw)
+        rec.append(("gemm split %s x %d->%d" % (tuple(shape), a16.shape[1] // 3, b16.shape[0]), bits(out)))
+        return out
+
+    ops.gemm16_nhwc = spy16
     result = {}
     scales = [float(s) for s in a.scales.split(",")]
     with torch.no_grad():
