@@ -65,11 +65,6 @@ def parse(argv=None):
     ap.add_argument("--batch", type=int, default=0, help="images per GPU per step (0 = workload default)")
     ap.add_argument("--unique", type=int, default=0, help="distinct synthetic images per GPU (0 = the batch: no image twice in a step)")
     ap.add_argument("--variant", type=int, default=2, help="0 generic sweep, 1 blocked streaming sweep, 2 weights-stationary persistent walk")
-    ap.add_argument("--xcd-map", type=int, default=1)
-    ap.add_argument("--tile", type=int, default=8, help="sweep tile shape id (irn_walk_set_option 'tile')")
-    ap.add_argument("--streams", type=int, default=1, help="channel-chunk classes on separate streams (merged=0)")
-    ap.add_argument("--merged", type=int, default=0, help="all channel-chunk widths in one launch per sweep")
-    ap.add_argument("--probe", type=int, default=0, help="diagnostic: time the weight-streaming skeleton instead")
     ap.add_argument("--walk-option", action="append", default=[], metavar="NAME=VALUE",
                     help="extra irn_walk_set_option settings (tuning experiments), e.g. poll_delay=8")
     ap.add_argument("--accel", type=int, default=1,
@@ -346,11 +341,6 @@ def run_walk(a, workload, rank, world, device, dist, parallel, steps, warmup, ba
 
     walker = indexing.RandomWalk(radius, device)
     walker.set_option("variant", a.variant)
-    walker.set_option("xcd_map", a.xcd_map)
-    walker.set_option("tile", a.tile)
-    walker.set_option("streams", a.streams)
-    walker.set_option("merged", a.merged)
-    walker.set_option("probe", a.probe)
     walker.set_option("accel", 0 if workload == "walk_plain" else a.accel)
     if warmup == 0:
         walker.set_option("poll_delay_auto", 0)          # no untimed step for the start-up probe to run in (profiler passes)

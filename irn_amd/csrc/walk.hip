@@ -371,156 +371,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, MAXW))) 
     sweep_body<R, CH, P, TH, TW>(I, B, src, dst, plane_tab, xs, last, cheb, ck);
 }
 
-// Diagnostic kernel (irn_walk_set_option("probe", mode)): the weight-streaming skeleton of the sweep
-// without state staging, LDS windows or the fp64 epilogue — measures what the access pattern itself
-// sustains.  mode 1: forward + backward loads (as the sweep issues them); mode 2: forward loads only
-// (aligned, each byte once); mode 3: as 1 but every load waits for the previous pair (no overlap);
-// mode 4: as 1 with the backward column shift rounded to a multiple of 4 (16-byte aligned loads).
-template <int R, int P, int TH, int TW, int MAXW, int MODE>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, MAXW))) void probe_kernel(
-    const WalkImg *__restrict__ imgs, const int4 *__restrict__ block_map, const int *__restrict__ plane_tab, int phase,
-    int last) {
-    constexpr int H = R - 1;
-    const int4 e = block_map[blockIdx.x];
-    if (e.x < 0) return;
-    const WalkImg I = imgs[e.x];
-    const int tid = threadIdx.x;
-    const int trow = tid / (TW / P), tcol = (tid % (TW / P)) * P;
-    const int y = e.y + trow, x = e.z + tcol;
-    const bool live = y < I.h && x < I.w;
-    const unsigned p0 = live ? (unsigned)(y * I.w + x) : 0u;
-    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(
-        (void *)(I.wts - I.front_pad), 0, (int)(I.n_dirs * I.plane_stride * 4), 0x00020000);
-    const int voff = (int)(p0 * 4u), ps4 = (int)(I.plane_stride * 4), fp4 = I.front_pad * 4, w4 = I.w * 4;
-    float acc[P];
-#pragma unroll
-    for (int j = 0; j < P; ++j) acc[j] = 0.f;
-#pragma unroll 1
-    for (int dy = 0; dy <= H; ++dy) {
-        const int rowoff4 = dy * w4;
-        const int *prow = plane_tab + dy * (2 * H + 1);
-        static_for<2 * H + 1>([&](auto ix) __attribute__((always_inline)) {
-            constexpr int dx = decltype(ix)::value - H;
-            const int ent = prow[dx + H];
-            const int soff = fp4 + (ent < 0 ? ~ent : ent) * ps4;
-            float wf[P], wb[P];
-            load_w<P>(wf, wrsrc, voff, soff);
-            if constexpr (MODE == 4) load_w<P>(wb, wrsrc, voff, soff - rowoff4 - (dx & ~3) * 4);
-            else if constexpr (MODE != 2) load_w<P>(wb, wrsrc, voff, soff - rowoff4 - dx * 4);
-#pragma unroll
-            for (int j = 0; j < P; ++j) {
-                acc[j] += wf[j];
-                if constexpr (MODE != 2) acc[j] += wb[j];
-            }
-            if constexpr (MODE == 3) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        });
-    }
-    float *dst = last ? I.out : ((phase & 1) ? I.xa : I.xb);
-    if (live)
-#pragma unroll
-        for (int j = 0; j < P; ++j)
-            if (x + j < I.w) dst[(unsigned)(e.w & 0xffff) * (unsigned)(I.h * I.w) + p0 + j] = acc[j];
-}
+// The one tile shape of the blocked sweep: 8 x 128 pixels per 256-thread workgroup, 4 pixels per thread, at most 2 waves per
+// SIMD — the best of the twelve shapes measured in rounds 1-3 (profiles/README.md); the others went with round 6's prune.
+constexpr int kTileP = 4, kTileH = 8, kTileW = 128, kTileMaxW = 2;
+constexpr int kMaxChunk = 4;      // channels of an image a workgroup carries at once (its LDS state window per channel)
 
-// All channel-chunk widths of a sweep in ONE launch: the workgroup's width comes from its block-map
-// entry.  The register budget is that of the widest body, which the occupancy cap (MAXW) already
-// grants every width, and the dispatcher balances small and large widths inside one grid instead
-// of the small widths' chains setting the pace on their own streams.
-template <int R, int P, int TH, int TW, int MAXW>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, MAXW))) void sweep_merged_kernel(
-    const WalkImg *__restrict__ imgs, const int4 *__restrict__ block_map, const int *__restrict__ plane_tab, int phase,
-    int last, int cheb, float ck) {
-    extern __shared__ __attribute__((aligned(16))) float xs[];
-    const int4 e = block_map[blockIdx.x];
-    if (e.x < 0) return;
-    const WalkImg I = imgs[e.x];
-    const BlockEnt B{e.x, e.y, e.z, e.w & 0xffff};
-    const float *src = (phase & 1) ? I.xb : I.xa;
-    float *dst = (last && !cheb) ? I.out : ((phase & 1) ? I.xa : I.xb);
-    switch (e.w >> 16) {
-        case 1: sweep_body<R, 1, P, TH, TW>(I, B, src, dst, plane_tab, xs, last, cheb, ck); break;
-        case 2: sweep_body<R, 2, P, TH, TW>(I, B, src, dst, plane_tab, xs, last, cheb, ck); break;
-        case 3: sweep_body<R, 3, P, TH, TW>(I, B, src, dst, plane_tab, xs, last, cheb, ck); break;
-        default: sweep_body<R, 4, P, TH, TW>(I, B, src, dst, plane_tab, xs, last, cheb, ck); break;
-    }
-}
-
-// tile shapes selectable with irn_walk_set_option("tile", id)
-struct TileShape {
-    int P, TH, TW, MAXW;
-};
-constexpr TileShape kTiles[] = {{4, 16, 64, 4}, {4, 16, 64, 8}, {2, 16, 32, 4}, {1, 8, 32, 4},
-                                {1, 8, 32, 8},  {4, 32, 32, 4}, {2, 16, 32, 8}, {4, 8, 128, 4},
-                                {4, 8, 128, 2}, {4, 8, 128, 3}, {4, 4, 256, 4}, {2, 8, 64, 2}};
-constexpr int kNumTiles = sizeof(kTiles) / sizeof(kTiles[0]);
-
-template <int R, int CH, int T>
-int launch_sweep_tile(const WalkImg *imgs, const int4 *map, const int *ptab, int nb, int phase, int last, int cheb, float ck,
-                      hipStream_t stream) {
-    constexpr int P = kTiles[T].P, TH = kTiles[T].TH, TW = kTiles[T].TW, MAXW = kTiles[T].MAXW;
-    using G = Geo<R, P, TH, TW>;
+template <int R, int CH>
+int launch_sweep(const WalkImg *imgs, const int4 *map, const int *ptab, int nb, int phase, int last, int cheb, float ck,
+                 hipStream_t stream) {
+    using G = Geo<R, kTileP, kTileH, kTileW>;
     const size_t lds = sizeof(float) * CH * G::LH * G::LW;
-    hipLaunchKernelGGL((sweep_blocked_kernel<R, CH, P, TH, TW, MAXW>), dim3(nb), dim3(256), lds, stream, imgs, map, ptab,
+    hipLaunchKernelGGL((sweep_blocked_kernel<R, CH, kTileP, kTileH, kTileW, kTileMaxW>), dim3(nb), dim3(256), lds, stream, imgs, map, ptab,
                        phase, last, cheb, ck);
     IRN_LAUNCH_CHECK("sweep_blocked_kernel");
     return IRN_OK;
-}
-
-template <int R, int T>
-int launch_merged_tile(const WalkImg *imgs, const int4 *map, const int *ptab, int nb, int max_nch, int phase, int last, int cheb, float ck,
-                       hipStream_t stream) {
-    constexpr int P = kTiles[T].P, TH = kTiles[T].TH, TW = kTiles[T].TW, MAXW = kTiles[T].MAXW;
-    using G = Geo<R, P, TH, TW>;
-    const size_t lds = sizeof(float) * max_nch * G::LH * G::LW;
-    hipLaunchKernelGGL((sweep_merged_kernel<R, P, TH, TW, MAXW>), dim3(nb), dim3(256), lds, stream, imgs, map, ptab,
-                       phase, last, cheb, ck);
-    IRN_LAUNCH_CHECK("sweep_merged_kernel");
-    return IRN_OK;
-}
-
-template <int R>
-int launch_merged(int tile, const WalkImg *imgs, const int4 *map, const int *ptab, int nb, int max_nch, int phase,
-                  int last, int cheb, float ck, hipStream_t stream) {
-    switch (tile) {
-        case 0: return launch_merged_tile<R, 0>(imgs, map, ptab, nb, max_nch, phase, last, cheb, ck, stream);
-        case 1: return launch_merged_tile<R, 1>(imgs, map, ptab, nb, max_nch, phase, last, cheb, ck, stream);
-        case 2: return launch_merged_tile<R, 2>(imgs, map, ptab, nb, max_nch, phase, last, cheb, ck, stream);
-        case 3: return launch_merged_tile<R, 3>(imgs, map, ptab, nb, max_nch, phase, last, cheb, ck, stream);
-        case 4: return launch_merged_tile<R, 4>(imgs, map, ptab, nb, max_nch, phase, last, cheb, ck, stream);
-        case 5: return launch_merged_tile<R, 5>(imgs, map, ptab, nb, max_nch, phase, last, cheb, ck, stream);
-        case 6: return launch_merged_tile<R, 6>(imgs, map, ptab, nb, max_nch, phase, last, cheb, ck, stream);
-        case 7: return launch_merged_tile<R, 7>(imgs, map, ptab, nb, max_nch, phase, last, cheb, ck, stream);
-        default: return fail(IRN_ERR_ARG, "merged launch exists for tiles 0-7");
-    }
-}
-
-template <int R, int MODE>
-int launch_probe(const WalkImg *imgs, const int4 *map, const int *ptab, int nb, int phase, int last, hipStream_t stream) {
-    constexpr int T = 7;
-    constexpr int P = kTiles[T].P, TH = kTiles[T].TH, TW = kTiles[T].TW, MAXW = kTiles[T].MAXW;
-    hipLaunchKernelGGL((probe_kernel<R, P, TH, TW, MAXW, MODE>), dim3(nb), dim3(256), 0, stream, imgs, map, ptab, phase,
-                       last);
-    IRN_LAUNCH_CHECK("probe_kernel");
-    return IRN_OK;
-}
-
-template <int R, int CH>
-int launch_sweep(int tile, const WalkImg *imgs, const int4 *map, const int *ptab, int nb, int phase, int last, int cheb, float ck,
-                 hipStream_t stream) {
-    switch (tile) {
-        case 0: return launch_sweep_tile<R, CH, 0>(imgs, map, ptab, nb, phase, last, cheb, ck, stream);
-        case 1: return launch_sweep_tile<R, CH, 1>(imgs, map, ptab, nb, phase, last, cheb, ck, stream);
-        case 2: return launch_sweep_tile<R, CH, 2>(imgs, map, ptab, nb, phase, last, cheb, ck, stream);
-        case 3: return launch_sweep_tile<R, CH, 3>(imgs, map, ptab, nb, phase, last, cheb, ck, stream);
-        case 4: return launch_sweep_tile<R, CH, 4>(imgs, map, ptab, nb, phase, last, cheb, ck, stream);
-        case 5: return launch_sweep_tile<R, CH, 5>(imgs, map, ptab, nb, phase, last, cheb, ck, stream);
-        case 6: return launch_sweep_tile<R, CH, 6>(imgs, map, ptab, nb, phase, last, cheb, ck, stream);
-        case 7: return launch_sweep_tile<R, CH, 7>(imgs, map, ptab, nb, phase, last, cheb, ck, stream);
-        case 8: return launch_sweep_tile<R, CH, 8>(imgs, map, ptab, nb, phase, last, cheb, ck, stream);
-        case 9: return launch_sweep_tile<R, CH, 9>(imgs, map, ptab, nb, phase, last, cheb, ck, stream);
-        case 10: return launch_sweep_tile<R, CH, 10>(imgs, map, ptab, nb, phase, last, cheb, ck, stream);
-        default: return launch_sweep_tile<R, CH, 11>(imgs, map, ptab, nb, phase, last, cheb, ck, stream);
-    }
 }
 
 }  // namespace
@@ -711,21 +575,6 @@ extern "C" int irn_walk_set_option(irn_walk_ctx *ctx, const char *name, int valu
             (void)hipFree(ctx->res_prof_dev);
             ctx->res_prof_dev = nullptr;
         }
-    } else if (!strcmp(name, "xcd_map")) {
-        ctx->xcd_map = value ? 1 : 0;
-    } else if (!strcmp(name, "probe")) {
-        if (value < 0 || value > 4) return fail(IRN_ERR_ARG, "probe must be in [0,4]");
-        ctx->probe = value;
-    } else if (!strcmp(name, "merged")) {
-        ctx->merged = value ? 1 : 0;
-    } else if (!strcmp(name, "streams")) {
-        ctx->use_streams = value ? 1 : 0;
-    } else if (!strcmp(name, "tile")) {
-        if (value < 0 || value >= kNumTiles) return fail(IRN_ERR_ARG, "tile must be in [0,%d)", kNumTiles);
-        ctx->tile = value;
-    } else if (!strcmp(name, "max_chunk")) {
-        if (value < 1 || value > 4) return fail(IRN_ERR_ARG, "max_chunk must be in [1,4]");
-        ctx->max_chunk = value;
     } else {
         return fail(IRN_ERR_ARG, "irn_walk_set_option: unknown option '%s'", name);
     }
@@ -814,7 +663,7 @@ extern "C" int irn_walk_configure(irn_walk_ctx *ctx, int n_images, const int32_t
     for (int k = 0; k < 5; ++k) ctx->cls_begin[k] = ctx->cls_count[k] = 0;
     ctx->max_nch = 1;
     if (blocked_ok) {
-        const int NX = ctx->xcd_map ? 8 : 1;
+        const int NX = 8;
         for (int cls = 4; cls >= 1; --cls) {          // widest first: its workgroups run longest
             while (map.size() % NX) map.push_back(make_int4(-1, 0, 0, 0));   // keep block b on XCD b % 8
             ctx->cls_begin[cls] = (int)map.size();
@@ -824,12 +673,12 @@ extern "C" int irn_walk_configure(irn_walk_ctx *ctx, int n_images, const int32_t
                 int best = 0;
                 for (int k = 1; k < NX; ++k)
                     if (load[k] < load[best]) best = k;
-                for (int c0 = 0; c0 < c[i]; c0 += ctx->max_chunk) {
-                    const int nch = std::min(ctx->max_chunk, c[i] - c0);
+                for (int c0 = 0; c0 < c[i]; c0 += kMaxChunk) {
+                    const int nch = std::min(kMaxChunk, c[i] - c0);
                     if (nch != cls) continue;
                     ctx->max_nch = std::max(ctx->max_nch, nch);
-                    for (int ty = 0; ty < h[i]; ty += kTiles[ctx->tile].TH)
-                        for (int tx = 0; tx < w[i]; tx += kTiles[ctx->tile].TW) {
+                    for (int ty = 0; ty < h[i]; ty += kTileH)
+                        for (int tx = 0; tx < w[i]; tx += kTileW) {
                             q[best].push_back(make_int4(i, ty, tx, c0 | (nch << 16)));
                             ++load[best];
                         }
@@ -888,7 +737,7 @@ template <int R, int CH>
 static int launch_blocked_cls(irn_walk_ctx *ctx, int phase, int last, int cheb, float ck, hipStream_t stream) {
     const int nb = ctx->cls_count[CH];
     if (nb <= 0) return IRN_OK;
-    return launch_sweep<R, CH>(ctx->tile, ctx->imgs_dev, ctx->map_dev + ctx->cls_begin[CH], ctx->tab->plane_tab, nb,
+    return launch_sweep<R, CH>(ctx->imgs_dev, ctx->map_dev + ctx->cls_begin[CH], ctx->tab->plane_tab, nb,
                                phase, last, cheb, ck, stream);
 }
 
@@ -897,22 +746,6 @@ static int launch_blocked_cls(irn_walk_ctx *ctx, int phase, int last, int cheb, 
 // of workgroups then overlaps the big one instead of costing a full kernel latency per sweep.
 template <int R>
 static int launch_blocked(irn_walk_ctx *ctx, int phase, int last, int cheb, float ck, hipStream_t const *st) {
-    if (ctx->probe) {   // timing skeleton over the whole block map (results are meaningless)
-        if (kTiles[ctx->tile].TH != 8 || kTiles[ctx->tile].TW != 128)
-            return fail(IRN_ERR_ARG, "probe needs an 8x128 tile (7, 8 or 9)");
-        const WalkImg *im = ctx->imgs_dev;
-        const int4 *mp = ctx->map_dev;
-        const int *pt = ctx->tab->plane_tab;
-        switch (ctx->probe) {
-            case 1: return launch_probe<R, 1>(im, mp, pt, ctx->map_len, phase, last, st[0]);
-            case 2: return launch_probe<R, 2>(im, mp, pt, ctx->map_len, phase, last, st[0]);
-            case 3: return launch_probe<R, 3>(im, mp, pt, ctx->map_len, phase, last, st[0]);
-            default: return launch_probe<R, 4>(im, mp, pt, ctx->map_len, phase, last, st[0]);
-        }
-    }
-    if (ctx->merged)
-        return launch_merged<R>(ctx->tile, ctx->imgs_dev, ctx->map_dev, ctx->tab->plane_tab, ctx->map_len, ctx->max_nch,
-                                phase, last, cheb, ck, st[0]);
     int rc = launch_blocked_cls<R, 1>(ctx, phase, last, cheb, ck, st[0]);
     if (!rc) rc = launch_blocked_cls<R, 2>(ctx, phase, last, cheb, ck, st[1]);
     if (!rc) rc = launch_blocked_cls<R, 3>(ctx, phase, last, cheb, ck, st[2]);
@@ -956,7 +789,7 @@ int irn::streaming_run(irn_walk_ctx *ctx, int n_sweeps, hipStream_t stream, bool
     // stream of every channel-chunk class: the class with most workgroups stays on the caller's stream
     hipStream_t st[4] = {stream, stream, stream, stream};
     int n_side = 0;
-    if (blocked && !ctx->merged && !ctx->probe && ctx->use_streams && n_steps > 0) {
+    if (blocked && n_steps > 0) {
         int big = 1;
         for (int k = 2; k <= 4; ++k)
             if (ctx->cls_count[k] > ctx->cls_count[big]) big = k;

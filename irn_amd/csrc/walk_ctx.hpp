@@ -65,12 +65,10 @@ struct irn_walk_ctx {
     const DeviceTable *tab = nullptr;   // raster order
     int variant = 1;                    // 0 generic, 1 blocked streaming sweeps, 2 weights-stationary persistent walk
                                         // (irn_walk_create picks 2 for radius 5/10, 0 otherwise)
-    int xcd_map = 1;                    // keep all tiles of an image on one XCD
-    int tile = 8;                       // index into kTiles (8x128 tile, 4 px/thread, MAXW 2: best measured)
-    int use_streams = 1;                // run the channel-chunk classes of a sweep on separate streams
+    // blocked sweep: all tiles of an image on one XCD, one tile shape (walk.hip kTile*), the channel-chunk classes of a sweep on
+    // separate streams
     hipStream_t side[3] = {nullptr, nullptr, nullptr};
     hipEvent_t ev_fork = nullptr, ev_join[3] = {nullptr, nullptr, nullptr};
-    int max_chunk = 4;
     // batch
     int n = 0;
     std::vector<int> h, w, c;
@@ -88,8 +86,6 @@ struct irn_walk_ctx {
     int cls_begin[5] = {0, 0, 0, 0, 0};    // block-map slice of channel-chunk width k: [cls_begin[k], +cls_count[k])
     int cls_count[5] = {0, 0, 0, 0, 0};
     int map_len = 0, max_nch = 1;
-    int probe = 0;                         // diagnostic: replace the sweeps by the streaming skeleton (tile 7 only)
-    int merged = 0;                        // 1: one launch per sweep for all widths; 0: one launch per width, on streams
     // pinned staging for the per-run descriptors (2 slots, guarded by events)
     void *stage[2] = {nullptr, nullptr};
     size_t stage_cap = 0;

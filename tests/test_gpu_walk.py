@@ -48,8 +48,8 @@ def test_edge_to_affinity_exact(golden, r):
         assert np.array_equal(ab[b], O.edge_to_affinity(eb[b].reshape(-1), pio.path_indices))
 
 
-@pytest.mark.parametrize("variant,tile", [(0, 0), (1, 0), (1, 1), (1, 2), (1, 3), (1, 4), (1, 5), (1, 6), (1, 7), (1, 8), (1, 9), (1, 10), (1, 11)])
-def test_propagate_to_edge_vs_reference_golden(golden, variant, tile):
+@pytest.mark.parametrize("variant", [0, 1])
+def test_propagate_to_edge_vs_reference_golden(golden, variant):
     from irn_amd.misc import indexing
     wk, names = _cases(golden)
     for n in names:
@@ -58,7 +58,6 @@ def test_propagate_to_edge_vs_reference_golden(golden, variant, tile):
             continue
         walker = indexing.RandomWalk(r, _dev())
         walker.set_option("variant", variant)
-        walker.set_option("tile", tile)
         cam = torch.from_numpy(wk[n + "_cam"]).to(_dev())
         if n.endswith("_ck"):
             cam = cam.view(2, c // 2, h, w)
@@ -119,10 +118,10 @@ def test_ragged_batch_equals_single_images(golden):
     for i in (0, 4):
         st = O.propagate_to_edge_stencil(cams[i].cpu().numpy(), edges[i].cpu().numpy(), 5, 10, 5)
         assert np.abs(batch[i] - st).max() <= TOL_F64
-    for opt in ("xcd_map", "merged", "streams"):
-        walker.set_option(opt, 0)
-        again = walker(edges, cams, beta=10, exp_times=5)
-        assert all(np.array_equal(a.cpu().numpy(), b) for a, b in zip(again, batch)), opt
+    again = walker(edges, cams, beta=10, exp_times=5)
+    assert all(np.array_equal(a.cpu().numpy(), b) for a, b in zip(again, batch))
+    with pytest.raises(Exception):
+        walker.set_option("tile", 3)            # the tuning knobs of rounds 1-3 went with round 6's prune: unknown names fail
     walker.close()
 
 
@@ -157,19 +156,15 @@ def test_instance_split_channels(golden):
 
 # ---- BASELINE sizes: properties that need no O(N^3) reference --------------------------------
 
-@pytest.mark.parametrize("r,h,w,c,tile", [(10, 128, 128, 3, 0), (5, 128, 128, 3, 0), (10, 94, 125, 2, 0),
-                                          (10, 256, 256, 5, 0), (10, 94, 125, 7, 1), (10, 128, 128, 4, 2),
-                                          (5, 94, 125, 6, 2), (10, 125, 94, 3, 3), (5, 128, 128, 1, 3),
-                                          (10, 94, 125, 5, 4), (5, 125, 94, 2, 5), (10, 128, 128, 2, 6),
-                                          (10, 130, 250, 3, 7), (10, 128, 128, 3, 8), (5, 94, 125, 4, 8),
-                                          (10, 94, 125, 2, 9), (10, 40, 300, 1, 10), (10, 125, 94, 4, 11)])
-def test_full_size_blocked_equals_generic_and_conserves_mass(r, h, w, c, tile):
+@pytest.mark.parametrize("r,h,w,c", [(10, 128, 128, 3), (5, 128, 128, 3), (10, 94, 125, 2), (10, 256, 256, 5), (10, 94, 125, 7),
+                                     (5, 94, 125, 6), (10, 125, 94, 3), (5, 128, 128, 1), (5, 125, 94, 2), (10, 130, 250, 3),
+                                     (10, 40, 300, 1)])
+def test_full_size_blocked_equals_generic_and_conserves_mass(r, h, w, c):
     from irn_amd import synth
     from irn_amd.misc import indexing
     edge = torch.from_numpy(synth.edge_field(h, w, seed=7)).to(_dev())
     cam = torch.from_numpy(synth.cam_blobs(c, h, w, seed=7)).to(_dev())
     walker = indexing.RandomWalk(r, _dev())
-    walker.set_option("tile", tile)
     n_sw = 64
     fast = walker([edge], [cam], beta=10, n_sweeps=n_sw)[0]
     n_dirs = {5: 34, 10: 152}[r]

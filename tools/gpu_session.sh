@@ -1,7 +1,7 @@
 #!/bin/bash
 # One gpurun call (round ${ROUND:-5}) (results land in gpurun_out/r4_sN/; copy what should be judged into profiles/).
 # usage: tools/gpu_session.sh <N> [what...]
-#   what: tests tests_all testsel smoke bench default ab abopt prof pmc pmcsq <script under tools/>
+#   what: tests tests_all testsel smoke bench default ab abopt prof pmc pmcsq <script under tools/> (the round-4/5 A/B scripts are in git history)
 #   env:  TESTSEL="-k expr or paths" (testsel), AB_LIBS="libirn_hip.so other.so", AB_WL="walk coco walk_r5",
 #         AB_OPTS="accel=1 accel=0" (abopt: one bench run per option string; "+" joins several options of one run)
 set -u
@@ -103,17 +103,11 @@ warmvoc)
   # tuned NHWC entries for the two image sizes that dominate VOC12 (500x375, 375x500), 8 images per trunk pass
   T0=$(date +%s)
   timeout 1200 python tools/miopen_warmup.py --channels-last 1 --single 0 --sizes ${VOC_SIZES:-375x500,500x375} --out $OUT/miopen_db_voc > $OUT/miopen_warmup_voc.log 2>&1; echo "VOC-size NHWC warm-up rc=$? wall $(( $(date +%s) - T0 )) s"; grep -E "^cam|^irnet|nhwc_shapes|find database" $OUT/miopen_warmup_voc.log ;;
-chlast)
-  bash tools/r4_channels_last_ab.sh $OUT ;;
-miopen)
-  bash tools/r4_miopen_ab.sh $OUT ${MIOPEN_ARGS:-} ;;
 libtests)
   # the walk's GPU tests against another build of the library (IRN_HIP_LIB)
   for lib in ${AB_LIBS:-libirn_hip.so}; do
     IRN_HIP_LIB=$PWD/irn_amd/lib/$lib timeout 900 python -m pytest tests/test_gpu_resident.py tests/test_gpu_schedule.py tests/test_gpu_walk.py tests/test_gpu_parity_r2.py -m gpu -q -x -k "not forward and not edge_displacement" > $OUT/pytest_${lib%.so}.log 2>&1; echo "$lib tests rc=$?"; tail -2 $OUT/pytest_${lib%.so}.log
   done ;;
-stepprof)
-  for lib in ${AB_LIBS:-libirn_hip.so}; do echo "== $lib"; bash tools/r4_profile.sh $OUT $lib; done > $OUT/step_profile.txt 2>&1; cat $OUT/step_profile.txt ;;
 ranks)
   # the N > 1 bench path on this one-GPU box: two ranks on device 0 (gloo), then what RCCL does with a shared device
   timeout 600 python -m pytest tests/test_gpu_bench_ranks.py -m gpu -q -s --durations=5 > $OUT/pytest_ranks.log 2>&1; echo "ranks pytest rc=$?"
