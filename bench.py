@@ -61,7 +61,7 @@ def parse(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default="walk", choices=["walk", "walk_r5", "walk_plain", "walk_voc", "walk_voc_r5", "ins", "ins_r10", "coco", "cam", "e2e", "steps", "steps_voc"])
+    ap.add_argument("--workload", default="walk", choices=["walk", "walk_r5", "walk_plain", "walk_voc", "walk_voc_r5", "ins", "ins_r10", "coco", "cam", "e2e", "cam_fp32", "e2e_fp32", "steps", "steps_voc"])
     ap.add_argument("--batch", type=int, default=0, help="images per GPU per step (0 = workload default)")
     ap.add_argument("--unique", type=int, default=0, help="distinct synthetic images per GPU (0 = the batch: no image twice in a step)")
     ap.add_argument("--variant", type=int, default=2, help="0 generic sweep, 1 blocked streaming sweep, 2 weights-stationary persistent walk")
@@ -85,7 +85,7 @@ def parse(argv=None):
                          "sharing one device, a co-tenant on the GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-legs", action="store_true", help="skip the short secondary runs (cam, e2e, steps, walk_r5, ins, coco)")
-    ap.add_argument("--legs", default="walk_voc,walk_voc_r5,walk_r5,walk_plain,ins,ins_r10,coco,cam,e2e,steps,steps_voc")
+    ap.add_argument("--legs", default="walk_voc,walk_voc_r5,walk_r5,walk_plain,ins,ins_r10,coco,cam,e2e,cam_fp32,e2e_fp32,steps,steps_voc")
     ap.add_argument("--legs-budget-s", type=float, default=240.0,
                     help="stop starting new legs once the legs have used this much wall time (the rest are recorded as skipped)")
     ap.add_argument("--loader-workers", type=int, default=4, help="DataLoader workers of the `steps` workload")
@@ -502,6 +502,9 @@ def run_backbone(a, workload, rank, world, device, dist, parallel, steps, warmup
         cl = _r50.channels_last_for(probe)
     out["trunk"] = {"layout": "channels_last" if cl else "nchw", "fused_1x1_gemm": bool(cl and _r50.FUSED_GEMM and _r50.FUSED_EPILOGUE),
                     "split_precision_1x1": bool(cl and _r50.FUSED_GEMM and _r50.FUSED_EPILOGUE and _r50.SPLIT_GEMM),
+                    "arithmetic": "fp32" + ("; 1x1 convolutions of the bottlenecks as fp16 hi/lo split products (2 x 11-bit operands, fp32 accumulation: "
+                                            "as close to fp64 as the fp32 GEMM, tests/test_gpu_split_gemm.py); the *_fp32 legs run without them"
+                                            if (cl and _r50.FUSED_GEMM and _r50.FUSED_EPILOGUE and _r50.SPLIT_GEMM) else ""),
                     "deterministic": bool(_r50.DETERMINISTIC), "tuned_nhwc_shapes": len(_r50.tuned_nhwc_shapes()),
                     "miopen_db": os.environ.get("MIOPEN_USER_DB_PATH"), "miopen_key": _common.miopen_mode_key()}
     if walker is not None:
@@ -677,10 +680,18 @@ def describe(workload, r):
                 "on a synthetic VOC directory of 512x512 JPEGs, random-init checkpoints, files written")
     return ("%s: synthetic 512x512 uint8 images resident in HBM, multi-scale inputs built on the GPU (irn_msf_pack), ResNet-50 CAM "
             "at scales %s + flip (random-init weights, fp32, MIOpen)%s" %
-            (workload, r.get("scales"), "" if workload == "cam" else "; EdgeDisplacement forward; walk radius 10 beta 10 2^8; label epilogue"))
+            (workload, r.get("scales"), "" if workload.startswith("cam") else "; EdgeDisplacement forward; walk radius 10 beta 10 2^8; label epilogue"))
 
 
 def run_workload(a, workload, rank, world, device, dist, parallel, steps, warmup, batch=0):
+    if workload.endswith("_fp32"):
+        # the backbone legs with the split-precision 1x1 convolutions switched off (IRN_SPLIT_GEMM=0): plain fp32 GEMMs everywhere
+        from irn_amd.net import resnet50 as _r50
+        saved, _r50.SPLIT_GEMM = _r50.SPLIT_GEMM, False
+        try:
+            return run_backbone(a, workload[:-5], rank, world, device, dist, parallel, steps, warmup, batch)
+        finally:
+            _r50.SPLIT_GEMM = saved
     if workload in WALK_WORKLOADS:
         return run_walk(a, workload, rank, world, device, dist, parallel, steps, warmup, batch)
     if workload in ("ins", "ins_r10"):
@@ -691,7 +702,7 @@ def run_workload(a, workload, rank, world, device, dist, parallel, steps, warmup
 
 
 LEG_RUNS = {   # short runs for the `legs` object of the default line: (steps, warmup, batch)
-    "cam": (12, 1, 8), "e2e": (12, 1, 8), "steps": (2, 1, 256), "walk_r5": (10, 2, 256), "walk_plain": (4, 1, 192),
+    "cam": (12, 1, 8), "e2e": (12, 1, 8), "cam_fp32": (12, 1, 8), "e2e_fp32": (12, 1, 8), "steps": (2, 1, 256), "walk_r5": (10, 2, 256), "walk_plain": (4, 1, 192),
     "ins": (10, 2, 128), "ins_r10": (8, 2, 128), "coco": (10, 2, 2),
     "walk_voc": (10, 2, 192), "walk_voc_r5": (10, 2, 256), "steps_voc": (1, 1, 256),
 }
@@ -804,8 +815,7 @@ def main(argv=None):
     device = torch.device("cuda", ordinal)
     if world > 1:          # one line per rank: which device, which shipped data it found (an 8-GPU node met for the first time)
         from irn_amd.step import _common
-        print(_common.startup_line(rank, world, ordinal, os.environ.get("MIOPEN_USER_DB_PATH") or "(claimed at the first backbone pass)"),
-              file=sys.stderr, flush=True)
+        _common.say(_common.startup_line(rank, world, ordinal, os.environ.get("MIOPEN_USER_DB_PATH") or "(claimed at the first backbone pass)"))
     # nccl == RCCL on ROCm.  The data path has no collective — the group only serves the contract's barrier and
     # max-over-ranks — so an RCCL start-up that fails or hangs must not cost the line: `auto` probes it under a deadline,
     # the ranks agree over a gloo control group, and the line says which backend served it
@@ -818,6 +828,7 @@ def main(argv=None):
                  "coco": "random-walk label generation stage, COCO shape", "ins": "instance label generation stage",
                  "ins_r10": "instance label generation stage, radius 10",
                  "cam": "multi-scale CAM inference stage", "e2e": "CAM + IRNet + walk + labels, end to end",
+                 "cam_fp32": "multi-scale CAM inference stage, fp32 GEMMs only", "e2e_fp32": "CAM + IRNet + walk + labels, end to end, fp32 GEMMs only",
                  "walk_voc": "random-walk label generation stage, VOC12 image-size histogram (ragged grids)",
                  "walk_voc_r5": "random-walk label generation stage, VOC12 image-size histogram, radius 5",
                  "steps_voc": "run_sample.py step API on JPEGs with the VOC12 image-size histogram",

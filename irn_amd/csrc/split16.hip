@@ -22,15 +22,29 @@ constexpr int kThreads = 256;
 constexpr float kFp16Max = 65504.f;
 
 // one thread = 8 consecutive channels of one pixel: two 16-byte loads, three 16-byte stores
+// Row maps of the padded form (irn_split16_pad): pixel (n, y, x) of an [N, h, w] map lives at row n (h+2)(w+2) + (y+1)(w+2) + x+1
+// of the zero-bordered layout a 3x3 / pad 1 convolution reads as nine row-shifted GEMM operands (conv1x1.cpp).
+struct PadMap {
+    unsigned h, w;          // 0, 0: dense on both sides
+    int in_pad, out_pad;
+};
+__device__ __forceinline__ unsigned padded_row(unsigned row, unsigned h, unsigned w) {
+    const unsigned n = row / (h * w), r = row - n * (h * w), y = r / w, x = r - y * w;
+    return n * (h + 2u) * (w + 2u) + (y + 1u) * (w + 2u) + x + 1u;
+}
+
 template <bool BN, bool RELU>
 __global__ __launch_bounds__(kThreads) void split16_kernel(const float *__restrict__ x, const float *__restrict__ scale,
                                                            const float *__restrict__ shift, _Float16 *__restrict__ out,
                                                            unsigned n_pieces, unsigned n_ch, unsigned pieces_per_row,
-                                                           unsigned *__restrict__ overflow) {
+                                                           unsigned *__restrict__ overflow, PadMap pm) {
     const unsigned p = blockIdx.x * (unsigned)kThreads + threadIdx.x;
     if (p >= n_pieces) return;
-    const unsigned row = p / pieces_per_row, c0 = (p - row * pieces_per_row) * 8u;
-    const f4v *src = reinterpret_cast<const f4v *>(x + (size_t)p * 8u);
+    unsigned row = p / pieces_per_row;
+    const unsigned c0 = (p - row * pieces_per_row) * 8u;
+    const unsigned prow = pm.h ? padded_row(row, pm.h, pm.w) : row;
+    const f4v *src = reinterpret_cast<const f4v *>(x + (size_t)(pm.in_pad ? prow : row) * n_ch + c0);
+    if (pm.out_pad) row = prow;
     f4v a = __builtin_nontemporal_load(src), b = __builtin_nontemporal_load(src + 1);
     float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
     if (BN) {
@@ -63,9 +77,10 @@ __global__ __launch_bounds__(kThreads) void split16_kernel(const float *__restri
 }  // namespace
 }  // namespace irn
 
-extern "C" int irn_split16(const float *x_dev, const float *scale_dev, const float *shift_dev, int relu, void *out_dev,
-                           int64_t n_pixels, int n_channels, unsigned *overflow_dev, void *stream) {
-    using namespace irn;
+namespace irn {
+namespace {
+int split16_launch(const float *x_dev, const float *scale_dev, const float *shift_dev, int relu, void *out_dev, int64_t n_pixels,
+                   int n_channels, unsigned *overflow_dev, void *stream, PadMap pm) {
     if (!x_dev || !out_dev) return fail(IRN_ERR_ARG, "irn_split16: null pointer");
     if ((scale_dev != nullptr) != (shift_dev != nullptr)) return fail(IRN_ERR_ARG, "irn_split16: scale and shift come together");
     if (relu && !scale_dev) return fail(IRN_ERR_ARG, "irn_split16: relu only with the batch norm in front of it");
@@ -79,9 +94,26 @@ extern "C" int irn_split16(const float *x_dev, const float *scale_dev, const flo
     const dim3 grid((n_pieces + kThreads - 1) / kThreads), block(kThreads);
     hipStream_t s = (hipStream_t)stream;
     _Float16 *out = (_Float16 *)out_dev;
-    if (!scale_dev) hipLaunchKernelGGL((split16_kernel<false, false>), grid, block, 0, s, x_dev, scale_dev, shift_dev, out, n_pieces, (unsigned)n_channels, ppr, overflow_dev);
-    else if (relu) hipLaunchKernelGGL((split16_kernel<true, true>), grid, block, 0, s, x_dev, scale_dev, shift_dev, out, n_pieces, (unsigned)n_channels, ppr, overflow_dev);
-    else hipLaunchKernelGGL((split16_kernel<true, false>), grid, block, 0, s, x_dev, scale_dev, shift_dev, out, n_pieces, (unsigned)n_channels, ppr, overflow_dev);
+    if (!scale_dev) hipLaunchKernelGGL((split16_kernel<false, false>), grid, block, 0, s, x_dev, scale_dev, shift_dev, out, n_pieces, (unsigned)n_channels, ppr, overflow_dev, pm);
+    else if (relu) hipLaunchKernelGGL((split16_kernel<true, true>), grid, block, 0, s, x_dev, scale_dev, shift_dev, out, n_pieces, (unsigned)n_channels, ppr, overflow_dev, pm);
+    else hipLaunchKernelGGL((split16_kernel<true, false>), grid, block, 0, s, x_dev, scale_dev, shift_dev, out, n_pieces, (unsigned)n_channels, ppr, overflow_dev, pm);
     IRN_LAUNCH_CHECK("split16_kernel");
     return IRN_OK;
+}
+}  // namespace
+}  // namespace irn
+
+extern "C" int irn_split16(const float *x_dev, const float *scale_dev, const float *shift_dev, int relu, void *out_dev,
+                           int64_t n_pixels, int n_channels, unsigned *overflow_dev, void *stream) {
+    return irn::split16_launch(x_dev, scale_dev, shift_dev, relu, out_dev, n_pixels, n_channels, overflow_dev, stream, irn::PadMap{0u, 0u, 0, 0});
+}
+
+extern "C" int irn_split16_pad(const float *x_dev, const float *scale_dev, const float *shift_dev, int relu, void *out_dev,
+                               int64_t n_images, int h, int w, int n_channels, int in_padded, int out_padded, unsigned *overflow_dev,
+                               void *stream) {
+    using namespace irn;
+    if (n_images < 0 || h < 1 || w < 1) return fail(IRN_ERR_ARG, "irn_split16_pad: n_images >= 0, h, w >= 1");
+    if ((int64_t)n_images * (h + 2) * (w + 2) * n_channels >= (1ll << 31)) return fail(IRN_ERR_ARG, "irn_split16_pad: at most 2^31 - 1 padded elements per call");
+    return split16_launch(x_dev, scale_dev, shift_dev, relu, out_dev, n_images * h * w, n_channels, overflow_dev, stream,
+                          PadMap{(unsigned)h, (unsigned)w, in_padded ? 1 : 0, out_padded ? 1 : 0});
 }

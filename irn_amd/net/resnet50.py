@@ -179,6 +179,11 @@ FUSED_GEMM = os.environ.get("IRN_FUSED_GEMM", "1") != "0"
 SPLIT_GEMM = os.environ.get("IRN_SPLIT_GEMM", "1") != "0"
 SPLIT_MIN_PLANES = int(os.environ.get("IRN_SPLIT_MIN_PLANES", "64"))
 SPLIT_MIN_INPUT = int(os.environ.get("IRN_SPLIT_MIN_INPUT", str(1 << 20)))
+#   conv2 (3x3, stride 1) of units with at least SPLIT_MIN_PLANES_3X3 planes on maps of at least SPLIT_MIN_ROWS_3X3 pixels per
+#       pass: nine accumulating split GEMMs on the zero-bordered operand (ops.conv3x3_split) — 1.7-2.2x MIOpen's fp32 convolution
+#       at 512 planes from 32x32 maps up, level at 16x16 and at 256 planes (profiles/r06_s6_conv3x3_split_probe.txt): stage 4 only.
+SPLIT_MIN_PLANES_3X3 = int(os.environ.get("IRN_SPLIT_MIN_PLANES_3X3", "512"))
+SPLIT_MIN_ROWS_3X3 = int(os.environ.get("IRN_SPLIT_MIN_ROWS_3X3", "8192"))
 
 
 def _gemm_path(x):
@@ -333,6 +338,10 @@ class Bottleneck(nn.Module):
                     if planes >= SPLIT_MIN_PLANES:
                         p["w3_16"], p["a3"] = ops.split_weight(folded64[1].flatten(1))
                         p["s2"], p["t2"] = self.bn2.folded()
+                        c2 = self.conv2
+                        if (planes >= SPLIT_MIN_PLANES_3X3 and planes % 8 == 0 and tuple(c2.kernel_size) == (3, 3) and tuple(c2.stride) == (1, 1)
+                                and tuple(c2.padding) == (1, 1) and tuple(c2.dilation) == (1, 1) and c2.groups == 1):
+                            p["w2_16"], p["a2"] = ops.split_weight_3x3(c2.weight.detach().double())
                     if cin * couts >= SPLIT_MIN_INPUT and cin % 8 == 0:
                         p["w1_16"], p["a1"] = ops.split_weight(folded64[0].flatten(1))
                         if self.downsample is not None and tuple(self.downsample[0].stride) == (1, 1):
@@ -362,8 +371,13 @@ class Bottleneck(nn.Module):
         else:
             y = ops.conv1x1_nhwc(x, p["w1"], p["b1"], relu=True)
         c2 = self.conv2
-        y = F.conv2d(y, p["w2"], None, c2.stride, c2.padding, c2.dilation, c2.groups)
-        y = y.contiguous(memory_format=torch.channels_last)
+        y_pad = None
+        if "w2_16" in p and y.shape[0] * y.shape[2] * y.shape[3] >= SPLIT_MIN_ROWS_3X3:
+            y_shape = tuple(int(v) for v in y.shape)
+            y_pad = ops.conv3x3_split(y, p["w2_16"], p["a2"])        # bordered fp32 [N (H+2)(W+2), planes]
+        else:
+            y = F.conv2d(y, p["w2"], None, c2.stride, c2.padding, c2.dilation, c2.groups)
+            y = y.contiguous(memory_format=torch.channels_last)
         ds = self.downsample[0] if self.downsample is not None else None
         sc = None
         if ds is not None:
@@ -374,6 +388,10 @@ class Bottleneck(nn.Module):
             else:
                 sc = ops.conv1x1_nhwc(x, p["wd"].reshape(p["wd"].shape[0], -1))
         res = x if ds is None else sc
+        if y_pad is not None:
+            y3 = ops.split16_pad(y_pad, y_shape, p["s2"], p["t2"], relu=True, in_padded=True)
+            return ops.gemm16_nhwc(y3, p["w3_16"], (y_shape[0], p["w3"].shape[0], y_shape[2], y_shape[3]), p["b3"], residual=res, relu=True,
+                                   alpha=p["a3"], out=sc)
         if "w3_16" in p and y.shape[1] % 8 == 0:
             # bn2 + ReLU + split in one pass over the 3x3 convolution's output, then ONE fp16 GEMM with the unit's whole tail
             y3 = ops.split16(y, p["s2"], p["t2"], relu=True)

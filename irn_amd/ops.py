@@ -322,19 +322,97 @@ def gemm16_nhwc(a16, b16, shape, bias=None, residual=None, relu=False, alpha=1.0
     return out
 
 
-def split_weight(w64):
+def split_weight(w64, p=None):
     """Weight [cout, cin] (float64, batch norm folded in) -> (b16 fp16 [cout, 3 cin] = [w_hi | w_lo | w_hi 2^-11] of w 2^p, alpha =
     2^-p): p puts the largest |w 2^p| into [2^13, 2^14), so that w_lo = fp16(w 2^p - w_hi) <= 8 stays a normal fp16 number for
-    every weight above 2^-17 of the largest (smaller ones contribute below the fp32 rounding of the sum)."""
+    every weight above 2^-17 of the largest (smaller ones contribute below the fp32 rounding of the sum).  `p` given: the
+    exponent of a larger tensor this one is a slice of (the taps of a 3x3 weight share one)."""
     import math
     w64 = w64.detach().double()
-    top = float(w64.abs().max())
-    p = 13 - int(math.floor(math.log2(top))) if top > 0 else 0
+    if p is None:
+        top = float(w64.abs().max())
+        p = 13 - int(math.floor(math.log2(top))) if top > 0 else 0
     ws = w64 * (2.0 ** p)
     hi = ws.to(torch.float16)
     lo = (ws - hi.double()).to(torch.float16)
     hi_s = (hi.double() * 2.0 ** -11).to(torch.float16)
     return torch.cat([hi, lo, hi_s], dim=1).contiguous(), 2.0 ** -p
+
+
+def split_weight_3x3(w64):
+    """3x3 weight [cout, cin, 3, 3] (float64) -> (fp16 [9, cout, 3 cin]: one `split_weight` operand per tap (ky, kx) in raster
+    order, one common exponent, alpha)."""
+    import math
+    w64 = w64.detach().double()
+    top = float(w64.abs().max())
+    p = 13 - int(math.floor(math.log2(top))) if top > 0 else 0
+    taps = [split_weight(w64[:, :, ky, kx], p)[0] for ky in range(3) for kx in range(3)]
+    return torch.stack(taps).contiguous(), 2.0 ** -p
+
+
+_PAD_BUFS = {}         # (device, stream, n, c, h, w, cout) -> (zero-bordered fp16 operand, fp32 result), a few most recent shapes
+_PAD_BUFS_MAX = 6
+
+
+def split16_pad(x, shape, scale=None, shift=None, relu=False, in_padded=False, out=None):
+    """`split16` between a dense map and its zero-bordered form (irn_split16_pad).  shape = (n, c, h, w) of the DENSE map.
+    in_padded: `x` is the bordered fp32 form [n (h+2)(w+2), c] (a `conv3x3_split` result), the result is the dense fp16
+    [n h w, 3c]; `out` given (a bordered fp16 buffer's interior view, borders already zero): `x` is a dense channels-last fp32
+    tensor and the split goes into the bordered form."""
+    n, c, h, w_ = (int(v) for v in shape)
+    _need_cuda(x, "x")
+    if c % 8:
+        raise ValueError("split16_pad: %d channels; a multiple of 8 is needed" % c)
+    if in_padded:
+        if x.dtype != torch.float32 or not x.is_contiguous() or x.numel() != n * (h + 2) * (w_ + 2) * c:
+            raise ValueError("split16_pad: x must be the contiguous bordered fp32 form of a %s map" % (shape,))
+    elif x.dtype != torch.float32 or tuple(x.shape) != (n, c, h, w_) or not x.is_contiguous(memory_format=torch.channels_last):
+        raise ValueError("split16_pad: x must be a channels-last fp32 %s tensor" % (shape,))
+    out_padded = out is not None
+    if out is None:
+        out = torch.empty((n * h * w_, 3 * c), dtype=torch.float16, device=x.device)
+    elif out.dtype != torch.float16 or not out.is_contiguous() or out.numel() < n * (h + 2) * (w_ + 2) * 3 * c:
+        raise ValueError("split16_pad: out must be a contiguous fp16 buffer of the bordered form")
+    if n * h * w_ == 0:
+        return out
+    with torch.cuda.device(x.device):
+        check(lib.irn_split16_pad(x.data_ptr(), None if scale is None else scale.data_ptr(), None if shift is None else shift.data_ptr(),
+                                  1 if relu else 0, out.data_ptr(), n, h, w_, c, 1 if in_padded else 0, 1 if out_padded else 0,
+                                  _split_flag(x.device).data_ptr(), _stream()))
+    return out
+
+
+def conv3x3_split(x, w16, alpha):
+    """3x3 / stride 1 / pad 1 convolution (no bias) of a channels-last fp32 activation [N, C, H, W] in the split-precision form,
+    WITHOUT materialising an im2col operand: the activation is split once into a zero-bordered fp16 matrix [N (H+2)(W+2), 3C];
+    there tap (ky, kx) is the same matrix shifted by (ky-1)(W+2) + (kx-1) rows, so the convolution is nine `gemm16_nhwc` calls
+    accumulating in fp32 (fixed order).  w16 = `split_weight_3x3` fp16 [9, cout, 3C].  -> the result in the bordered fp32 form
+    [N (H+2)(W+2), cout] (border rows hold garbage; `split16_pad(..., in_padded=True)` reads the interior).  Valid until the
+    next call with the same shape on this stream.  Reference: conv2 of Bottleneck.forward, net/resnet50.py:40."""
+    _need_cuda(x, "x")
+    n, c, h, w_ = (int(v) for v in x.shape)
+    cout = int(w16.shape[1])
+    if tuple(w16.shape) != (9, cout, 3 * c) or w16.dtype != torch.float16 or not w16.is_contiguous():
+        raise ValueError("conv3x3_split: w16 must be a contiguous fp16 [9, cout, %d] tensor" % (3 * c))
+    hp, wp = h + 2, w_ + 2
+    m_pad, guard = n * hp * wp, wp + 1
+    key = (x.device.index, torch.cuda.current_stream(x.device).cuda_stream, n, c, h, w_, cout)
+    bufs = _PAD_BUFS.pop(key, None)
+    if bufs is None:
+        while len(_PAD_BUFS) >= _PAD_BUFS_MAX:
+            _PAD_BUFS.pop(next(iter(_PAD_BUFS)))
+        bufs = (torch.zeros((m_pad + 2 * guard, 3 * c), dtype=torch.float16, device=x.device),
+                torch.empty((1, cout, m_pad, 1), dtype=torch.float32, device=x.device).contiguous(memory_format=torch.channels_last))
+    _PAD_BUFS[key] = bufs                         # most recent last
+    a_buf, out = bufs
+    split16_pad(x, (n, c, h, w_), out=a_buf[guard:])
+    t = 0
+    for ky in range(3):
+        for kx in range(3):
+            off = guard + (ky - 1) * wp + (kx - 1)
+            gemm16_nhwc(a_buf[off:off + m_pad], w16[t], (1, cout, m_pad, 1), residual=out if t else None, alpha=alpha, out=out)
+            t += 1
+    return out.view(m_pad, cout)
 
 
 def conv1x1_algo_count(m, cin, cout, bias, residual, relu):

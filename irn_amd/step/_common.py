@@ -213,6 +213,16 @@ def untuned_report(reset=True):
                 "; %d zero rows filled partial passes" % pad if pad else ""))
 
 
+def say(line):
+    """One whole line on stderr in ONE write: eight ranks starting at once must not interleave each other's lines."""
+    import sys
+    try:
+        sys.stderr.flush()
+        os.write(sys.stderr.fileno(), (line.rstrip("\n") + "\n").encode("utf-8", "replace"))
+    except Exception:            # no real file behind sys.stderr (a capturing harness)
+        print(line, file=sys.stderr, flush=True)
+
+
 def startup_line(rank, n_workers, device, db_dir):
     """One line per worker / rank at start-up (stderr): which device it owns and whether the data this build's speed rests
     on was found for it — the things that differ between the box the defaults were measured on and an eight-GPU node met for
@@ -253,7 +263,7 @@ def step_summary(rank, walker=None):
         except Exception:
             pass
     for m in parts:
-        print("[worker %d] %s" % (int(rank), m), file=sys.stderr, flush=True)
+        say("[worker %d] %s" % (int(rank), m))
 
 
 def check_split_overflow(what):
@@ -396,8 +406,7 @@ def _pool_worker(rank, device, n_workers, cmd_q, res_q):
             os.environ.pop("IRN_MIOPEN_DB_DEV", None)
             db_dir = miopen_setup(int(device))           # stable per-device database, never shared by two live processes
             torch.cuda.set_device(int(device))
-            import sys
-            print(startup_line(rank, n_workers, device, db_dir), file=sys.stderr, flush=True)
+            say(startup_line(rank, n_workers, device, db_dir))
         res_q.put((rank, "ready", None))
         while True:
             cmd = cmd_q.get()
@@ -558,8 +567,7 @@ def spawn_workers(work, model, shards, args):
             db_dir = miopen_setup(devs[0])      # the same MIOpen settings a pool worker would run with
             if "startup" not in _WARNED:
                 _WARNED.add("startup")
-                import sys
-                print(startup_line(0, 1, devs[0], db_dir), file=sys.stderr, flush=True)
+                say(startup_line(0, 1, devs[0], db_dir))
             work(0, model, shards, args)
             torch.cuda.synchronize()
             step_summary(0)

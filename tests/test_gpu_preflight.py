@@ -41,12 +41,14 @@ def test_bench_walk_as_eight_ranks_on_one_device():
     assert out.returncode == 0, out.stderr[-3000:]
     assert len(lines) == 1, out.stdout[-2000:]
     d = json.loads(lines[0])
-    starts = [l for l in out.stderr.splitlines() if l.startswith("irn_amd worker ")]
+    import re
+    starts = [l[l.index("irn_amd worker "):] for l in out.stderr.splitlines() if "irn_amd worker " in l]     # (a library may have left text in front)
+    ranks = sorted(int(v) for v in re.findall(r"irn_amd worker (\d+)/8", out.stderr))
     print("bench.py walk, 8 ranks on device 0: %.0f images/s whole job, %.2f ms per step, %.0f s wall; start-up lines: %d, e.g. %s" % (
         d["value"], d["ms_per_step"], wall, len(starts), starts[0] if starts else None))
     assert d["n_gpus"] == 8 and d["config"]["process_group"]["ranks"] == 8 and d["config"]["process_group"]["backend"] == "gloo"
     assert d["value"] > 0 and d["scaling"] == "weak" and d["config"]["images_per_gpu_per_step"] == 16 and d["roofline"]["achieved"] > 0
-    assert len(starts) == 8 and sorted(int(l.split()[2].split("/")[0]) for l in starts) == list(range(8))
+    assert ranks == list(range(8)), out.stderr[-3000:]
     assert all("MIOpen database" in l and "GEMM rank table" in l for l in starts)
 
 
@@ -115,7 +117,7 @@ def test_run_sample_four_workers_write_the_files_of_one_on_a_mixed_tree(tmp_path
 
     four, t4 = run("four", "0,0,0,0")
     one, t1 = run("one", "0")
-    starts = [l for l in four.stderr.splitlines() if l.startswith("irn_amd worker ")]
+    starts = [l for l in four.stderr.splitlines() if "irn_amd worker " in l]
     nchw = [l for l in (four.stderr + one.stderr).splitlines() if "trunk passes ran NCHW" in l]
     print("run_sample.py on %d images of 5 sizes: four workers %.0f s, one worker %.0f s; %d start-up lines; NCHW reports: %s" % (
         len(names), t4, t1, len(starts), nchw[:2]))

@@ -100,6 +100,42 @@ def test_split_gemm_equals_the_exact_expression_like_the_fp32_gemm(case, bias, r
         assert out.data_ptr() == buf.data_ptr() and torch.equal(out, got)
 
 
+@pytest.mark.parametrize("n,c,cout,h,w", [(2, 64, 32, 9, 11), (1, 512, 512, 16, 16), (3, 128, 256, 7, 5), (2, 8, 8, 1, 1), (1, 16, 8, 1, 6)])
+def test_conv3x3_as_nine_accumulating_split_gemms(n, c, cout, h, w):
+    """ops.conv3x3_split (irn_split16_pad + 9 x irn_gemm16_nhwc on row-shifted views of the zero-bordered operand) against the
+    exact 3x3 / pad 1 convolution, at the accuracy of MIOpen's fp32 convolution; the bordered result read back through the
+    batch-norm + ReLU + split pass equals the dense one; same bits on every call, also after other shapes used the buffers."""
+    import torch.nn.functional as F
+    from irn_amd import ops
+    dev = _dev()
+    g = torch.Generator().manual_seed(n * 100 + c + h)
+    x = torch.relu(torch.randn(n, c, h, w, generator=g)) * 2.0
+    wt = torch.randn(cout, c, 3, 3, generator=g) / (9 * c) ** 0.5
+    want = F.conv2d(x.double(), wt.double(), None, 1, 1)
+    w16, alpha = ops.split_weight_3x3(wt.double().to(dev))
+    assert w16.shape == (9, cout, 3 * c)
+    xd = _cl(x.to(dev))
+    pad = ops.conv3x3_split(xd, w16, alpha)
+    assert pad.shape == (n * (h + 2) * (w + 2), cout)
+    got = pad.view(n, h + 2, w + 2, cout)[:, 1:-1, 1:-1].permute(0, 3, 1, 2).cpu().double()
+    f32 = F.conv2d(xd, _cl(wt.to(dev)), None, 1, 1).cpu().double()
+    err, err32, scale = float((got - want).abs().max()), float((f32 - want).abs().max()), float(want.abs().max())
+    print("3x3 %s -> %d: nine split GEMMs %.2e, MIOpen fp32 %.2e from fp64 (max |value| %.2f)" % ((n, c, h, w), cout, err, err32, scale))
+    assert err <= 4.0 * err32 + 2e-6 * scale and err <= 1e-5 * max(1.0, scale)
+    first = pad.clone()
+    # the bordered form through the tail pass: batch norm + ReLU + split of the interior == the same pass on the dense tensor
+    scale_c, shift_c = (torch.rand(cout, generator=g) + 0.5).to(dev), torch.randn(cout, generator=g).to(dev)
+    if cout % 8 == 0:
+        dense = _cl(pad.view(n, h + 2, w + 2, cout)[:, 1:-1, 1:-1].permute(0, 3, 1, 2).contiguous())
+        a = ops.split16_pad(pad, (n, cout, h, w), scale_c, shift_c, relu=True, in_padded=True)
+        b = ops.split16(dense, scale_c, shift_c, relu=True)
+        assert torch.equal(a, b)
+    ops.conv3x3_split(_cl(torch.randn(1, c, h + 1, w + 2, generator=g).to(dev)), w16, alpha)       # another shape in between
+    again = ops.conv3x3_split(xd, w16, alpha)
+    assert torch.equal(again, first)
+    assert not ops.split_overflowed()
+
+
 def test_bottleneck_split_path_vs_composed_modules_and_fp32_gemm_path(monkeypatch):
     """A whole unit (identity and projection, stride 1) on the channels-last inference path with IRN_SPLIT_GEMM on: against the
     composed PyTorch modules (conv -> FrozenBatchNorm -> ReLU ... in NCHW, what the reference runs) and against the fp32-GEMM
@@ -120,9 +156,11 @@ def test_bottleneck_split_path_vs_composed_modules_and_fp32_gemm_path(monkeypatc
             monkeypatch.setattr(r50, "SPLIT_GEMM", True)
             monkeypatch.setattr(r50, "SPLIT_MIN_PLANES", 64)
             monkeypatch.setattr(r50, "SPLIT_MIN_INPUT", 1 << 20)
+            monkeypatch.setattr(r50, "SPLIT_MIN_ROWS_3X3", 1)             # the 512-plane units take the nine-GEMM 3x3 here too
             unit._gemm = None
             y_split = unit(_cl(x))
             p = unit.gemm_params()
+            assert ("w2_16" in p) == (planes >= 512)
             assert "w3_16" in p and (("w1_16" in p) == (c_in * (planes + (4 * planes if project else 0)) >= 1 << 20))
             assert torch.equal(y_split, unit(_cl(x)))
             monkeypatch.setattr(r50, "SPLIT_GEMM", False)
