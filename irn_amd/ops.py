@@ -291,7 +291,37 @@ def split16(x, scale=None, shift=None, relu=False):
     return out
 
 
-def gemm16_nhwc(a16, b16, shape, bias=None, residual=None, relu=False, alpha=1.0, out=None, algo_rank=0):
+def gemm16_algo_count(m, k, cout, bias, residual, relu):
+    """How many kernels hipBLASLt's heuristic offers for the split-precision problem (tools/gemm16_tune.py times each once)."""
+    n = C.c_int(0)
+    check(lib.irn_gemm16_algo_count(int(m), int(k), int(cout), int(bool(bias)), int(bool(residual)), int(bool(relu)),
+                                    int(lib.irn_conv1x1_workspace_bytes()), C.byref(n)))
+    return n.value
+
+
+_GEMM_RANKS16 = None
+
+
+def gemm_ranks16():
+    """`ranks16` of the shipped table (gemm_ranks): (m, k, cout, bias, residual, relu) -> entry of hipBLASLt's list for the fp16
+    operand problems, measured once per device by tools/gemm16_tune.py; unlisted problems use entry 0."""
+    global _GEMM_RANKS16
+    if _GEMM_RANKS16 is None:
+        ranks = {}
+        try:
+            import json
+            import os
+            from .step import _common
+            path = os.path.join(_common.gemm_table_root(), _common.miopen_cache_key() + ".json")
+            if os.path.exists(path) and os.environ.get("IRN_GEMM_TABLE", "1") != "0":
+                ranks = {tuple(int(v) for v in k.split(",")): int(r) for k, r in json.load(open(path)).get("ranks16", {}).items()}
+        except Exception:
+            ranks = {}
+        _GEMM_RANKS16 = ranks
+    return _GEMM_RANKS16
+
+
+def gemm16_nhwc(a16, b16, shape, bias=None, residual=None, relu=False, alpha=1.0, out=None, algo_rank=None):
     """act(alpha * a16 . b16^T + bias (+ residual)) as a channels-last fp32 [N, cout, H, W] tensor of `shape` (irn_gemm16_nhwc):
     a16 fp16 [N*H*W, k] from `split16`, b16 fp16 [cout, k] = [w_hi | w_lo | w_hi 2^-11] of the weight scaled by 1 / alpha."""
     _need_cuda(a16, "a16")
@@ -315,6 +345,16 @@ def gemm16_nhwc(a16, b16, shape, bias=None, residual=None, relu=False, alpha=1.0
     ws = _GEMM_WS.get(dev)
     if ws is None:
         ws = _GEMM_WS[dev] = torch.empty(int(lib.irn_conv1x1_workspace_bytes()), dtype=torch.uint8, device=a16.device)
+    if algo_rank is None:
+        prob = (m, k, cout, int(bias is not None), int(residual is not None), int(bool(relu)))
+        algo_rank = gemm_ranks16().get(prob, 0)
+        if algo_rank:
+            n_algos = _GEMM_NALGOS.get(("f16",) + prob)
+            if n_algos is None:
+                with torch.cuda.device(a16.device):
+                    n_algos = _GEMM_NALGOS[("f16",) + prob] = gemm16_algo_count(*prob)
+            if algo_rank >= n_algos:          # another hipBLASLt build than the one the table was measured with
+                algo_rank = 0
     with torch.cuda.device(a16.device):
         check(lib.irn_gemm16_nhwc(a16.data_ptr(), b16.data_ptr(), None if bias is None else bias.data_ptr(),
                                   None if residual is None else residual.data_ptr(), out.data_ptr(), m, k, cout,
@@ -402,9 +442,10 @@ def conv3x3_split(x, w16, alpha):
         while len(_PAD_BUFS) >= _PAD_BUFS_MAX:
             _PAD_BUFS.pop(next(iter(_PAD_BUFS)))
         bufs = (torch.zeros((m_pad + 2 * guard, 3 * c), dtype=torch.float16, device=x.device),
-                torch.empty((1, cout, m_pad, 1), dtype=torch.float32, device=x.device).contiguous(memory_format=torch.channels_last))
+                torch.empty((m_pad, cout), dtype=torch.float32, device=x.device))
     _PAD_BUFS[key] = bufs                         # most recent last
-    a_buf, out = bufs
+    a_buf, out2d = bufs
+    out = out2d.view(1, m_pad, 1, cout).permute(0, 3, 1, 2)         # the same memory as a channels-last [1, cout, m_pad, 1] tensor
     split16_pad(x, (n, c, h, w_), out=a_buf[guard:])
     t = 0
     for ky in range(3):
@@ -412,7 +453,7 @@ def conv3x3_split(x, w16, alpha):
             off = guard + (ky - 1) * wp + (kx - 1)
             gemm16_nhwc(a_buf[off:off + m_pad], w16[t], (1, cout, m_pad, 1), residual=out if t else None, alpha=alpha, out=out)
             t += 1
-    return out.view(m_pad, cout)
+    return out2d
 
 
 def conv1x1_algo_count(m, cin, cout, bias, residual, relu):

@@ -25,3 +25,7 @@ done
 run 3x3_on_256 cam IRN_SPLIT_MIN_PLANES_3X3=256
 run steps_on steps
 run steps_voc_on steps_voc
+# rank table of the fp16 problems, then the same legs with it
+timeout 900 python tools/gemm16_tune.py $OUT/tune > $OUT/gemm16_tune.log 2>&1; echo "tune rc=$?"; tail -4 $OUT/gemm16_tune.log
+run table_on cam
+run table_on e2e
