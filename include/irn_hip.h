@@ -307,12 +307,18 @@ int irn_conv1x1_nhwc(const float *x_dev, const float *w_dev, const float *bias_d
 int irn_split16(const float *x_dev, const float *scale_dev, const float *shift_dev, int relu, void *out_dev, int64_t n_pixels,
                 int n_channels, unsigned *overflow_dev, void *stream);
 /* The same pass between a dense map [n_images, h, w, n_channels] and its zero-bordered form [n_images, h+2, w+2, .] (pixel (n, y, x)
- * at row n (h+2)(w+2) + (y+1)(w+2) + x+1; borders are never written — the caller zeroes the buffer once): in_padded = x is the
- * bordered fp32 form (interior read), out_padded = out is the bordered fp16 form (interior written).  On the bordered form a
- * 3x3 / pad 1 / stride 1 convolution (conv2 of Bottleneck.forward, net/resnet50.py:40) is NINE irn_gemm16_nhwc calls that
- * accumulate (residual = out) over row-shifted views of one operand: tap (ky, kx) reads row r + (ky-1)(w+2) + (kx-1). */
+ * at row n (h+2)(w+2) + (y+1)(w+2) + x+1): in_padded = x is the bordered fp32 form (interior read), out_padded = out is the
+ * bordered fp16 form (interior split from the pixels, border rows written as zeros: the buffer needs no preparation).  On the
+ * bordered form a 3x3 / pad 1 / stride 1 convolution (conv2 of Bottleneck.forward, net/resnet50.py:40) is NINE fp16 GEMMs that
+ * accumulate over row-shifted views of one operand — tap (ky, kx) reads row r + (ky-1)(w+2) + (kx-1):
+ * irn_conv3x3_split_gemm: a16 dev fp16 = the bordered operand [n (h+2)(w+2), 3 cin] with (w+3) rows of valid memory in front of
+ *   and behind it (any content), w16 dev fp16 [9, cout, 3 cin] (one irn_gemm16_nhwc operand per tap, raster order, one common
+ *   scale), out dev fp32 [n (h+2)(w+2), cout] = alpha sum_taps a16[shifted] . w16[tap]^T, accumulated tap after tap in fp32 in a
+ *   fixed order; border rows of `out` hold garbage.  algo_rank / workspace as irn_conv1x1_nhwc. */
 int irn_split16_pad(const float *x_dev, const float *scale_dev, const float *shift_dev, int relu, void *out_dev, int64_t n_images,
                     int h, int w, int n_channels, int in_padded, int out_padded, unsigned *overflow_dev, void *stream);
+int irn_conv3x3_split_gemm(const void *a16_dev, const void *w16_dev, float *out_dev, int64_t n_images, int h, int w, int cin, int cout,
+                           float alpha, int algo_rank, void *workspace_dev, size_t workspace_bytes, void *stream);
 int irn_gemm16_algo_count(int64_t m, int k, int cout, int has_bias, int has_residual, int relu, size_t workspace_bytes,
                           int *count_out);
 int irn_gemm16_nhwc(const void *a16_dev, const void *b16_dev, const float *bias_dev, const float *residual_dev, float *out_dev,

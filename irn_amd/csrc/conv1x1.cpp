@@ -218,4 +218,38 @@ int irn_gemm16_nhwc(const void *a16_dev, const void *b16_dev, const float *bias_
     return IRN_OK;
 }
 
+// 3x3 / pad 1 / stride 1 convolution on the zero-bordered split operand (irn_split16_pad): nine accumulating GEMMs, one call.
+int irn_conv3x3_split_gemm(const void *a16_dev, const void *w16_dev, float *out_dev, int64_t n_images, int h, int w, int cin, int cout,
+                           float alpha, int algo_rank, void *workspace_dev, size_t workspace_bytes, void *stream) {
+    using namespace irn;
+    if (!a16_dev || !w16_dev || !out_dev) return fail(IRN_ERR_ARG, "conv3x3_split_gemm: a16, w16 and out must not be NULL");
+    if (n_images < 1 || h < 1 || w < 1) return fail(IRN_ERR_ARG, "conv3x3_split_gemm: n_images, h, w must be positive");
+    const int64_t m = n_images * (h + 2) * (int64_t)(w + 2);
+    const int k = 3 * cin;
+    if (int rc = check_shape(m, k, cout)) return rc;
+    if (k & 7) return fail(IRN_ERR_ARG, "conv3x3_split_gemm: cin = %d must be a multiple of 8", cin);
+    if (workspace_bytes && !workspace_dev) return fail(IRN_ERR_ARG, "conv3x3_split_gemm: workspace_bytes > 0 with a NULL workspace");
+    int dev = 0;
+    IRN_HIP_TRY(hipGetDevice(&dev));
+    std::lock_guard<std::mutex> lk(g_mu);
+    hipblasLtHandle_t handle;
+    if (int rc = get_handle(dev, &handle)) return rc;
+    Plan *first = nullptr, *rest = nullptr;          // beta = 0 for the first tap, 1 (C = D = out) for the other eight
+    if (int rc = get_plan(handle, dev, m, k, cout, false, false, false, workspace_bytes, &first, 1)) return rc;
+    if (int rc = get_plan(handle, dev, m, k, cout, false, true, false, workspace_bytes, &rest, 1)) return rc;
+    if (int rc = get_plan(handle, dev, m, k, cout, false, false, false, workspace_bytes, &first, 1)) return rc;      // (the cache may have been emptied by the call above)
+    const int r0 = algo_rank >= 0 && algo_rank < first->n_algos ? algo_rank : 0, r1 = algo_rank >= 0 && algo_rank < rest->n_algos ? algo_rank : 0;
+    const char *a = (const char *)a16_dev, *wt = (const char *)w16_dev;
+    const size_t row_bytes = (size_t)k * 2u, tap_bytes = (size_t)cout * k * 2u;
+    for (int t = 0; t < 9; ++t) {
+        const int ky = t / 3, kx = t % 3;
+        const int64_t off = (int64_t)(ky - 1) * (w + 2) + (kx - 1);
+        const float beta = t ? 1.0f : 0.0f;
+        Plan *p = t ? rest : first;
+        IRN_LT_TRY(hipblasLtMatmul(handle, p->desc, &alpha, wt + t * tap_bytes, p->a, a + off * (int64_t)row_bytes, p->b, &beta, out_dev, p->c,
+                                   out_dev, p->d, &p->algo[t ? r1 : r0].algo, workspace_dev, workspace_bytes, (hipStream_t)stream));
+    }
+    return IRN_OK;
+}
+
 }  // extern "C"

@@ -42,9 +42,26 @@ __global__ __launch_bounds__(kThreads) void split16_kernel(const float *__restri
     if (p >= n_pieces) return;
     unsigned row = p / pieces_per_row;
     const unsigned c0 = (p - row * pieces_per_row) * 8u;
-    const unsigned prow = pm.h ? padded_row(row, pm.h, pm.w) : row;
-    const f4v *src = reinterpret_cast<const f4v *>(x + (size_t)(pm.in_pad ? prow : row) * n_ch + c0);
-    if (pm.out_pad) row = prow;
+    const f4v *src;
+    if (pm.out_pad) {
+        // threads enumerate the rows of the BORDERED form: interior rows are split from their pixel, border rows are written as
+        // zeros here (the operand needs no zeroing by the caller and may come fresh from an allocator every call)
+        const unsigned hp = pm.h + 2u, wp = pm.w + 2u;
+        const unsigned n = row / (hp * wp), r = row - n * (hp * wp), yp = r / wp, xp = r - yp * wp;
+        if (yp == 0u || yp > pm.h || xp == 0u || xp > pm.w) {
+            _Float16 *dst = out + (size_t)row * (3u * n_ch) + c0;
+            const h8v z = {0, 0, 0, 0, 0, 0, 0, 0};
+            *reinterpret_cast<h8v *>(dst) = z;
+            *reinterpret_cast<h8v *>(dst + n_ch) = z;
+            *reinterpret_cast<h8v *>(dst + 2u * n_ch) = z;
+            return;
+        }
+        const unsigned dense = n * (pm.h * pm.w) + (yp - 1u) * pm.w + (xp - 1u);
+        src = reinterpret_cast<const f4v *>(x + (size_t)(pm.in_pad ? row : dense) * n_ch + c0);
+    } else {
+        const unsigned prow = pm.h ? padded_row(row, pm.h, pm.w) : row;
+        src = reinterpret_cast<const f4v *>(x + (size_t)(pm.in_pad ? prow : row) * n_ch + c0);
+    }
     f4v a = __builtin_nontemporal_load(src), b = __builtin_nontemporal_load(src + 1);
     float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
     if (BN) {
@@ -87,7 +104,9 @@ int split16_launch(const float *x_dev, const float *scale_dev, const float *shif
     if (n_pixels < 0 || n_channels <= 0 || (n_channels & 7)) return fail(IRN_ERR_ARG, "irn_split16: n_channels must be a positive multiple of 8");
     if (((uintptr_t)x_dev | (uintptr_t)out_dev | (uintptr_t)scale_dev | (uintptr_t)shift_dev) & 15u)
         return fail(IRN_ERR_ARG, "irn_split16: tensors and constants must be 16-byte aligned");
-    const int64_t numel = n_pixels * n_channels;
+    int64_t rows = n_pixels;                       // rows the threads enumerate: the bordered form's when it is the output
+    if (pm.out_pad) rows = n_pixels / ((int64_t)pm.h * pm.w) * (pm.h + 2) * (pm.w + 2);
+    const int64_t numel = rows * n_channels;
     if (numel == 0) return IRN_OK;
     if (numel >= (1ll << 31)) return fail(IRN_ERR_ARG, "irn_split16: %lld elements; at most 2^31 - 1 per call", (long long)numel);
     const unsigned n_pieces = (unsigned)(numel / 8), ppr = (unsigned)n_channels / 8u;

@@ -181,8 +181,9 @@ SPLIT_MIN_PLANES = int(os.environ.get("IRN_SPLIT_MIN_PLANES", "64"))
 SPLIT_MIN_INPUT = int(os.environ.get("IRN_SPLIT_MIN_INPUT", str(1 << 20)))
 #   conv2 (3x3, stride 1) of units with at least SPLIT_MIN_PLANES_3X3 planes on maps of at least SPLIT_MIN_ROWS_3X3 pixels per
 #       pass: nine accumulating split GEMMs on the zero-bordered operand (ops.conv3x3_split) — 1.7-2.2x MIOpen's fp32 convolution
-#       at 512 planes from 32x32 maps up, level at 16x16 and at 256 planes (profiles/r06_s6_conv3x3_split_probe.txt): stage 4 only.
-SPLIT_MIN_PLANES_3X3 = int(os.environ.get("IRN_SPLIT_MIN_PLANES_3X3", "512"))
+#       at 512 planes from 32x32 maps up, level at 16x16 and, in isolation, at 256 planes (profiles/r06_s6_conv3x3_split_probe.txt);
+#       end to end the 256-plane stage gains another 1.7 % (profiles/r06_s7_*): stages 3 and 4.
+SPLIT_MIN_PLANES_3X3 = int(os.environ.get("IRN_SPLIT_MIN_PLANES_3X3", "256"))
 SPLIT_MIN_ROWS_3X3 = int(os.environ.get("IRN_SPLIT_MIN_ROWS_3X3", "8192"))
 
 

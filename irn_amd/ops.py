@@ -390,15 +390,11 @@ def split_weight_3x3(w64):
     return torch.stack(taps).contiguous(), 2.0 ** -p
 
 
-_PAD_BUFS = {}         # (device, stream, n, c, h, w, cout) -> (zero-bordered fp16 operand, fp32 result), a few most recent shapes
-_PAD_BUFS_MAX = 6
-
-
 def split16_pad(x, shape, scale=None, shift=None, relu=False, in_padded=False, out=None):
     """`split16` between a dense map and its zero-bordered form (irn_split16_pad).  shape = (n, c, h, w) of the DENSE map.
     in_padded: `x` is the bordered fp32 form [n (h+2)(w+2), c] (a `conv3x3_split` result), the result is the dense fp16
     [n h w, 3c]; `out` given (a bordered fp16 buffer's interior view, borders already zero): `x` is a dense channels-last fp32
-    tensor and the split goes into the bordered form."""
+    tensor and the split goes into the bordered form, zero border rows included."""
     n, c, h, w_ = (int(v) for v in shape)
     _need_cuda(x, "x")
     if c % 8:
@@ -412,7 +408,7 @@ def split16_pad(x, shape, scale=None, shift=None, relu=False, in_padded=False, o
     if out is None:
         out = torch.empty((n * h * w_, 3 * c), dtype=torch.float16, device=x.device)
     elif out.dtype != torch.float16 or not out.is_contiguous() or out.numel() < n * (h + 2) * (w_ + 2) * 3 * c:
-        raise ValueError("split16_pad: out must be a contiguous fp16 buffer of the bordered form")
+        raise ValueError("split16_pad: out must be a contiguous fp16 buffer of the bordered form (its border rows are written too)")
     if n * h * w_ == 0:
         return out
     with torch.cuda.device(x.device):
@@ -424,36 +420,31 @@ def split16_pad(x, shape, scale=None, shift=None, relu=False, in_padded=False, o
 
 def conv3x3_split(x, w16, alpha):
     """3x3 / stride 1 / pad 1 convolution (no bias) of a channels-last fp32 activation [N, C, H, W] in the split-precision form,
-    WITHOUT materialising an im2col operand: the activation is split once into a zero-bordered fp16 matrix [N (H+2)(W+2), 3C];
-    there tap (ky, kx) is the same matrix shifted by (ky-1)(W+2) + (kx-1) rows, so the convolution is nine `gemm16_nhwc` calls
-    accumulating in fp32 (fixed order).  w16 = `split_weight_3x3` fp16 [9, cout, 3C].  -> the result in the bordered fp32 form
-    [N (H+2)(W+2), cout] (border rows hold garbage; `split16_pad(..., in_padded=True)` reads the interior).  Valid until the
-    next call with the same shape on this stream.  Reference: conv2 of Bottleneck.forward, net/resnet50.py:40."""
+    WITHOUT materialising an im2col operand: the activation is split once into a zero-bordered fp16 matrix [N (H+2)(W+2), 3C]
+    (irn_split16_pad writes the borders too); there tap (ky, kx) is the same matrix shifted by (ky-1)(W+2) + (kx-1) rows, so the
+    convolution is nine fp16 GEMMs accumulating in fp32 in a fixed order (irn_conv3x3_split_gemm, one call).  w16 =
+    `split_weight_3x3` fp16 [9, cout, 3C].  -> the result in the bordered fp32 form [N (H+2)(W+2), cout] (border rows hold
+    garbage; `split16_pad(..., in_padded=True)` reads the interior).  Reference: conv2 of Bottleneck.forward, net/resnet50.py:40."""
     _need_cuda(x, "x")
     n, c, h, w_ = (int(v) for v in x.shape)
     cout = int(w16.shape[1])
-    if tuple(w16.shape) != (9, cout, 3 * c) or w16.dtype != torch.float16 or not w16.is_contiguous():
-        raise ValueError("conv3x3_split: w16 must be a contiguous fp16 [9, cout, %d] tensor" % (3 * c))
-    hp, wp = h + 2, w_ + 2
-    m_pad, guard = n * hp * wp, wp + 1
-    key = (x.device.index, torch.cuda.current_stream(x.device).cuda_stream, n, c, h, w_, cout)
-    bufs = _PAD_BUFS.pop(key, None)
-    if bufs is None:
-        while len(_PAD_BUFS) >= _PAD_BUFS_MAX:
-            _PAD_BUFS.pop(next(iter(_PAD_BUFS)))
-        bufs = (torch.zeros((m_pad + 2 * guard, 3 * c), dtype=torch.float16, device=x.device),
-                torch.empty((m_pad, cout), dtype=torch.float32, device=x.device))
-    _PAD_BUFS[key] = bufs                         # most recent last
-    a_buf, out2d = bufs
-    out = out2d.view(1, m_pad, 1, cout).permute(0, 3, 1, 2)         # the same memory as a channels-last [1, cout, m_pad, 1] tensor
+    if tuple(w16.shape) != (9, cout, 3 * c) or w16.dtype != torch.float16 or not w16.is_contiguous() or w16.device != x.device:
+        raise ValueError("conv3x3_split: w16 must be a contiguous fp16 [9, cout, %d] tensor on %s" % (3 * c, x.device))
+    m_pad, guard = n * (h + 2) * (w_ + 2), w_ + 3
+    a_buf = torch.empty((m_pad + 2 * guard, 3 * c), dtype=torch.float16, device=x.device)        # guard rows: valid memory, any content
+    out = torch.empty((m_pad, cout), dtype=torch.float32, device=x.device)
+    if m_pad == 0:
+        return out
     split16_pad(x, (n, c, h, w_), out=a_buf[guard:])
-    t = 0
-    for ky in range(3):
-        for kx in range(3):
-            off = guard + (ky - 1) * wp + (kx - 1)
-            gemm16_nhwc(a_buf[off:off + m_pad], w16[t], (1, cout, m_pad, 1), residual=out if t else None, alpha=alpha, out=out)
-            t += 1
-    return out2d
+    dev = (x.device.index if x.device.index is not None else torch.cuda.current_device(), torch.cuda.current_stream(x.device).cuda_stream)
+    ws = _GEMM_WS.get(dev)
+    if ws is None:
+        ws = _GEMM_WS[dev] = torch.empty(int(lib.irn_conv1x1_workspace_bytes()), dtype=torch.uint8, device=x.device)
+    rank = gemm_ranks16().get((m_pad, 3 * c, cout, 0, 1, 0), 0)
+    with torch.cuda.device(x.device):
+        check(lib.irn_conv3x3_split_gemm(a_buf[guard:].data_ptr(), w16.data_ptr(), out.data_ptr(), n, h, w_, c, cout, float(alpha), int(rank),
+                                         ws.data_ptr(), ws.numel(), _stream()))
+    return out
 
 
 def conv1x1_algo_count(m, cin, cout, bias, residual, relu):

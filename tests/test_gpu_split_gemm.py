@@ -160,7 +160,7 @@ def test_bottleneck_split_path_vs_composed_modules_and_fp32_gemm_path(monkeypatc
             unit._gemm = None
             y_split = unit(_cl(x))
             p = unit.gemm_params()
-            assert ("w2_16" in p) == (planes >= 512)
+            assert ("w2_16" in p) == (planes >= r50.SPLIT_MIN_PLANES_3X3)
             assert "w3_16" in p and (("w1_16" in p) == (c_in * (planes + (4 * planes if project else 0)) >= 1 << 20))
             assert torch.equal(y_split, unit(_cl(x)))
             monkeypatch.setattr(r50, "SPLIT_GEMM", False)
