@@ -122,7 +122,8 @@ def test_conv3x3_as_nine_accumulating_split_gemms(n, c, cout, h, w):
     err, err32, scale = float((got - want).abs().max()), float((f32 - want).abs().max()), float(want.abs().max())
     print("3x3 %s -> %d: nine split GEMMs %.2e, MIOpen fp32 %.2e from fp64 (max |value| %.2f)" % ((n, c, h, w), cout, err, err32, scale))
     assert err <= 4.0 * err32 + 2e-6 * scale and err <= 1e-5 * max(1.0, scale)
-    first = pad.clone()
+    interior = lambda t: t.view(n, h + 2, w + 2, cout)[:, 1:-1, 1:-1]       # (border rows hold garbage by contract)
+    first = interior(pad).clone()
     # the bordered form through the tail pass: batch norm + ReLU + split of the interior == the same pass on the dense tensor
     scale_c, shift_c = (torch.rand(cout, generator=g) + 0.5).to(dev), torch.randn(cout, generator=g).to(dev)
     if cout % 8 == 0:
@@ -132,7 +133,7 @@ def test_conv3x3_as_nine_accumulating_split_gemms(n, c, cout, h, w):
         assert torch.equal(a, b)
     ops.conv3x3_split(_cl(torch.randn(1, c, h + 1, w + 2, generator=g).to(dev)), w16, alpha)       # another shape in between
     again = ops.conv3x3_split(xd, w16, alpha)
-    assert torch.equal(again, first)
+    assert torch.equal(interior(again), first)
     assert not ops.split_overflowed()
 
 
