@@ -314,11 +314,13 @@ int irn_split16(const float *x_dev, const float *scale_dev, const float *shift_d
  * irn_conv3x3_split_gemm: a16 dev fp16 = the bordered operand [n (h+2)(w+2), 3 cin] with (w+3) rows of valid memory in front of
  *   and behind it (any content), w16 dev fp16 [9, cout, 3 cin] (one irn_gemm16_nhwc operand per tap, raster order, one common
  *   scale), out dev fp32 [n (h+2)(w+2), cout] = alpha sum_taps a16[shifted] . w16[tap]^T, accumulated tap after tap in fp32 in a
- *   fixed order; border rows of `out` hold garbage.  algo_rank / workspace as irn_conv1x1_nhwc. */
+ *   fixed order; border rows of `out` hold garbage.  row_fused = 1: w16 = [3, cout, 9 cin] (the three taps of a kernel row side by
+ *   side) and THREE GEMMs over K = 9 cin — the taps (ky, 0..2) of a pixel are three consecutive memory rows, so a kernel row's
+ *   operand is the same buffer read with leading dimension 3 cin and 9 cin columns.  algo_rank / workspace as irn_conv1x1_nhwc. */
 int irn_split16_pad(const float *x_dev, const float *scale_dev, const float *shift_dev, int relu, void *out_dev, int64_t n_images,
                     int h, int w, int n_channels, int in_padded, int out_padded, unsigned *overflow_dev, void *stream);
 int irn_conv3x3_split_gemm(const void *a16_dev, const void *w16_dev, float *out_dev, int64_t n_images, int h, int w, int cin, int cout,
-                           float alpha, int algo_rank, void *workspace_dev, size_t workspace_bytes, void *stream);
+                           float alpha, int row_fused, int algo_rank, void *workspace_dev, size_t workspace_bytes, void *stream);
 int irn_gemm16_algo_count(int64_t m, int k, int cout, int has_bias, int has_residual, int relu, size_t workspace_bytes,
                           int *count_out);
 int irn_gemm16_nhwc(const void *a16_dev, const void *b16_dev, const float *bias_dev, const float *residual_dev, float *out_dev,

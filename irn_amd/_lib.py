@@ -64,7 +64,7 @@ _SIGS = {
     "irn_conv1x1_nhwc": (i32, [vp, vp, vp, vp, vp, i64, i32, i32, i32, i32, vp, sz, vp]),
     "irn_split16": (i32, [vp, vp, vp, i32, vp, i64, i32, vp, vp]),
     "irn_split16_pad": (i32, [vp, vp, vp, i32, vp, i64, i32, i32, i32, i32, i32, vp, vp]),
-    "irn_conv3x3_split_gemm": (i32, [vp, vp, vp, i64, i32, i32, i32, i32, f32, i32, vp, sz, vp]),
+    "irn_conv3x3_split_gemm": (i32, [vp, vp, vp, i64, i32, i32, i32, i32, f32, i32, i32, vp, sz, vp]),
     "irn_gemm16_algo_count": (i32, [i64, i32, i32, i32, i32, i32, sz, C.POINTER(i32)]),
     "irn_gemm16_nhwc": (i32, [vp, vp, vp, vp, vp, i64, i32, i32, i32, f32, i32, vp, sz, vp]),
     "irn_stem_pool": (i32, [vp, vp, vp, i64, i32, i32, i32, vp, vp]),

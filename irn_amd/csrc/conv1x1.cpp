@@ -32,8 +32,8 @@ struct Plan {
     int n_algos = 0;
 };
 
-// (device, m, cin, cout, bias, residual, relu, workspace, operand type: 0 fp32 / 1 fp16)
-using Key = std::tuple<int, int64_t, int, int, int, int, int, size_t, int>;
+// (device, m, cin, cout, bias, residual, relu, workspace, operand type: 0 fp32 / 1 fp16, leading dimension of x: 0 = cin)
+using Key = std::tuple<int, int64_t, int, int, int, int, int, size_t, int, int64_t>;
 
 std::mutex g_mu;
 std::map<int, hipblasLtHandle_t> g_handles;
@@ -74,8 +74,8 @@ int epilogue_of(bool bias, bool relu) {
 
 // caller holds g_mu
 int get_plan(hipblasLtHandle_t handle, int dev, int64_t m, int cin, int cout, bool bias, bool residual, bool relu,
-             size_t workspace_bytes, Plan **out, int f16 = 0) {
-    Key key(dev, m, cin, cout, bias, residual, relu, workspace_bytes, f16);
+             size_t workspace_bytes, Plan **out, int f16 = 0, int64_t ldx = 0) {
+    Key key(dev, m, cin, cout, bias, residual, relu, workspace_bytes, f16, ldx);
     const hipDataType ab_type = f16 ? HIP_R_16F : HIP_R_32F;      // operands; C / D / bias / scale stay fp32, fp32 accumulation
     auto it = g_plans.find(key);
     if (it != g_plans.end()) {
@@ -101,7 +101,8 @@ int get_plan(hipblasLtHandle_t handle, int dev, int64_t m, int cin, int cout, bo
     }
     // stored shapes (column-major): A = w [cin x cout], B = x [cin x m], C / D = [cout x m]
     IRN_LT_TRY(hipblasLtMatrixLayoutCreate(&p->a, ab_type, (uint64_t)cin, (uint64_t)cout, (int64_t)cin));
-    IRN_LT_TRY(hipblasLtMatrixLayoutCreate(&p->b, ab_type, (uint64_t)cin, (uint64_t)m, (int64_t)cin));
+    // ldx < cin: consecutive rows of x OVERLAP (row r = memory rows r .. r + cin/ldx - 1 of a narrower matrix): the row-fused 3x3
+    IRN_LT_TRY(hipblasLtMatrixLayoutCreate(&p->b, ab_type, (uint64_t)cin, (uint64_t)m, ldx ? ldx : (int64_t)cin));
     IRN_LT_TRY(hipblasLtMatrixLayoutCreate(&p->c, HIP_R_32F, (uint64_t)cout, (uint64_t)m, (int64_t)cout));
     IRN_LT_TRY(hipblasLtMatrixLayoutCreate(&p->d, HIP_R_32F, (uint64_t)cout, (uint64_t)m, (int64_t)cout));
     hipblasLtMatmulPreference_t pref = nullptr;
@@ -218,35 +219,41 @@ int irn_gemm16_nhwc(const void *a16_dev, const void *b16_dev, const float *bias_
     return IRN_OK;
 }
 
-// 3x3 / pad 1 / stride 1 convolution on the zero-bordered split operand (irn_split16_pad): nine accumulating GEMMs, one call.
+// 3x3 / pad 1 / stride 1 convolution on the zero-bordered split operand (irn_split16_pad), one call.
+//   row_fused = 0: nine accumulating GEMMs over K = 3 cin, w16 = [9, cout, 3 cin];
+//   row_fused = 1: THREE accumulating GEMMs over K = 9 cin, w16 = [3, cout, 9 cin] (the three taps of a kernel row side by side):
+//       the taps (ky, 0..2) of pixel r are the memory rows r + (ky-1)(w+2) - 1, +0, +1 — contiguous — so the operand of a kernel
+//       row is the SAME buffer read with leading dimension 3 cin and 9 cin columns (overlapping rows).  A third of the
+//       read-modify-write passes over the fp32 result (which were 40 % of the nine-GEMM form's time at 512 planes).
 int irn_conv3x3_split_gemm(const void *a16_dev, const void *w16_dev, float *out_dev, int64_t n_images, int h, int w, int cin, int cout,
-                           float alpha, int algo_rank, void *workspace_dev, size_t workspace_bytes, void *stream) {
+                           float alpha, int row_fused, int algo_rank, void *workspace_dev, size_t workspace_bytes, void *stream) {
     using namespace irn;
     if (!a16_dev || !w16_dev || !out_dev) return fail(IRN_ERR_ARG, "conv3x3_split_gemm: a16, w16 and out must not be NULL");
     if (n_images < 1 || h < 1 || w < 1) return fail(IRN_ERR_ARG, "conv3x3_split_gemm: n_images, h, w must be positive");
     const int64_t m = n_images * (h + 2) * (int64_t)(w + 2);
-    const int k = 3 * cin;
+    const int k1 = 3 * cin, k = row_fused ? 3 * k1 : k1, n_gemms = row_fused ? 3 : 9;
     if (int rc = check_shape(m, k, cout)) return rc;
-    if (k & 7) return fail(IRN_ERR_ARG, "conv3x3_split_gemm: cin = %d must be a multiple of 8", cin);
+    if (k1 & 7) return fail(IRN_ERR_ARG, "conv3x3_split_gemm: cin = %d must be a multiple of 8", cin);
     if (workspace_bytes && !workspace_dev) return fail(IRN_ERR_ARG, "conv3x3_split_gemm: workspace_bytes > 0 with a NULL workspace");
     int dev = 0;
     IRN_HIP_TRY(hipGetDevice(&dev));
     std::lock_guard<std::mutex> lk(g_mu);
     hipblasLtHandle_t handle;
     if (int rc = get_handle(dev, &handle)) return rc;
-    Plan *first = nullptr, *rest = nullptr;          // beta = 0 for the first tap, 1 (C = D = out) for the other eight
-    if (int rc = get_plan(handle, dev, m, k, cout, false, false, false, workspace_bytes, &first, 1)) return rc;
-    if (int rc = get_plan(handle, dev, m, k, cout, false, true, false, workspace_bytes, &rest, 1)) return rc;
-    if (int rc = get_plan(handle, dev, m, k, cout, false, false, false, workspace_bytes, &first, 1)) return rc;      // (the cache may have been emptied by the call above)
+    const int64_t ldx = row_fused ? k1 : 0;
+    Plan *first = nullptr, *rest = nullptr;          // beta = 0 for the first GEMM, 1 (C = D = out) for the others
+    if (int rc = get_plan(handle, dev, m, k, cout, false, false, false, workspace_bytes, &first, 1, ldx)) return rc;
+    if (int rc = get_plan(handle, dev, m, k, cout, false, true, false, workspace_bytes, &rest, 1, ldx)) return rc;
+    if (int rc = get_plan(handle, dev, m, k, cout, false, false, false, workspace_bytes, &first, 1, ldx)) return rc;      // (the cache may have been emptied by the call above)
     const int r0 = algo_rank >= 0 && algo_rank < first->n_algos ? algo_rank : 0, r1 = algo_rank >= 0 && algo_rank < rest->n_algos ? algo_rank : 0;
     const char *a = (const char *)a16_dev, *wt = (const char *)w16_dev;
-    const size_t row_bytes = (size_t)k * 2u, tap_bytes = (size_t)cout * k * 2u;
-    for (int t = 0; t < 9; ++t) {
-        const int ky = t / 3, kx = t % 3;
+    const size_t row_bytes = (size_t)k1 * 2u, w_bytes = (size_t)cout * k * 2u;
+    for (int t = 0; t < n_gemms; ++t) {
+        const int ky = row_fused ? t : t / 3, kx = row_fused ? 0 : t % 3;
         const int64_t off = (int64_t)(ky - 1) * (w + 2) + (kx - 1);
         const float beta = t ? 1.0f : 0.0f;
         Plan *p = t ? rest : first;
-        IRN_LT_TRY(hipblasLtMatmul(handle, p->desc, &alpha, wt + t * tap_bytes, p->a, a + off * (int64_t)row_bytes, p->b, &beta, out_dev, p->c,
+        IRN_LT_TRY(hipblasLtMatmul(handle, p->desc, &alpha, wt + t * w_bytes, p->a, a + off * (int64_t)row_bytes, p->b, &beta, out_dev, p->c,
                                    out_dev, p->d, &p->algo[t ? r1 : r0].algo, workspace_dev, workspace_bytes, (hipStream_t)stream));
     }
     return IRN_OK;

@@ -379,6 +379,10 @@ def split_weight(w64, p=None):
     return torch.cat([hi, lo, hi_s], dim=1).contiguous(), 2.0 ** -p
 
 
+# three GEMMs over 9 cin (row-fused) instead of nine over 3 cin: IRN_CONV3X3_ROW_FUSED=0 keeps the nine
+CONV3X3_ROW_FUSED = __import__("os").environ.get("IRN_CONV3X3_ROW_FUSED", "1") != "0"
+
+
 def split_weight_3x3(w64):
     """3x3 weight [cout, cin, 3, 3] (float64) -> (fp16 [9, cout, 3 cin]: one `split_weight` operand per tap (ky, kx) in raster
     order, one common exponent, alpha)."""
@@ -387,6 +391,8 @@ def split_weight_3x3(w64):
     top = float(w64.abs().max())
     p = 13 - int(math.floor(math.log2(top))) if top > 0 else 0
     taps = [split_weight(w64[:, :, ky, kx], p)[0] for ky in range(3) for kx in range(3)]
+    if CONV3X3_ROW_FUSED:      # [3, cout, 9 cin]: the three taps of a kernel row side by side (irn_conv3x3_split_gemm row_fused)
+        return torch.stack([torch.cat(taps[3 * ky:3 * ky + 3], dim=1) for ky in range(3)]).contiguous(), 2.0 ** -p
     return torch.stack(taps).contiguous(), 2.0 ** -p
 
 
@@ -428,8 +434,9 @@ def conv3x3_split(x, w16, alpha):
     _need_cuda(x, "x")
     n, c, h, w_ = (int(v) for v in x.shape)
     cout = int(w16.shape[1])
-    if tuple(w16.shape) != (9, cout, 3 * c) or w16.dtype != torch.float16 or not w16.is_contiguous() or w16.device != x.device:
-        raise ValueError("conv3x3_split: w16 must be a contiguous fp16 [9, cout, %d] tensor on %s" % (3 * c, x.device))
+    fused = int(w16.shape[0]) == 3
+    if tuple(w16.shape) not in ((9, cout, 3 * c), (3, cout, 9 * c)) or w16.dtype != torch.float16 or not w16.is_contiguous() or w16.device != x.device:
+        raise ValueError("conv3x3_split: w16 must be a contiguous fp16 [9, cout, %d] or [3, cout, %d] tensor on %s" % (3 * c, 9 * c, x.device))
     m_pad, guard = n * (h + 2) * (w_ + 2), w_ + 3
     a_buf = torch.empty((m_pad + 2 * guard, 3 * c), dtype=torch.float16, device=x.device)        # guard rows: valid memory, any content
     out = torch.empty((m_pad, cout), dtype=torch.float32, device=x.device)
@@ -440,9 +447,9 @@ def conv3x3_split(x, w16, alpha):
     ws = _GEMM_WS.get(dev)
     if ws is None:
         ws = _GEMM_WS[dev] = torch.empty(int(lib.irn_conv1x1_workspace_bytes()), dtype=torch.uint8, device=x.device)
-    rank = gemm_ranks16().get((m_pad, 3 * c, cout, 0, 1, 0), 0)
+    rank = 0 if fused else gemm_ranks16().get((m_pad, 3 * c, cout, 0, 1, 0), 0)
     with torch.cuda.device(x.device):
-        check(lib.irn_conv3x3_split_gemm(a_buf[guard:].data_ptr(), w16.data_ptr(), out.data_ptr(), n, h, w_, c, cout, float(alpha), int(rank),
+        check(lib.irn_conv3x3_split_gemm(a_buf[guard:].data_ptr(), w16.data_ptr(), out.data_ptr(), n, h, w_, c, cout, float(alpha), 1 if fused else 0, int(rank),
                                          ws.data_ptr(), ws.numel(), _stream()))
     return out
 

@@ -100,9 +100,11 @@ def test_split_gemm_equals_the_exact_expression_like_the_fp32_gemm(case, bias, r
         assert out.data_ptr() == buf.data_ptr() and torch.equal(out, got)
 
 
+@pytest.mark.parametrize("fused", [True, False])
 @pytest.mark.parametrize("n,c,cout,h,w", [(2, 64, 32, 9, 11), (1, 512, 512, 16, 16), (3, 128, 256, 7, 5), (2, 8, 8, 1, 1), (1, 16, 8, 1, 6)])
-def test_conv3x3_as_nine_accumulating_split_gemms(n, c, cout, h, w):
-    """ops.conv3x3_split (irn_split16_pad + 9 x irn_gemm16_nhwc on row-shifted views of the zero-bordered operand) against the
+def test_conv3x3_as_nine_accumulating_split_gemms(n, c, cout, h, w, fused, monkeypatch):
+    """ops.conv3x3_split (irn_split16_pad + irn_conv3x3_split_gemm: nine GEMMs over 3 cin, or — row-fused, the default — three over
+    9 cin reading the same zero-bordered operand with overlapping rows) against the
     exact 3x3 / pad 1 convolution, at the accuracy of MIOpen's fp32 convolution; the bordered result read back through the
     batch-norm + ReLU + split pass equals the dense one; same bits on every call, also after other shapes used the buffers."""
     import torch.nn.functional as F
@@ -112,15 +114,16 @@ def test_conv3x3_as_nine_accumulating_split_gemms(n, c, cout, h, w):
     x = torch.relu(torch.randn(n, c, h, w, generator=g)) * 2.0
     wt = torch.randn(cout, c, 3, 3, generator=g) / (9 * c) ** 0.5
     want = F.conv2d(x.double(), wt.double(), None, 1, 1)
+    monkeypatch.setattr(ops, "CONV3X3_ROW_FUSED", fused)
     w16, alpha = ops.split_weight_3x3(wt.double().to(dev))
-    assert w16.shape == (9, cout, 3 * c)
+    assert w16.shape == ((3, cout, 9 * c) if fused else (9, cout, 3 * c))
     xd = _cl(x.to(dev))
     pad = ops.conv3x3_split(xd, w16, alpha)
     assert pad.shape == (n * (h + 2) * (w + 2), cout)
     got = pad.view(n, h + 2, w + 2, cout)[:, 1:-1, 1:-1].permute(0, 3, 1, 2).cpu().double()
     f32 = F.conv2d(xd, _cl(wt.to(dev)), None, 1, 1).cpu().double()
     err, err32, scale = float((got - want).abs().max()), float((f32 - want).abs().max()), float(want.abs().max())
-    print("3x3 %s -> %d: nine split GEMMs %.2e, MIOpen fp32 %.2e from fp64 (max |value| %.2f)" % ((n, c, h, w), cout, err, err32, scale))
+    print("3x3 %s -> %d (%s): split GEMMs %.2e, MIOpen fp32 %.2e from fp64 (max |value| %.2f)" % ((n, c, h, w), cout, "three over 9 cin" if fused else "nine over 3 cin", err, err32, scale))
     assert err <= 4.0 * err32 + 2e-6 * scale and err <= 1e-5 * max(1.0, scale)
     interior = lambda t: t.view(n, h + 2, w + 2, cout)[:, 1:-1, 1:-1]       # (border rows hold garbage by contract)
     first = interior(pad).clone()
