@@ -84,6 +84,8 @@ def parse(argv=None):
                     help="e2e / steps: record persistent walks that were re-run on the streaming sweeps instead of failing the run (ranks "
                          "sharing one device, a co-tenant on the GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-traffic", action="store_true",
+                    help="do not re-measure roofline.traffic (two short rocprofv3 --pmc passes of this script, ~40 s): use profiles/traffic_<workload>.json")
     ap.add_argument("--no-legs", action="store_true", help="skip the short secondary runs (cam, e2e, steps, walk_r5, ins, coco)")
     ap.add_argument("--legs", default="walk_voc,walk_voc_r5,walk_r5,walk_plain,ins,ins_r10,coco,cam,e2e,cam_fp32,e2e_fp32,steps,steps_voc")
     ap.add_argument("--legs-budget-s", type=float, default=240.0,
@@ -708,7 +710,50 @@ LEG_RUNS = {   # short runs for the `legs` object of the default line: (steps, w
 }
 
 
-def roofline_object(a, workload, r):
+def measure_traffic(a, workload, batch):
+    """HBM bytes of ONE launch of the dominant kernel, measured now: two rocprofv3 passes of this very script (`--pmc FETCH_SIZE`,
+    then `--pmc WRITE_SIZE` — separate passes, counters only, as /opt/skills/guides/MI355X_MICROARCH.md prescribes) with one
+    step and no warm-up, i.e. exactly one launch of `resident_kernel`; FETCH_SIZE doubled (gfx950 reports half the bytes of wide
+    reads).  -> (bytes, detail) or (None, why)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    prof = shutil.which("rocprofv3")
+    if not prof:
+        return None, "rocprofv3 not on PATH"
+    tmp = tempfile.mkdtemp(prefix="irn_pmc_")
+    kb = {}
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(tmp, counter)
+            cmd = [prof, "--pmc", counter, "-d", out, "-o", "t", "-f", "csv", "--", sys.executable, os.path.abspath(__file__), "--workload", workload,
+                   "--batch", str(batch), "--steps", "1", "--warmup", "0", "--no-legs", "--no-cpu-baseline", "--no-traffic", "--variant", str(a.variant),
+                   "--accel", str(a.accel)]
+            env = dict(os.environ, TMPDIR="/tmp")
+            res = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=240)
+            if res.returncode != 0:
+                return None, "rocprofv3 --pmc %s failed (rc %d)" % (counter, res.returncode)
+            tot, launches = 0.0, set()
+            for f in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
+                for row in csv.DictReader(open(f)):
+                    if "resident_kernel" in row.get("Kernel_Name", "") and row.get("Counter_Name") == counter:
+                        tot += float(row.get("Counter_Value", 0) or 0)
+                        launches.add(row.get("Dispatch_Id"))
+            if not launches:
+                return None, "no resident_kernel dispatch in the %s pass" % counter
+            kb[counter] = tot / len(launches)
+        hbm = (2.0 * kb["FETCH_SIZE"] + kb["WRITE_SIZE"]) * 1024.0
+        return hbm, "measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes of one launch each; FETCH_SIZE %.0f KB raw (doubled), WRITE_SIZE %.0f KB" % (
+            kb["FETCH_SIZE"], kb["WRITE_SIZE"])
+    except Exception as e:          # noqa: BLE001 — never lose the bench line to the counters
+        return None, repr(e)[:200]
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+def roofline_object(a, workload, r, live_traffic=None):
     if workload not in WALK_WORKLOADS:
         return None
     sec = r["avg_launch_ms"] * 1e-3
@@ -727,6 +772,12 @@ def roofline_object(a, workload, r):
                     workload, tj.get("session", "see profiles/README.md"))
         except Exception:
             traffic = None
+    source = None if traffic is None else "static"
+    if live_traffic is not None:
+        if live_traffic[0] is not None:
+            traffic, traffic_src, source = live_traffic[0], live_traffic[1], "measured"
+        elif traffic_src:
+            traffic_src += "; live measurement unavailable: %s" % live_traffic[1]
     resident = a.variant == 2
     kernel = ("resident_kernel<%d> (weights-stationary persistent walk: one launch = the whole walk of the batch)" % r["radius"]) if resident else \
              ("sweep_blocked_kernel<%d,CH> (one operator application over the batch = 1 launch per channel-chunk width)" % r["radius"])
@@ -753,7 +804,7 @@ def roofline_object(a, workload, r):
         top = dict(hbm)
         top["bound"] = "hbm"
         top["fp32_vector"] = fma
-    top.update({"traffic": traffic, "traffic_source": None if traffic is None else "static", "traffic_detail": traffic_src, "kernel": kernel, "avg_launch_ms": r["avg_launch_ms"],
+    top.update({"traffic": traffic, "traffic_source": source, "traffic_detail": traffic_src, "kernel": kernel, "avg_launch_ms": r["avg_launch_ms"],
                 "sweeps_per_launch": r["sweeps_per_launch"], "launches_timed": r["launches_timed"],
                 "sweep_share_of_step": r["sweep_share_of_step"],
                 "schedule": {"n_sweeps": r["n_sweeps"], "operator_applications": r["n_applied"],
@@ -844,8 +895,13 @@ def main(argv=None):
                                          "devices": (a.rank_devices or "one per rank (LOCAL_RANK)"),
                                          "note": getattr(dist, "note", None),
                                          "used_for": "barrier + max-over-ranks of the timed region only"}},
-            "roofline": roofline_object(a, a.workload, r),
+            "roofline": None,
         }
+        live = None
+        if world == 1 and a.workload == "walk" and a.variant == 2 and not a.no_traffic and not a.no_legs:
+            torch.cuda.synchronize()
+            live = measure_traffic(a, a.workload, r["batch"])      # (a child process on the same GPU; this one is idle meanwhile)
+        res["roofline"] = roofline_object(a, a.workload, r, live)
         if "shapes" in r:
             res["config"].update({"variant": a.variant, "mean_channels": float(np.mean([s[2] for s in r["shapes"]])),
                                   "walk_self_checks": r.get("tuning")})

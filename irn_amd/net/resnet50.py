@@ -180,10 +180,13 @@ SPLIT_GEMM = os.environ.get("IRN_SPLIT_GEMM", "1") != "0"
 SPLIT_MIN_PLANES = int(os.environ.get("IRN_SPLIT_MIN_PLANES", "64"))
 SPLIT_MIN_INPUT = int(os.environ.get("IRN_SPLIT_MIN_INPUT", str(1 << 20)))
 #   conv2 (3x3, stride 1) of units with at least SPLIT_MIN_PLANES_3X3 planes on maps of at least SPLIT_MIN_ROWS_3X3 pixels per
-#       pass: nine accumulating split GEMMs on the zero-bordered operand (ops.conv3x3_split) — 1.7-2.2x MIOpen's fp32 convolution
-#       at 512 planes from 32x32 maps up, level at 16x16 and, in isolation, at 256 planes (profiles/r06_s6_conv3x3_split_probe.txt);
-#       end to end the 256-plane stage gains another 1.7 % (profiles/r06_s7_*): stages 3 and 4.
-SPLIT_MIN_PLANES_3X3 = int(os.environ.get("IRN_SPLIT_MIN_PLANES_3X3", "256"))
+#       pass: accumulating split GEMMs on row-shifted views of ONE zero-bordered operand (ops.conv3x3_split), no im2col — nine
+#       over 3 cin, or (default) three over 9 cin: the three taps of a kernel row are consecutive memory rows, so the operand of a
+#       kernel row is the same buffer read with overlapping rows (leading dimension 3 cin, 9 cin columns).  Against MIOpen's
+#       fp32 convolution at 512 planes: 1.7-2.2x for the nine (profiles/r06_s6_conv3x3_split_probe.txt); end to end `cam` 133.6 ->
+#       153.0 (nine) -> 164.6 (three) -> 166.0 with the 128-plane stage included, 158.5 with the 64-plane one too
+#       (profiles/r06_s9_conv3x3_row_fused_ab.txt): stages 2-4.
+SPLIT_MIN_PLANES_3X3 = int(os.environ.get("IRN_SPLIT_MIN_PLANES_3X3", "128"))
 SPLIT_MIN_ROWS_3X3 = int(os.environ.get("IRN_SPLIT_MIN_ROWS_3X3", "8192"))
 
 

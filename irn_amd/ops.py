@@ -321,6 +321,28 @@ def gemm_ranks16():
     return _GEMM_RANKS16
 
 
+_GEMM_RANKS3X3 = None
+
+
+def gemm_ranks3x3():
+    """`ranks3x3` of the shipped table: (rows of the bordered operand, cin, cout) -> entry of hipBLASLt's list for the row-fused 3x3
+    split convolution (irn_conv3x3_split_gemm), measured by tools/gemm16_tune.py; unlisted problems use entry 0."""
+    global _GEMM_RANKS3X3
+    if _GEMM_RANKS3X3 is None:
+        ranks = {}
+        try:
+            import json
+            import os
+            from .step import _common
+            path = os.path.join(_common.gemm_table_root(), _common.miopen_cache_key() + ".json")
+            if os.path.exists(path) and os.environ.get("IRN_GEMM_TABLE", "1") != "0":
+                ranks = {tuple(int(v) for v in k.split(",")): int(r) for k, r in json.load(open(path)).get("ranks3x3", {}).items()}
+        except Exception:
+            ranks = {}
+        _GEMM_RANKS3X3 = ranks
+    return _GEMM_RANKS3X3
+
+
 def gemm16_nhwc(a16, b16, shape, bias=None, residual=None, relu=False, alpha=1.0, out=None, algo_rank=None):
     """act(alpha * a16 . b16^T + bias (+ residual)) as a channels-last fp32 [N, cout, H, W] tensor of `shape` (irn_gemm16_nhwc):
     a16 fp16 [N*H*W, k] from `split16`, b16 fp16 [cout, k] = [w_hi | w_lo | w_hi 2^-11] of the weight scaled by 1 / alpha."""
@@ -424,7 +446,7 @@ def split16_pad(x, shape, scale=None, shift=None, relu=False, in_padded=False, o
     return out
 
 
-def conv3x3_split(x, w16, alpha):
+def conv3x3_split(x, w16, alpha, algo_rank=None):
     """3x3 / stride 1 / pad 1 convolution (no bias) of a channels-last fp32 activation [N, C, H, W] in the split-precision form,
     WITHOUT materialising an im2col operand: the activation is split once into a zero-bordered fp16 matrix [N (H+2)(W+2), 3C]
     (irn_split16_pad writes the borders too); there tap (ky, kx) is the same matrix shifted by (ky-1)(W+2) + (kx-1) rows, so the
@@ -447,7 +469,9 @@ def conv3x3_split(x, w16, alpha):
     ws = _GEMM_WS.get(dev)
     if ws is None:
         ws = _GEMM_WS[dev] = torch.empty(int(lib.irn_conv1x1_workspace_bytes()), dtype=torch.uint8, device=x.device)
-    rank = 0 if fused else gemm_ranks16().get((m_pad, 3 * c, cout, 0, 1, 0), 0)
+    rank = algo_rank
+    if rank is None:
+        rank = gemm_ranks3x3().get((m_pad, c, cout), 0) if fused else gemm_ranks16().get((m_pad, 3 * c, cout, 0, 1, 0), 0)
     with torch.cuda.device(x.device):
         check(lib.irn_conv3x3_split_gemm(a_buf[guard:].data_ptr(), w16.data_ptr(), out.data_ptr(), n, h, w_, c, cout, float(alpha), 1 if fused else 0, int(rank),
                                          ws.data_ptr(), ws.numel(), _stream()))

@@ -466,13 +466,20 @@ def test_bench_contract_one_json_line():
     # round 5 hygiene: no image twice in the timed batch, the traffic figure says where it comes from, the CPU is named, the
     # ragged leg reports how the persistent launch packed it and that nothing fell back, the backbone leg says which trunk ran
     assert r["config"]["images_per_gpu_per_step"] == 8
-    assert rf["traffic_source"] in (None, "static") and (rf["traffic"] is None) == (rf["traffic_source"] is None)
+    # round 6: re-measured inside the run (two rocprofv3 --pmc passes of one launch each) when rocprofv3 is there, else the static figure
+    assert rf["traffic_source"] in (None, "static", "measured") and (rf["traffic"] is None) == (rf["traffic_source"] is None)
+    import shutil
+    if shutil.which("rocprofv3"):
+        assert rf["traffic_source"] == "measured" and 0 < rf["traffic"] < rf["hbm_equivalent"]["algorithmic_bytes_per_launch"], rf.get("traffic_detail")
     assert isinstance(cb["cpu_model"], str) and cb["cpu_model"]
     wv = r["legs"]["walk_voc"]
     assert wv["value"] > 0 and wv["rounds"] > 0 and wv["fallback_runs"] == 0 and wv["grid_pixels"] > 0
     trunk = r["legs"]["cam"]["trunk"]
     assert trunk["layout"] in ("channels_last", "nchw") and trunk["fused_1x1_gemm"] == (trunk["layout"] == "channels_last")
     assert trunk["deterministic"] is True and trunk["miopen_key"].endswith("-det") and r["legs"]["cam"]["value"] > 0      # the default mode
+    assert trunk["split_precision_1x1"] == (trunk["layout"] == "channels_last") and 0 < r["legs"]["cam"]["matrix_fp32_frac"] < 2
+    cc = cb["cam"]                      # round 6: the CAM half of the metric on the host cores, beside legs.cam
+    assert cc["kind"] == "port" and cc["value"] > 0 and cc["cores"] == cb["cores"] and abs(cc["gflop_per_image"] - 974.04) < 0.01
 
 
 def test_upload_never_blocks_and_equals_cuda():

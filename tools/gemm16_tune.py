@@ -62,6 +62,15 @@ def main():
         return real(a16, b16, shape, bias, residual, relu, alpha, out, algo_rank)
 
     ops.gemm16_nhwc = spy
+    convs = {}
+    real3 = ops.conv3x3_split
+
+    def spy3(x, w16, alpha, algo_rank=None):
+        n, c, h, w = (int(v) for v in x.shape)
+        convs[(n, c, h, w, int(w16.shape[1]))] = convs.get((n, c, h, w, int(w16.shape[1])), 0) + 1
+        return real3(x, w16, alpha, algo_rank)
+
+    ops.conv3x3_split = spy3
     with torch.no_grad():
         for size in a.sizes.split(","):
             h, w = (int(v) for v in size.split("x"))
@@ -70,6 +79,7 @@ def main():
             irn.forward_batch([torch.randn(2, 3, h, w, device=dev) for _ in range(a.batch)])
     torch.cuda.synchronize()
     ops.gemm16_nhwc = real
+    ops.conv3x3_split = real3
     lines = ["# split-precision GEMMs (fp16 operands, fp32 accumulation): ms per call for hipBLASLt's first pick and for the best of its list",
              "%9s %6s %5s %3s %3s %4s %5s | %8s %5s %8s | %9s" % ("m", "k", "cout", "b", "res", "relu", "calls", "gemm[0]", "best", "gemm[k]", "max|diff|")]
     ranks, tot0, totk = {}, 0.0, 0.0
@@ -104,12 +114,41 @@ def main():
         totk += times[best if times[best] < 0.97 * times[0] else 0] * problems[key]
         lines.append("%9d %6d %5d %3d %3d %4d %5d | %8.4f %5d %8.4f | %9.2e" % (m, k, cout, hb, hr, relu, problems[key], times[0], best, times[best], diff))
     lines.append("# %d problems; all calls with the first pick %.3f ms, with the table %.3f ms; %d table entries" % (len(problems), tot0, totk, len(ranks)))
+    # the row-fused 3x3 split convolutions: the rank applies to its three GEMMs (the heuristic list of the accumulating one)
+    ranks3, t30, t3k = {}, 0.0, 0.0
+    lines.append("# row-fused 3x3 split convolutions: (n, cin, h, w, cout), calls | ms with the first pick, best rank, ms with it")
+    for (n, c, h, w, cout), calls in sorted(convs.items()):
+        g = torch.Generator(device=dev).manual_seed(n + c + h + w)
+        x = torch.relu(torch.randn(n, c, h, w, device=dev, generator=g)).contiguous(memory_format=torch.channels_last)
+        w16, alpha = ops.split_weight_3x3(torch.randn(cout, c, 3, 3, device=dev, generator=g).double() * 0.02)
+        m_pad = n * (h + 2) * (w + 2)
+        n_algo = ops.gemm16_algo_count(m_pad, 9 * c, cout, 0, 1, 0)          # (an upper bound: the overlapping-row layout may offer fewer)
+        inner = lambda t: t.view(n, h + 2, w + 2, cout)[:, 1:-1, 1:-1]
+        ref = inner(ops.conv3x3_split(x, w16, alpha, algo_rank=0)).clone()
+        times = []
+        for r in range(n_algo):
+            try:
+                got = inner(ops.conv3x3_split(x, w16, alpha, algo_rank=r))
+                if float((got - ref).abs().max() / ref.abs().max().clamp_min(1e-30)) > 1e-5:
+                    times.append(float("inf"))
+                    continue
+                times.append(time_ms(lambda: ops.conv3x3_split(x, w16, alpha, algo_rank=r), n=10))
+            except Exception as ex:      # noqa: BLE001
+                times.append(float("inf"))
+        best = min(range(n_algo), key=lambda r: times[r])
+        if times[best] < 0.97 * times[0]:
+            ranks3["%d,%d,%d" % (m_pad, c, cout)] = best
+        t30 += times[0] * calls
+        t3k += times[best if times[best] < 0.97 * times[0] else 0] * calls
+        lines.append("%s %3d | %8.4f %3d %8.4f" % ((n, c, h, w, cout), calls, times[0], best, times[best]))
+    lines.append("# %d 3x3 problems; all calls with the first pick %.3f ms, with the table %.3f ms; %d table entries" % (len(convs), t30, t3k, len(ranks3)))
     open(os.path.join(a.out, "gemm16_tune.txt"), "w").write("\n".join(lines) + "\n")
     print("\n".join(lines[-12:]))
     if a.write:
         path = os.path.join(_common.gemm_table_root(), _common.miopen_cache_key() + ".json")
         table = json.load(open(path)) if os.path.exists(path) else {"ranks": {}}
         table["ranks16"] = ranks
+        table["ranks3x3"] = ranks3
         json.dump(table, open(path, "w"), indent=0, sort_keys=True)
         json.dump(table, open(os.path.join(a.out, os.path.basename(path)), "w"), indent=0, sort_keys=True)      # travels back with gpurun_out
         print("wrote", path, "(copy in", a.out + ")")
