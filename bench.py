@@ -733,8 +733,8 @@ def measure_traffic(a, workload, batch):
                    "--accel", str(a.accel)]
             env = dict(os.environ, TMPDIR="/tmp")
             res = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=240)
-            if res.returncode != 0:
-                return None, "rocprofv3 --pmc %s failed (rc %d)" % (counter, res.returncode)
+            # (the exit status is not the criterion: on this image the profiled python process can die in an exit handler AFTER
+            # rocprofv3 has written its tables — what counts is whether the kernel's counter rows are there)
             tot, launches = 0.0, set()
             for f in glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True):
                 for row in csv.DictReader(open(f)):
@@ -742,7 +742,7 @@ def measure_traffic(a, workload, batch):
                         tot += float(row.get("Counter_Value", 0) or 0)
                         launches.add(row.get("Dispatch_Id"))
             if not launches:
-                return None, "no resident_kernel dispatch in the %s pass" % counter
+                return None, "no resident_kernel dispatch in the %s pass (rocprofv3 rc %d)" % (counter, res.returncode)
             kb[counter] = tot / len(launches)
         hbm = (2.0 * kb["FETCH_SIZE"] + kb["WRITE_SIZE"]) * 1024.0
         return hbm, "measured in this run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes of one launch each; FETCH_SIZE %.0f KB raw (doubled), WRITE_SIZE %.0f KB" % (

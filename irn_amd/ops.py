@@ -446,6 +446,9 @@ def split16_pad(x, shape, scale=None, shift=None, relu=False, in_padded=False, o
     return out
 
 
+_ROW_FUSED_REFUSED = False
+
+
 def conv3x3_split(x, w16, alpha, algo_rank=None):
     """3x3 / stride 1 / pad 1 convolution (no bias) of a channels-last fp32 activation [N, C, H, W] in the split-precision form,
     WITHOUT materialising an im2col operand: the activation is split once into a zero-bordered fp16 matrix [N (H+2)(W+2), 3C]
@@ -472,8 +475,22 @@ def conv3x3_split(x, w16, alpha, algo_rank=None):
     rank = algo_rank
     if rank is None:
         rank = gemm_ranks3x3().get((m_pad, c, cout), 0) if fused else gemm_ranks16().get((m_pad, 3 * c, cout, 0, 1, 0), 0)
+    global _ROW_FUSED_REFUSED
     with torch.cuda.device(x.device):
-        check(lib.irn_conv3x3_split_gemm(a_buf[guard:].data_ptr(), w16.data_ptr(), out.data_ptr(), n, h, w_, c, cout, float(alpha), 1 if fused else 0, int(rank),
+        if fused and not _ROW_FUSED_REFUSED:
+            rc = lib.irn_conv3x3_split_gemm(a_buf[guard:].data_ptr(), w16.data_ptr(), out.data_ptr(), n, h, w_, c, cout, float(alpha), 1, int(rank),
+                                            ws.data_ptr(), ws.numel(), _stream())
+            if rc == 0:
+                return out
+            # this hipBLASLt build does not take an operand with overlapping rows: the nine-GEMM form computes the same sums
+            _ROW_FUSED_REFUSED = True
+            import warnings
+            warnings.warn("irn_amd: hipBLASLt refused the row-fused 3x3 operand (%s); using nine GEMMs per 3x3 convolution (~7 %% slower "
+                          "backbones)" % lib.irn_last_error().decode(errors="replace"), RuntimeWarning)
+        if fused:                                   # [3, cout, 9c] -> [9, cout, 3c]: the same taps, one per GEMM
+            w16 = w16.view(3, cout, 3, 3 * c).permute(0, 2, 1, 3).reshape(9, cout, 3 * c).contiguous()
+            rank = 0
+        check(lib.irn_conv3x3_split_gemm(a_buf[guard:].data_ptr(), w16.data_ptr(), out.data_ptr(), n, h, w_, c, cout, float(alpha), 0, int(rank),
                                          ws.data_ptr(), ws.numel(), _stream()))
     return out
 
