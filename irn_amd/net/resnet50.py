@@ -365,8 +365,11 @@ class Bottleneck(nn.Module):
 
     def _forward_gemm(self, x):
         """Channels-last inference path: conv1 and conv3 are GEMMs over the [pixels, channels] matrix the activation
-        already is, with batch norm, residual and ReLU in their epilogue (`ops.conv1x1_nhwc`) — no elementwise pass is
-        left around them; the 3x3 convolution stays on MIOpen with its one in-place `bn_act_` pass."""
+        already is, with batch norm, residual and ReLU in their epilogue — fp32 (`ops.conv1x1_nhwc`) or, where `gemm_params`
+        prepared the fp16 hi/lo weight operands, in split precision (`ops.gemm16_nhwc` on `ops.split16`'s operand; module
+        comment above SPLIT_GEMM).  The 3x3 convolution is MIOpen's with one in-place `bn_act_` pass behind it, or — stride 1,
+        >= SPLIT_MIN_PLANES_3X3 planes — three accumulating split GEMMs on a zero-bordered operand (`ops.conv3x3_split`) whose
+        bordered result feeds bn2 + ReLU + the split for conv3 in one pass."""
         from .. import ops
         p = self.gemm_params()
         x3 = ops.split16(x) if "w1_16" in p else None                     # the block input as fp16 hi/lo (it stays fp32 too: the residual)

@@ -55,11 +55,6 @@ constexpr int find_s(int lo, int hi, int dx) {
     return -1;
 }
 
-template <int CTRL>
-__device__ __forceinline__ float dpp0(float v) {      // out-of-row sources read 0
-    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
-}
-
 // ---- mode 2: windows from LDS, next row's window ahead of this row's FMAs ----
 template <int QI, int RI>
 __device__ __forceinline__ void win_load(f4a (&w)[7], const float *arow) {
