@@ -856,3 +856,44 @@ def test_instance_step_pipeline_order(monkeypatch):
     # a batch is collected one turn after its back half: its detections cross PCIe under the next batch's kernels
     assert stages.index(("write", "a")) > stages.index(("front", "b")) and stages.index(("write", "b")) > stages.index(("front", "c"))
     assert [w[2] for w in log if w[0] == "write"] == ["pending-a1", "pending-b1", "pending-c1"]
+
+
+def test_split_weight_operands_reconstruct_the_weight_to_22_bits_and_the_split_product_is_fp32_grade():
+    """The host half of the split-precision convolutions (irn_amd/ops.py split_weight[_3x3]; reference net/resnet50.py:34-54 with
+    FixedBatchNorm folded in): [w_hi | w_lo | w_hi 2^-11] of w 2^p reconstructs w to 2^-22 of the layer's largest weight, every
+    entry stays inside fp16's range, the taps of a 3x3 weight share one exponent in both operand layouts — and the product the GPU
+    forms with them, emulated here in numpy (fp16 operands, exact products, wide accumulation), is as close to the exact one as a
+    correctly rounded fp32 dot product."""
+    from irn_amd import ops
+    g = torch.Generator().manual_seed(4)
+    for cout, cin, spread in ((64, 256, 1.0), (512, 128, 1e-3), (8, 16, 30.0)):
+        w = torch.randn(cout, cin, generator=g).double() * spread * torch.rand(cout, 1, generator=g).double()
+        b16, alpha = ops.split_weight(w)
+        assert b16.dtype == torch.float16 and b16.shape == (cout, 3 * cin) and float(b16.float().abs().max()) < 2.0 ** 14
+        hi, lo, his = b16[:, :cin].double(), b16[:, cin:2 * cin].double(), b16[:, 2 * cin:].double()
+        # the scaled copy is exact for every weight above 2^-17 of the largest, and off by at most half a subnormal step below
+        assert float((his - hi * 2.0 ** -11).abs().max()) <= 2.0 ** -25 and torch.equal(his[hi.abs() >= 0.125], (hi * 2.0 ** -11)[hi.abs() >= 0.125])
+        rec = (hi + lo) * alpha
+        assert float((rec - w).abs().max()) <= 2.0 ** -22 * float(w.abs().max())
+        # the activation side as irn_split16 forms it, and the three-term product
+        x = torch.relu(torch.randn(40, cin, generator=g)).float() * 5.0
+        xh = x.to(torch.float16)
+        xl = ((x - xh.float()) * 2048.0).to(torch.float16)
+        a16 = torch.cat([xh, xh, xl], dim=1).double()
+        got = alpha * (a16 @ b16.double().t())
+        want = x.double() @ w.t()
+        f32 = (x @ w.float().t()).double()
+        scale = float(want.abs().max())
+        assert float((got - want).abs().max()) <= 4e-7 * scale and float((got - want).abs().max()) <= 2.0 * float((f32 - want).abs().max()) + 1e-7 * scale
+    w3 = torch.randn(16, 8, 3, 3, generator=g).double() * 0.1
+    for fused, shape in ((False, (9, 16, 24)), (True, (3, 16, 72))):
+        ops.CONV3X3_ROW_FUSED, saved = fused, ops.CONV3X3_ROW_FUSED
+        try:
+            t16, a3 = ops.split_weight_3x3(w3)
+        finally:
+            ops.CONV3X3_ROW_FUSED = saved
+        assert tuple(t16.shape) == shape
+        taps = t16.view(3, 16, 3, 24).permute(0, 2, 1, 3).reshape(9, 16, 24) if fused else t16
+        for t in range(9):
+            rec = (taps[t][:, :8].double() + taps[t][:, 8:16].double()) * a3
+            assert float((rec - w3[:, :, t // 3, t % 3]).abs().max()) <= 2.0 ** -22 * float(w3.abs().max())
