@@ -103,12 +103,12 @@ def test_run_sample_four_workers_write_the_files_of_one_on_a_mixed_tree(tmp_path
     torch.save(weights.random_irn_state(2), tmp_path / "res50_irn.pth")
     lst = str(tmp_path / "lists" / "train.txt")
 
-    def run(tag, devices):
+    def run(tag, devices, *extra):
         cmd = [sys.executable, os.path.join(ROOT, "run_sample.py"), "--voc12_root", str(root), "--train_list", lst, "--infer_list", lst,
                "--num_workers", "4", "--cam_weights_name", str(tmp_path / "res50_cam"), "--irn_weights_name", str(tmp_path / "res50_irn.pth"),
                "--cam_out_dir", str(tmp_path / (tag + "_cam")), "--sem_seg_out_dir", str(tmp_path / (tag + "_sem")),
                "--ins_seg_out_dir", str(tmp_path / (tag + "_ins")), "--log_name", str(tmp_path / (tag + "_log")),
-               "--cam_scales", "1.0", "0.5", "--beta", "10", "--exp_times", "8", "--worker_devices", devices, "--step_timeout", "900"]
+               "--cam_scales", "1.0", "0.5", "--beta", "10", "--exp_times", "8", "--worker_devices", devices, "--step_timeout", "900"] + list(extra)
         t0 = time.time()
         out = subprocess.run(cmd, env=_clean_env(IRN_DETERMINISTIC="1", IRN_MIOPEN_CACHE=str(tmp_path / ("miopen_" + tag))),
                              capture_output=True, text=True, timeout=1200, cwd=ROOT)
@@ -117,6 +117,7 @@ def test_run_sample_four_workers_write_the_files_of_one_on_a_mixed_tree(tmp_path
 
     four, t4 = run("four", "0,0,0,0")
     one, t1 = run("one", "0")
+    fp32, _ = run("fp32", "0", "--split_gemm", "0")          # the same tree with plain fp32 GEMMs / MIOpen 3x3 convolutions
     starts = [l for l in four.stderr.splitlines() if "irn_amd worker " in l]
     nchw = [l for l in (four.stderr + one.stderr).splitlines() if "trunk passes ran NCHW" in l]
     print("run_sample.py on %d images of 5 sizes: four workers %.0f s, one worker %.0f s; %d start-up lines; NCHW reports: %s" % (
@@ -144,6 +145,18 @@ def test_run_sample_four_workers_write_the_files_of_one_on_a_mixed_tree(tmp_path
             n_det += len(da["class"])
     print("four workers vs one worker, default batch sizes, tuned + untuned sizes: %d CAM files, %d label pixels, %d detections bit-identical"
           % (len(names), n_px, n_det))
+    # the arithmetic switch: split-precision (default) against fp32 backbones on the same tree — CAMs inside the 1e-4 bar of the north
+    # star with an order of magnitude to spare (both are ~1e-5 from fp64); label pixels that differ are reported, not bounded: each
+    # run's labels are proven against the oracle on its own inputs in tests/test_gpu_steps.py
+    dev, n_lab = 0.0, 0
+    for n in names:
+        a = np.load(tmp_path / "one_cam" / (n + ".npy"), allow_pickle=True).item()
+        b = np.load(tmp_path / "fp32_cam" / (n + ".npy"), allow_pickle=True).item()
+        assert torch.equal(a["keys"], b["keys"])
+        dev = max(dev, float((a["cam"] - b["cam"]).abs().max()), float(np.abs(a["high_res"] - b["high_res"]).max()))
+        n_lab += int((np.asarray(Image.open(tmp_path / "one_sem" / (n + ".png"))) != np.asarray(Image.open(tmp_path / "fp32_sem" / (n + ".png")))).sum())
+    print("split-precision vs fp32 backbones on the same tree: max |CAM difference| %.2e (bar 1e-4), %d of %d label pixels differ" % (dev, n_lab, n_px))
+    assert dev <= 5e-5, dev
 
 
 def _rccl_rank(rank, world, port, q):
