@@ -897,3 +897,27 @@ def test_split_weight_operands_reconstruct_the_weight_to_22_bits_and_the_split_p
         for t in range(9):
             rec = (taps[t][:, :8].double() + taps[t][:, 8:16].double()) * a3
             assert float((rec - w3[:, :, t // 3, t % 3]).abs().max()) <= 2.0 ** -22 * float(w3.abs().max())
+
+
+def test_warmup_tool_picks_the_untuned_sizes_of_a_dataset(tmp_path):
+    """tools/miopen_warmup.py --from-list: the (H, W) histogram of a list's images from their JPEG headers, most frequent first,
+    minus what the shipped channels-last database covers, until the requested share of the images has a tuned size."""
+    import argparse
+    import importlib.util
+    from PIL import Image
+    root = tmp_path / "voc"
+    (root / "JPEGImages").mkdir(parents=True)
+    sizes = [(375, 500)] * 5 + [(300, 420)] * 3 + [(123, 77)] * 2 + [(64, 64)]
+    names = []
+    for i, (h, w) in enumerate(sizes):
+        names.append("2011_%06d" % i)
+        Image.new("RGB", (w, h)).save(root / "JPEGImages" / (names[-1] + ".jpg"))
+    (tmp_path / "list.txt").write_text("\n".join(names) + "\n")
+    spec = importlib.util.spec_from_file_location("miopen_warmup", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "miopen_warmup.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    shipped = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "irn_amd", "data", "miopen")
+    a = argparse.Namespace(from_list=str(tmp_path / "list.txt"), voc12_root=str(root), coverage=0.9, max_sizes=40, out=shipped)
+    assert mod.sizes_of_list(a) == "300x420,123x77"          # 375x500 is shipped; 8 + 2 of 11 images >= 90 %; 64x64 not needed
+    a.coverage, a.max_sizes = 1.0, 1
+    assert mod.sizes_of_list(a) == "300x420"

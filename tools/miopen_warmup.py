@@ -2,6 +2,9 @@
 """Fill MIOpen's find database for the shape set of the label-generation steps and ship it with the package.
 
     python tools/miopen_warmup.py [--out irn_amd/data/miopen] [--batch 8] [--sizes 512x512,375x500] [--find-mode 1]
+    python tools/miopen_warmup.py --channels-last 1 --single 0 --from-list voc12/train_aug.txt --voc12_root /data/VOC2012 --coverage 0.98
+        (the image sizes of YOUR dataset, read from the JPEG headers, most frequent first until `--coverage` of the images is
+        covered; sizes the shipped database already knows are skipped; ~40 s of GPU per size; then tools/miopen_det_filter.py)
 
 Runs the CAM network at the four scales (image + flip pairs, `--batch` pairs per trunk pass like make_cam) and the IRNet
 forward (`--batch` padded images per pass like the label steps) with MIOpen's FIND api enabled (PyTorch's
@@ -21,6 +24,39 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
+def sizes_of_list(a):
+    """The (H, W) histogram of the images named in `--from-list` (sizes from the JPEG headers, nothing is decoded), most frequent
+    first, minus the sizes the shipped channels-last database already covers, until `--coverage` of the images is covered."""
+    import collections
+    import json
+    from PIL import Image
+    from irn_amd.voc12 import dataloader
+    names = [l.strip().split()[0] for l in open(a.from_list) if l.strip()]
+    names = [os.path.splitext(os.path.basename(n))[0] for n in names]
+    hist = collections.Counter()
+    for n in names:
+        with Image.open(dataloader.get_img_path(n, a.voc12_root)) as im:
+            w, h = im.size
+        hist[(h, w)] += 1
+    tuned = set()
+    for d in sorted(os.listdir(a.out)) if os.path.isdir(a.out) else []:
+        path = os.path.join(a.out, d, "nhwc_shapes.json")
+        if os.path.exists(path) and not d.endswith("-det"):
+            tuned |= {(int(v[1]), int(v[2])) for v in json.load(open(path))}
+    total, covered, todo = sum(hist.values()), 0, []
+    for (h, w), c in hist.most_common():
+        if covered >= a.coverage * total or len(todo) >= a.max_sizes:
+            break
+        covered += c
+        if (h, w) not in tuned:
+            todo.append("%dx%d" % (h, w))
+    print("%d images, %d distinct sizes; %d sizes cover %.1f %% of them, %d of those are new: %s" % (
+        total, len(hist), len(todo) + sum(1 for s in hist if s in tuned), 100.0 * covered / max(total, 1), len(todo), ",".join(todo)), flush=True)
+    if not todo:
+        raise SystemExit("nothing to tune")
+    return ",".join(todo)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default=os.path.join(ROOT, "irn_amd", "data", "miopen"))
@@ -34,7 +70,13 @@ def main():
                     help="1: tune under MIOpen's deterministic attribute (round 5 measured: no fast NHWC fp32 solver survives it).  The "
                          "reproducible mode's database is DERIVED from the fast one instead: run tools/miopen_det_filter.py afterwards")
     ap.add_argument("--fused-gemm", type=int, default=1, help="the trunk's stride-1 1x1 convolutions are hipBLASLt GEMMs (not MIOpen problems)")
+    ap.add_argument("--from-list", default=None, help="an image list of the reference's format (voc12/train_aug.txt): tune the sizes that occur in it")
+    ap.add_argument("--voc12_root", default=None, help="dataset root of --from-list (JPEGImages/<name>.jpg)")
+    ap.add_argument("--coverage", type=float, default=0.98, help="--from-list: stop when this fraction of the images has a tuned size")
+    ap.add_argument("--max-sizes", type=int, default=40, help="--from-list: at most this many new sizes")
     a = ap.parse_args()
+    if a.from_list:
+        a.sizes = sizes_of_list(a)
     db = tempfile.mkdtemp(prefix="irn_miopen_warm_")
     os.environ["MIOPEN_USER_DB_PATH"] = db
     os.environ["MIOPEN_FIND_MODE"] = a.find_mode
