@@ -208,7 +208,7 @@ def untuned_report(reset=True):
         return ""
     top = sorted(sizes.items(), key=lambda kv: -kv[1])
     return ("irn_amd: %d of %d trunk passes ran NCHW (~0.8x) because their network-input size is not in the tuned database: %s%s"
-            "%s; tools/miopen_warmup.py --channels-last 1 --sizes ... adds sizes" % (
+            "%s; tools/miopen_warmup.py --channels-last 1 --sizes ... (or --from-list <image list>) adds sizes" % (
                 n_nchw, n_nchw + n_cl, ", ".join("%s x%d" % kv for kv in top[:8]), ", ... (%d sizes)" % len(top) if len(top) > 8 else "",
                 "; %d zero rows filled partial passes" % pad if pad else ""))
 
