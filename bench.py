@@ -733,7 +733,7 @@ def measure_traffic(a, workload, batch):
                    "--batch", str(batch), "--steps", "1", "--warmup", "0", "--no-legs", "--no-cpu-baseline", "--no-traffic", "--variant", str(a.variant),
                    "--accel", str(a.accel)]
             env = dict(os.environ, TMPDIR="/tmp")
-            res = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=240)
+            res = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=90)        # (a pass takes ~15 s)
             # (the exit status is not the criterion: on this image the profiled python process can die in an exit handler AFTER
             # rocprofv3 has written its tables — what counts is whether the kernel's counter rows are there)
             tot, launches = 0.0, set()
