@@ -733,7 +733,15 @@ def measure_traffic(a, workload, batch):
                    "--batch", str(batch), "--steps", "1", "--warmup", "0", "--no-legs", "--no-cpu-baseline", "--no-traffic", "--variant", str(a.variant),
                    "--accel", str(a.accel)]
             env = dict(os.environ, TMPDIR="/tmp")
-            res = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=90)        # (a pass takes ~15 s)
+            proc = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, start_new_session=True)
+            try:
+                proc.wait(timeout=90)                          # (a pass takes ~15 s)
+            except subprocess.TimeoutExpired:
+                import signal
+                os.killpg(proc.pid, signal.SIGKILL)            # exactly the process group started above (profiler + its python child)
+                proc.wait()
+                return None, "rocprofv3 --pmc %s did not finish within 90 s" % counter
+            res = proc
             # (the exit status is not the criterion: on this image the profiled python process can die in an exit handler AFTER
             # rocprofv3 has written its tables — what counts is whether the kernel's counter rows are there)
             tot, launches = 0.0, set()
