@@ -182,3 +182,55 @@ def test_bottleneck_split_path_vs_composed_modules_and_fp32_gemm_path(monkeypatc
         scale = float(y_ref.abs().max())
         print("unit %d -> %d planes, project %s: split path %.2e, fp32 GEMM path %.2e from fp64 (max |value| %.2f)" % (c_in, planes, project, e_split, e_f32, scale))
         assert e_split <= 4.0 * e_f32 + 1e-6 * scale and e_split <= 2e-5 * max(1.0, scale)
+
+
+def test_production_passes_vs_the_reference_goldens(golden, monkeypatch):
+    """The trunk exactly as the steps run it — 16-row channels-last passes, split-precision 1x1 GEMMs, row-fused split 3x3 in
+    stages 2-4 — against the REFERENCE's own CPU forwards (tests/golden/nets512.npz, nets_scales.npz: net/resnet50_cam.py:55-70,
+    net/resnet50_irn.py:216-234 run by tests/golden/make_golden.py) at the north star's 1e-4: CAM at 256^2 / 512^2 / 1024^2 with
+    the golden pair among seven others, EdgeDisplacement with ragged images padded to the 512^2 crop."""
+    from irn_amd import ops, synth
+    from irn_amd.net import resnet50 as r50, resnet50_cam, resnet50_irn, weights
+    dev = _dev()
+    monkeypatch.setattr(r50, "CHANNELS_LAST_MODE", "1")
+    monkeypatch.setattr(r50, "SPLIT_GEMM", True)
+    calls = {"gemm16": 0, "conv3x3": 0}
+    real16, real3 = ops.gemm16_nhwc, ops.conv3x3_split
+    monkeypatch.setattr(ops, "gemm16_nhwc", lambda *a, **k: (calls.__setitem__("gemm16", calls["gemm16"] + 1), real16(*a, **k))[1])
+    monkeypatch.setattr(ops, "conv3x3_split", lambda *a, **k: (calls.__setitem__("conv3x3", calls["conv3x3"] + 1), real3(*a, **k))[1])
+    cam = resnet50_cam.CAM()
+    cam.load_state_dict(weights.random_cam_state(seed=1), strict=True)
+    cam = cam.to(dev).eval()
+    norm = lambda t: t / (t.max(axis=(1, 2), keepdims=True) + 1e-5)
+    rel = lambda a, ref: float(np.abs(a - ref).max() / max(1.0, np.abs(ref).max()))
+    for gname, key in (("nets512", "cam512"), ("nets_scales", "cam256"), ("nets_scales", "cam1024")):
+        g = golden(gname)
+        h, w, seed = (int(v) for v in g[key + "_seed"])
+        pairs = [torch.from_numpy(synth.image_pair(h, w, seed + 100 * i)) for i in range(8)]       # pair 0 is the reference's input
+        before = dict(calls)
+        with torch.no_grad():
+            y = cam.forward_batch(torch.cat(pairs[3:] + pairs[:3]).to(dev)).cpu().numpy()          # ... at position 5 of the pass
+        assert calls["gemm16"] - before["gemm16"] >= 16 and calls["conv3x3"] - before["conv3x3"] >= (11 if h >= 512 else 3), (key, calls)      # the stride-1 3x3 of stages 2-4: 3 + 5 + 3 units (at 256^2 only stage 2 has >= 8192 rows)
+        ref = g[key + "_out"]
+        e_abs, e_norm = rel(y[5], ref), float(np.abs(norm(y[5]) - norm(ref)).max())
+        print("%s in a 16-row split-precision pass: %.2e relative, %.2e on the normalised CAM (bar 1e-4)" % (key, e_abs, e_norm))
+        assert y.shape == (8,) + ref.shape and e_abs <= 1e-4 and e_norm <= 1e-4, (key, e_abs, e_norm)
+    g5 = golden("nets512")
+    irn = resnet50_irn.EdgeDisplacement(crop_size=512)
+    irn.load_state_dict(weights.random_irn_state(seed=2), strict=False)
+    irn = irn.to(dev).eval()
+    keys = ("irn", "irn512", "irn", "irn512", "irn", "irn", "irn512", "irn")
+    items = []
+    for key in keys:
+        h, w, seed = (int(v) for v in g5[key + "_seed"])
+        items.append(torch.from_numpy(synth.image_pair(h, w, seed)).to(dev))
+    before = dict(calls)
+    with torch.no_grad():
+        outs = irn.forward_batch(items)
+    assert calls["conv3x3"] - before["conv3x3"] >= 11
+    worst = 0.0
+    for key, (edge, dp) in zip(keys, outs):
+        worst = max(worst, float(np.abs(edge.cpu().numpy() - g5[key + "_edge"]).max()), rel(dp.cpu().numpy(), g5[key + "_dp"]))
+    print("EdgeDisplacement, 8 ragged images in one split-precision pass: worst deviation from the reference %.2e (bar 1e-4)" % worst)
+    assert worst <= 1e-4
+    assert not ops.split_overflowed()
