@@ -11,6 +11,7 @@ Reference functions mirrored (names kept where the reference has one):
 GPU tensors in, GPU tensors out; no CPU fallback.
 """
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -402,7 +403,7 @@ def split_weight(w64, p=None):
 
 
 # three GEMMs over 9 cin (row-fused) instead of nine over 3 cin: IRN_CONV3X3_ROW_FUSED=0 keeps the nine
-CONV3X3_ROW_FUSED = __import__("os").environ.get("IRN_CONV3X3_ROW_FUSED", "1") != "0"
+CONV3X3_ROW_FUSED = os.environ.get("IRN_CONV3X3_ROW_FUSED", "1") != "0"
 
 
 def split_weight_3x3(w64):
